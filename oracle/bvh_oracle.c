@@ -1,0 +1,156 @@
+/*
+ * bvh_oracle.c — CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).  See bvh_oracle.h.
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off -fopenmp; no -ffast-math)
+ */
+#include "bvh_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------- f32 instantiation ------------------------------- */
+#define T float
+#define S(x) x##_f32
+#define NODE orc_node_f32
+#define FLAT orc_flat_f32
+#define RAY orc_ray_f32
+#define T_EPS FLT_EPSILON
+#define T_SQRT sqrtf
+#include "oracle_impl.inc"
+#undef T
+#undef S
+#undef NODE
+#undef FLAT
+#undef RAY
+#undef T_EPS
+#undef T_SQRT
+
+/* ------------------------------- f64 instantiation ------------------------------- */
+#define T double
+#define S(x) x##_f64
+#define NODE orc_node_f64
+#define FLAT orc_flat_f64
+#define RAY orc_ray_f64
+#define T_EPS DBL_EPSILON
+#define T_SQRT sqrt
+#include "oracle_impl.inc"
+#undef T
+#undef S
+#undef NODE
+#undef FLAT
+#undef RAY
+#undef T_EPS
+#undef T_SQRT
+
+/* ------------------------------- testbase.rs generators ------------------------------- */
+
+/* splitmix64 — testbase.rs:558-564 */
+uint64_t orc_splitmix64(uint64_t *x) {
+    *x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = *x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+/* next_point3_raw — testbase.rs:567-573 (a, b are i64; rotate_left is a 64-bit rotate) */
+void orc_next_point3_raw(uint64_t *seed, int32_t out[3]) {
+    uint64_t u = orc_splitmix64(seed);
+    int64_t a = (int64_t)((u >> 32) & 0xFFFFFFFFull) - 0x80000000ll;
+    int64_t b = (int64_t)(u & 0xFFFFFFFFull) - 0x80000000ll;
+    uint64_t ub = (uint64_t)b;
+    uint64_t rot = (ub << 6) | (ub >> 58);
+    int64_t c = a ^ (int64_t)rot;
+    out[0] = (int32_t)a;
+    out[1] = (int32_t)b;
+    out[2] = (int32_t)(uint32_t)(uint64_t)c; /* `as i32` truncates to the low 32 bits */
+}
+
+/* next_point3 — testbase.rs:576-595 */
+void orc_next_point3(uint64_t *seed, const float bounds[6], float out[3]) {
+    int32_t r[3];
+    orc_next_point3_raw(seed, r);
+    const float imax = (float)INT32_MAX; /* i32::MAX as f32 = 2147483648.0 */
+    for (int k = 0; k < 3; k++) {
+        float q = (float)r[k] / imax;
+        float fv = (q + 1.0f) * 0.5f;
+        float size = bounds[3 + k] - bounds[k];
+        float off = fv * size;
+        out[k] = bounds[k] + off;
+    }
+}
+
+static void tri_aabb(const float *t, float *box) { /* Triangle::new — testbase.rs:325-333 */
+    float b[6];
+    aabb_empty_f32(b);
+    aabb_grow_f32(b, t);
+    aabb_grow_f32(b, t + 3);
+    aabb_grow_f32(b, t + 6);
+    memcpy(box, b, sizeof b);
+}
+
+/* push_cube — testbase.rs:490-554 (vertex order preserved) */
+static void push_cube(const float pos[3], float *tris /* 12*9 */) {
+    /* corner offsets: tfr, tbr, tbl, tfl, bfr, bbr, bbl, bfl */
+    static const float off[8][3] = {
+        { 0.5f, 0.5f, -0.5f }, { 0.5f, 0.5f, 0.5f }, { -0.5f, 0.5f, 0.5f }, { -0.5f, 0.5f, -0.5f },
+        { 0.5f, -0.5f, -0.5f }, { 0.5f, -0.5f, 0.5f }, { -0.5f, -0.5f, 0.5f }, { -0.5f, -0.5f, -0.5f } };
+    enum { TFR, TBR, TBL, TFL, BFR, BBR, BBL, BFL };
+    static const int tri[12][3] = {
+        { TBR, TFR, TFL }, { TFL, TBL, TBR }, { BFL, BFR, BBR }, { BBR, BBL, BFL },
+        { TBL, TFL, BFL }, { BFL, BBL, TBL }, { BFR, TFR, TBR }, { TBR, BBR, BFR },
+        { TFL, TFR, BFR }, { BFR, BFL, TFL }, { BBR, TBR, TBL }, { TBL, BBL, BBR } };
+    float v[8][3];
+    for (int c = 0; c < 8; c++)
+        for (int k = 0; k < 3; k++) v[c][k] = pos[k] + off[c][k];
+    for (int t = 0; t < 12; t++)
+        for (int j = 0; j < 3; j++)
+            for (int k = 0; k < 3; k++) tris[t * 9 + j * 3 + k] = v[tri[t][j]][k];
+}
+
+/* create_n_cubes — testbase.rs:608-615 (seed 0) */
+void orc_create_n_cubes(size_t n_cubes, const float bounds[6], float *tris, float *aabbs) {
+    uint64_t seed = 0;
+    for (size_t i = 0; i < n_cubes; i++) {
+        float pos[3];
+        orc_next_point3(&seed, bounds, pos);
+        push_cube(pos, tris + i * 12 * 9);
+        for (int t = 0; t < 12; t++) tri_aabb(tris + (i * 12 + t) * 9, aabbs + (i * 12 + t) * 6);
+    }
+}
+
+/* create_ray — testbase.rs:687-691; the bench starts the stream at seed 0 (:825).
+ * splitmix64's state after k draws is k*GAMMA, so ray `first` starts at state 2*first*GAMMA. */
+void orc_create_rays(uint64_t first, size_t n, const float bounds[6], orc_ray_f32 *rays) {
+    uint64_t seed = 2ull * first * 0x9E3779B97F4A7C15ull;
+    for (size_t i = 0; i < n; i++) {
+        float o[3], d[3];
+        orc_next_point3(&seed, bounds, o);
+        orc_next_point3(&seed, bounds, d);
+        orc_ray_new_f32(o, d, &rays[i]);
+    }
+}
+
+/* generate_aligned_boxes + UnitBox::aabb — testbase.rs:109-116, 84-89 */
+void orc_aligned_boxes(float *aabbs) {
+    int i = 0;
+    for (int x = -10; x < 11; x++, i++) {
+        float pos[3] = { (float)x, 0.0f, 0.0f };
+        for (int k = 0; k < 3; k++) {
+            aabbs[i * 6 + k] = pos[k] + -0.5f;
+            aabbs[i * 6 + 3 + k] = pos[k] + 0.5f;
+        }
+    }
+}

@@ -1,0 +1,251 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; never from the product package bvh_amd/.
+Parity pin status: see the header of oracle/bvh_oracle.h ("partially pinned").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+NONE = 0xFFFFFFFF
+
+NODE_F32 = np.dtype([("l_min", "<f4", 3), ("l_max", "<f4", 3), ("r_min", "<f4", 3), ("r_max", "<f4", 3),
+                     ("parent", "<u4"), ("l", "<u4"), ("r", "<u4"), ("shape", "<u4")])
+NODE_F64 = np.dtype([("l_min", "<f8", 3), ("l_max", "<f8", 3), ("r_min", "<f8", 3), ("r_max", "<f8", 3),
+                     ("parent", "<u4"), ("l", "<u4"), ("r", "<u4"), ("shape", "<u4")])
+FLAT_F32 = np.dtype([("min", "<f4", 3), ("max", "<f4", 3), ("entry", "<u4"), ("exit", "<u4"), ("shape", "<u4")])
+FLAT_F64 = np.dtype([("min", "<f8", 3), ("max", "<f8", 3), ("entry", "<u4"), ("exit", "<u4"), ("shape", "<u4"),
+                     ("_pad", "<u4")])
+RAY_F32 = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("inv", "<f4", 3)])
+RAY_F64 = np.dtype([("o", "<f8", 3), ("d", "<f8", 3), ("inv", "<f8", 3)])
+assert NODE_F32.itemsize == 64 and NODE_F64.itemsize == 112
+assert FLAT_F32.itemsize == 36 and FLAT_F64.itemsize == 64
+assert RAY_F32.itemsize == 36 and RAY_F64.itemsize == 72
+
+DEFAULT_BOUNDS = np.array([-100000.0] * 3 + [100000.0] * 3, dtype=np.float32)  # testbase.rs:598-603
+
+
+class TravStats(C.Structure):
+    _fields_ = [("visited", C.c_uint64), ("leaf_visits", C.c_uint64), ("hits", C.c_uint64),
+                ("max_visited", C.c_uint64)]
+
+
+def build_library(force: bool = False) -> str:
+    src = [os.path.join(_HERE, f) for f in ("bvh_oracle.c", "oracle_impl.inc", "bvh_oracle.h")]
+    stale = force or not os.path.exists(_SO) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)
+    if stale and all(os.path.exists(s) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build_library()
+        _lib = C.CDLL(_SO)
+        _lib.orc_splitmix64.restype = C.c_uint64
+        _lib.orc_max_threads.restype = C.c_int
+        for s, ct in (("f32", C.c_float), ("f64", C.c_double)):
+            getattr(_lib, f"orc_surface_area_{s}").restype = ct
+            getattr(_lib, f"orc_ray_triangle_{s}").restype = ct
+            getattr(_lib, f"orc_flatten_{s}").restype = C.c_size_t
+            getattr(_lib, f"orc_traverse_flat_{s}").restype = C.c_uint64
+            getattr(_lib, f"orc_traverse_tree_{s}").restype = C.c_uint64
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _sfx(dtype):
+    return "f32" if np.dtype(dtype) == np.float32 else "f64"
+
+
+def _types(s):
+    return (np.float32, NODE_F32, FLAT_F32, RAY_F32) if s == "f32" else (np.float64, NODE_F64, FLAT_F64, RAY_F64)
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
+
+
+# ---------------------------------------------------------------- generators
+def create_n_cubes(n_cubes: int, bounds=DEFAULT_BOUNDS):
+    tris = np.empty((n_cubes * 12, 3, 3), dtype=np.float32)
+    aabbs = np.empty((n_cubes * 12, 6), dtype=np.float32)
+    b = np.ascontiguousarray(bounds, dtype=np.float32)
+    lib().orc_create_n_cubes(C.c_size_t(n_cubes), _p(b), _p(tris), _p(aabbs))
+    return tris, aabbs
+
+
+def create_rays(first: int, n: int, bounds=DEFAULT_BOUNDS):
+    rays = np.empty(n, dtype=RAY_F32)
+    b = np.ascontiguousarray(bounds, dtype=np.float32)
+    lib().orc_create_rays(C.c_uint64(first), C.c_size_t(n), _p(b), _p(rays))
+    return rays
+
+
+def aligned_boxes():
+    a = np.empty((21, 6), dtype=np.float32)
+    lib().orc_aligned_boxes(_p(a))
+    return a
+
+
+def make_rays(origins, dirs, dtype=np.float32):
+    s = _sfx(dtype)
+    ft, _, _, rt = _types(s)
+    o = np.ascontiguousarray(origins, dtype=ft).reshape(-1, 3)
+    d = np.ascontiguousarray(dirs, dtype=ft).reshape(-1, 3)
+    rays = np.empty(len(o), dtype=rt)
+    f = getattr(lib(), f"orc_ray_new_{s}")
+    for i in range(len(o)):
+        f(_p(o[i]), _p(d[i]), C.c_void_p(rays.ctypes.data + i * rt.itemsize))
+    return rays
+
+
+# ---------------------------------------------------------------- primitives
+def ray_intersects_aabb(ray, box) -> bool:
+    s = "f32" if ray.dtype == RAY_F32 else "f64"
+    ft = _types(s)[0]
+    b = np.ascontiguousarray(box, dtype=ft).reshape(6)
+    r = np.ascontiguousarray(ray).reshape(1)
+    return bool(getattr(lib(), f"orc_ray_intersects_aabb_{s}")(_p(r), _p(b)))
+
+
+def ray_slice(ray, box):
+    s = "f32" if ray.dtype == RAY_F32 else "f64"
+    ft = _types(s)[0]
+    b = np.ascontiguousarray(box, dtype=ft).reshape(6)
+    r = np.ascontiguousarray(ray).reshape(1)
+    out = np.zeros(2, dtype=ft)
+    ok = getattr(lib(), f"orc_ray_slice_{s}")(_p(r), _p(b), _p(out))
+    return (out[0], out[1]) if ok else None
+
+
+def ray_triangle(ray, a, b, c):
+    s = "f32" if ray.dtype == RAY_F32 else "f64"
+    ft = _types(s)[0]
+    r = np.ascontiguousarray(ray).reshape(1)
+    a, b, c = (np.ascontiguousarray(v, dtype=ft).reshape(3) for v in (a, b, c))
+    uv = np.zeros(2, dtype=ft)
+    d = getattr(lib(), f"orc_ray_triangle_{s}")(_p(r), _p(a), _p(b), _p(c), _p(uv))
+    return ft(d), uv[0], uv[1]
+
+
+def surface_area(box, dtype=np.float32):
+    s = _sfx(dtype)
+    b = np.ascontiguousarray(box, dtype=dtype).reshape(6)
+    return getattr(lib(), f"orc_surface_area_{s}")(_p(b))
+
+
+def center(box, dtype=np.float32):
+    s = _sfx(dtype)
+    b = np.ascontiguousarray(box, dtype=dtype).reshape(6)
+    out = np.zeros(3, dtype=dtype)
+    getattr(lib(), f"orc_center_{s}")(_p(b), _p(out))
+    return out
+
+
+def largest_axis(box, dtype=np.float32):
+    s = _sfx(dtype)
+    b = np.ascontiguousarray(box, dtype=dtype).reshape(6)
+    return int(getattr(lib(), f"orc_largest_axis_{s}")(_p(b)))
+
+
+# ---------------------------------------------------------------- build / flatten / traverse
+@dataclass
+class Tree:
+    nodes: np.ndarray
+    shape_node: np.ndarray
+
+
+def build(aabbs, parallel: bool = False) -> Tree:
+    s = _sfx(aabbs.dtype)
+    ft, nt, _, _ = _types(s)
+    a = np.ascontiguousarray(aabbs, dtype=ft).reshape(-1, 6)
+    n = len(a)
+    nodes = np.zeros(max(2 * n - 1, 0), dtype=nt)
+    shape_node = np.zeros(n, dtype=np.uint32)
+    fn = getattr(lib(), f"orc_build_par_{s}" if parallel else f"orc_build_{s}")
+    rc = fn(_p(a), C.c_size_t(n), _p(nodes), _p(shape_node))
+    if rc != 0:
+        raise MemoryError("oracle build failed")
+    return Tree(nodes, shape_node)
+
+
+def flatten(nodes) -> np.ndarray:
+    s = "f32" if nodes.dtype == NODE_F32 else "f64"
+    _, _, flt, _ = _types(s)
+    n_nodes = len(nodes)
+    n = (n_nodes + 1) // 2
+    cap = 3 * n - 2 if n >= 2 else n
+    out = np.zeros(max(cap, 0), dtype=flt)
+    got = getattr(lib(), f"orc_flatten_{s}")(_p(nodes), C.c_size_t(n_nodes), _p(out))
+    assert got == len(out), (got, len(out))
+    return out
+
+
+def traverse_flat(flat, shape_aabbs, rays, want_t: bool = False, threads: int = 1):
+    """returns (offsets[r+1], indices, tslice|None, stats dict)"""
+    s = "f32" if flat.dtype == FLAT_F32 else "f64"
+    ft = _types(s)[0]
+    sa = np.ascontiguousarray(shape_aabbs, dtype=ft).reshape(-1, 6)
+    rays = np.ascontiguousarray(rays)
+    nr = len(rays)
+    offsets = np.zeros(nr + 1, dtype=np.uint32)
+    st = TravStats()
+    fn = getattr(lib(), f"orc_traverse_flat_{s}")
+    total = fn(_p(flat), C.c_size_t(len(flat)), _p(sa), _p(rays), C.c_size_t(nr), _p(offsets), None,
+               C.c_uint64(0), None, C.byref(st), C.c_int(threads))
+    indices = np.zeros(total, dtype=np.uint32)
+    ts = np.zeros((total, 2), dtype=ft) if want_t else None
+    fn(_p(flat), C.c_size_t(len(flat)), _p(sa), _p(rays), C.c_size_t(nr), _p(offsets), _p(indices),
+       C.c_uint64(total), _p(ts), C.byref(st), C.c_int(threads))
+    stats = dict(visited=st.visited, leaf_visits=st.leaf_visits, hits=st.hits, max_visited=st.max_visited)
+    return offsets, indices, ts, stats
+
+
+def traverse_tree(nodes, shape_aabbs, rays):
+    s = "f32" if nodes.dtype == NODE_F32 else "f64"
+    ft = _types(s)[0]
+    sa = np.ascontiguousarray(shape_aabbs, dtype=ft).reshape(-1, 6)
+    rays = np.ascontiguousarray(rays)
+    nr = len(rays)
+    offsets = np.zeros(nr + 1, dtype=np.uint32)
+    fn = getattr(lib(), f"orc_traverse_tree_{s}")
+    total = fn(_p(nodes), C.c_size_t(len(nodes)), _p(sa), _p(rays), C.c_size_t(nr), _p(offsets), None, C.c_uint64(0))
+    indices = np.zeros(total, dtype=np.uint32)
+    fn(_p(nodes), C.c_size_t(len(nodes)), _p(sa), _p(rays), C.c_size_t(nr), _p(offsets), _p(indices),
+       C.c_uint64(total))
+    return offsets, indices
+
+
+def check_tree(nodes, aabbs) -> int:
+    s = "f32" if nodes.dtype == NODE_F32 else "f64"
+    ft = _types(s)[0]
+    a = np.ascontiguousarray(aabbs, dtype=ft).reshape(-1, 6)
+    return int(getattr(lib(), f"orc_check_tree_{s}")(_p(nodes), C.c_size_t(len(nodes)), _p(a), C.c_size_t(len(a))))
+
+
+def tree_stats(nodes, aabbs):
+    s = "f32" if nodes.dtype == NODE_F32 else "f64"
+    ft = _types(s)[0]
+    a = np.ascontiguousarray(aabbs, dtype=ft).reshape(-1, 6)
+    out = np.zeros(3, dtype=np.uint64)
+    getattr(lib(), f"orc_tree_stats_{s}")(_p(nodes), C.c_size_t(len(nodes)), _p(a), _p(out))
+    n = len(a)
+    return dict(max_depth=int(out[0]), mean_leaf_depth=float(out[1]) / max(n, 1), degenerate_splits=int(out[2]))

@@ -1,0 +1,263 @@
+"""Pin the CPU oracle against every known-answer vector the reference's own tests hold for the
+hot path (tests/golden/reference_known_answers.json, transcribed from /root/reference/src) and
+against the independent second restatement oracle/pyref.py.  CPU only.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import orc, pyref
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")))
+
+
+def unit_box(center, dtype=np.float32):
+    c = np.asarray(center, dtype=dtype)
+    return np.concatenate([c + dtype(-0.5), c + dtype(0.5)]).astype(dtype)
+
+
+# ---------------------------------------------------------------- 21-box golden hit sets
+@pytest.mark.parametrize("parallel", [False, True])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_aligned_boxes_golden_sets(parallel, dtype):
+    g = GOLD["aligned_boxes"]
+    aabbs = orc.aligned_boxes().astype(dtype)
+    tree = orc.build(aabbs, parallel=parallel)
+    assert orc.check_tree(tree.nodes, aabbs) == 0
+    flat = orc.flatten(tree.nodes)
+    assert len(flat) == 3 * 21 - 2
+    ids = np.array(g["ids"])
+    for case in g["rays"]:
+        rays = orc.make_rays([case["origin"]], [case["direction"]], dtype)
+        off, idx, _, _ = orc.traverse_flat(flat, aabbs, rays)
+        assert sorted(ids[idx].tolist()) == sorted(case["hit_ids"])
+        assert len(idx) == len(case["hit_ids"])
+        off2, idx2 = orc.traverse_tree(tree.nodes, aabbs, rays)
+        assert idx2.tolist() == idx.tolist()  # recursive and flat agree, same DFS order
+
+
+def test_shape_indices_cover_all_leaves():
+    # bvh_impl.rs:590-614
+    aabbs = orc.aligned_boxes()
+    tree = orc.build(aabbs)
+    leaves = tree.nodes[tree.nodes["shape"] != orc.NONE]
+    assert sorted(leaves["shape"].tolist()) == list(range(21))
+    inner = tree.nodes[tree.nodes["shape"] == orc.NONE]
+    assert len(inner) == 20
+    # set_bh_node_index: shape_node[i] is the leaf that holds shape i (bvh_node.rs:102)
+    for s, ni in enumerate(tree.shape_node):
+        assert tree.nodes[ni]["shape"] == s
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_one_node_bvh(dtype):
+    for case in GOLD["one_node"]["cases"]:
+        aabbs = unit_box(case["box_center"], dtype).reshape(1, 6)
+        tree = orc.build(aabbs)
+        assert len(tree.nodes) == 1 and tree.nodes[0]["shape"] == 0
+        flat = orc.flatten(tree.nodes)
+        assert len(flat) == 1 and flat[0]["entry"] == orc.NONE and flat[0]["exit"] == 1
+        rays = orc.make_rays([case["origin"]], [case["direction"]], dtype)
+        off, idx, _, _ = orc.traverse_flat(flat, aabbs, rays)
+        assert len(idx) == case["hits"]
+        off2, idx2 = orc.traverse_tree(tree.nodes, aabbs, rays)
+        assert len(idx2) == case["hits"]
+
+
+def test_empty_bvh():
+    # bvh_impl.rs:57-59, :563-574 ; flat_bvh.rs:245-248, :620-625
+    aabbs = np.zeros((0, 6), dtype=np.float32)
+    tree = orc.build(aabbs)
+    assert len(tree.nodes) == 0
+    assert orc.check_tree(tree.nodes, aabbs) == 0
+    flat = orc.flatten(tree.nodes)
+    assert len(flat) == 0
+    rays = orc.make_rays([[0, 0, 0]], [[1, 0, 0]])
+    off, idx, _, _ = orc.traverse_flat(flat, aabbs, rays)
+    assert off.tolist() == [0, 0] and len(idx) == 0
+
+
+# ---------------------------------------------------------------- slab edge cases
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_slab_edge_cases(dtype):
+    s = GOLD["slab"]
+    z = s["zero_depth"]
+    ray = orc.make_rays([z["origin"]], [z["direction"]], dtype)[0]
+    assert orc.ray_intersects_aabb(ray, z["aabb"]) is z["hit"]
+
+    a = s["slice_accuracy"]
+    pts = np.array(a["grow_points"], dtype=dtype)
+    box = np.concatenate([pts.min(axis=0), pts.max(axis=0)])
+    ray = orc.make_rays([a["origin"]], [a["direction"]], dtype)[0]
+    tmin, tmax = orc.ray_slice(ray, box)
+    assert abs(tmin - a["tmin"]) < a["tol"] and abs(tmax - a["tmax"]) < a["tol"]
+
+    p = s["parallel_miss"]
+    ray = orc.make_rays([p["origin"]], [p["direction"]], dtype)[0]
+    assert orc.ray_slice(ray, unit_box(p["box_center"], dtype)) is None
+
+    for c in s["in_plane"]:
+        ray = orc.make_rays([c["origin"]], [c["direction"]], dtype)[0]
+        box = unit_box(c["box_center"], dtype)
+        assert orc.ray_intersects_aabb(ray, box) is c["hit"]
+        assert orc.ray_slice(ray, box) is None
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_aabb_doc_tests(dtype):
+    d = GOLD["aabb_doc_tests"]
+    assert orc.surface_area(d["box"], dtype) == d["surface_area"]
+    assert orc.center(d["box"], dtype).tolist() == d["center"]
+    assert orc.largest_axis(d["largest_axis_box"], dtype) == d["largest_axis"]
+    # aabb_impl.rs:730-746: center must not overflow for huge boxes (min*0.5 + max*0.5 form)
+    big = np.finfo(dtype).max
+    c = orc.center([-big, -big, -big, big, big, big], dtype)
+    assert np.all(np.isfinite(c))
+
+
+def test_triangle_intersection_basic():
+    # ray_impl.rs:154-213: front-face hit returns distance, back-face is culled
+    ray = orc.make_rays([[0.25, 0.25, -1.0]], [[0, 0, 1]])[0]
+    a, b, c = [0, 0, 0], [0, 1, 0], [1, 0, 0]  # det > 0 for +z rays
+    d, u, v = orc.ray_triangle(ray, a, b, c)
+    d2, _, _ = orc.ray_triangle(ray, a, c, b)
+    assert (np.isfinite(d) and abs(d - 1.0) < 1e-6 and np.isinf(d2)) or (
+        np.isfinite(d2) and abs(d2 - 1.0) < 1e-6 and np.isinf(d))
+
+
+# ---------------------------------------------------------------- scene generators
+def test_scene_shape_and_invariants_1200():
+    tris, aabbs = orc.create_n_cubes(100)
+    assert len(tris) == GOLD["scene_shape"]["cubes_to_triangles"]["100"]
+    tree = orc.build(aabbs)
+    assert len(tree.nodes) == 2 * 1200 - 1
+    assert orc.check_tree(tree.nodes, aabbs) == 0  # is_consistent + assert_tight + coverage
+    flat = orc.flatten(tree.nodes)
+    assert len(flat) == 3 * 1200 - 2
+    par = orc.build(aabbs, parallel=True)
+    assert par.nodes.tobytes() == tree.nodes.tobytes()  # executor-independent (bvh_node.rs:138-142)
+    assert np.array_equal(par.shape_node, tree.shape_node)
+    # cube triangles are unit-sized and inside the (slightly grown) bounds
+    ext = aabbs[:, 3:] - aabbs[:, :3]
+    assert np.all(ext <= 1.0 + 1e-2) and np.all(aabbs[:, :3] >= -100001) and np.all(aabbs[:, 3:] <= 100001)
+
+
+def test_generators_match_independent_restatement():
+    state = 0
+    bounds = [float(v) for v in orc.DEFAULT_BOUNDS]
+    tris, _ = orc.create_n_cubes(5)
+    for i in range(5):
+        state, p = pyref.next_point3(state, bounds)
+        # top_front_right = pos + (0.5, 0.5, -0.5) is vertex 1 of triangle 0 (testbase.rs:491,500-504)
+        tfr = tris[i * 12, 1]
+        exp = [p[0] + np.float32(0.5), p[1] + np.float32(0.5), p[2] + np.float32(-0.5)]
+        assert tfr.tolist() == [float(v) for v in exp]
+    # ray stream, including O(1) seek
+    rays = orc.create_rays(0, 8)
+    rays_tail = orc.create_rays(5, 3)
+    assert rays[5:].tobytes() == rays_tail.tobytes()
+    state = 0
+    for i in range(8):
+        state, o = pyref.next_point3(state, bounds)
+        state, d = pyref.next_point3(state, bounds)
+        ro, rd, rinv = pyref.ray_new(o, d)
+        assert rays[i]["o"].tolist() == [float(v) for v in ro]
+        assert rays[i]["d"].tolist() == [float(v) for v in rd]
+        assert rays[i]["inv"].tolist() == [float(v) for v in rinv]
+    # bench quirk: scene and ray streams share seed 0, so ray k's origin is cube 2k's centre
+    assert np.allclose(rays[1]["o"], tris[2 * 12:3 * 12].reshape(-1, 3).mean(axis=0), atol=1e-2)
+
+
+# ---------------------------------------------------------------- C oracle vs independent pyref
+def _nodes_equal(c_nodes, py_nodes):
+    assert len(c_nodes) == len(py_nodes)
+    for cn, pn in zip(c_nodes, py_nodes):
+        assert cn["parent"] == pn["parent"]
+        if pn["leaf"]:
+            assert cn["shape"] == pn["shape"]
+        else:
+            assert cn["shape"] == orc.NONE and cn["l"] == pn["l"] and cn["r"] == pn["r"]
+            assert np.concatenate([cn["l_min"], cn["l_max"]]).tolist() == [float(v) for v in pn["l_aabb"]]
+            assert np.concatenate([cn["r_min"], cn["r_max"]]).tolist() == [float(v) for v in pn["r_aabb"]]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_c_oracle_equals_pyref_on_cubes(dtype):
+    _, aabbs = orc.create_n_cubes(25)  # 300 triangles, includes 150 degenerate pair splits
+    aabbs = aabbs.astype(dtype)
+    tree = orc.build(aabbs)
+    py_nodes, py_shape_node = pyref.build(aabbs)
+    _nodes_equal(tree.nodes, py_nodes)
+    assert tree.shape_node.tolist() == py_shape_node
+    flat = orc.flatten(tree.nodes)
+    py_flat = pyref.flatten(py_nodes, dtype)
+    assert len(flat) == len(py_flat)
+    for cf, pf in zip(flat, py_flat):
+        assert (cf["entry"], cf["exit"], cf["shape"]) == pf[1:]
+        assert np.concatenate([cf["min"], cf["max"]]).tolist() == [float(v) for v in pf[0]]
+    rays = orc.create_rays(0, 40).astype(orc.RAY_F32)
+    if dtype == np.float64:
+        rays = orc.make_rays(rays["o"], rays["d"], np.float64)
+    off, idx, _, _ = orc.traverse_flat(flat, aabbs, rays)
+    for i in range(len(rays)):
+        ray = ([dtype(v) for v in rays[i]["o"]], None, [dtype(v) for v in rays[i]["inv"]])
+        exp = pyref.traverse_flat(py_flat, aabbs, ray)
+        assert idx[off[i]:off[i + 1]].tolist() == exp
+        assert pyref.traverse_tree(py_nodes, aabbs, ray) == exp
+
+
+def test_c_oracle_equals_pyref_random_boxes():
+    rng = np.random.default_rng(7)
+    lo = rng.uniform(-50, 50, size=(257, 3)).astype(np.float32)
+    ext = rng.uniform(0, 4, size=(257, 3)).astype(np.float32)
+    ext[::7] = 0  # zero-thickness boxes
+    lo[100:110] = lo[100]  # identical centroids → degenerate split path (bvh_node.rs:114-124)
+    ext[100:110] = ext[100]
+    aabbs = np.concatenate([lo, lo + ext], axis=1)
+    tree = orc.build(aabbs)
+    assert orc.check_tree(tree.nodes, aabbs) == 0
+    py_nodes, py_sn = pyref.build(aabbs)
+    _nodes_equal(tree.nodes, py_nodes)
+    assert tree.shape_node.tolist() == py_sn
+
+
+# ---------------------------------------------------------------- closed-form flatten
+def test_flatten_closed_form():
+    _, aabbs = orc.create_n_cubes(100)
+    tree = orc.build(aabbs)
+    flat = orc.flatten(tree.nodes)
+    nodes = tree.nodes
+    n_nodes = len(nodes)
+    is_leaf = nodes["shape"] != orc.NONE
+    leaves_before = np.concatenate([[0], np.cumsum(is_leaf)[:-1]])
+    # k_i via pre-order subtree sizes
+    k = np.zeros(n_nodes, dtype=np.int64)
+    for i in range(n_nodes - 1, -1, -1):
+        k[i] = 1 if is_leaf[i] else k[nodes[i]["l"]] + k[nodes[i]["r"]]
+    for i in range(1, n_nodes):
+        nav = i - 1 + leaves_before[i]
+        assert flat[nav]["entry"] == nav + 1
+        assert flat[nav]["exit"] == nav + 3 * k[i] - 1
+        assert flat[nav]["shape"] == orc.NONE
+        if is_leaf[i]:
+            assert flat[nav + 1]["entry"] == orc.NONE and flat[nav + 1]["exit"] == nav + 2
+            assert flat[nav + 1]["shape"] == nodes[i]["shape"]
+            assert np.all(np.isinf(flat[nav + 1]["min"])) and np.all(flat[nav + 1]["max"] == -np.inf)
+
+
+def test_workload_statistics_120k():
+    """Re-derives the statistics SURVEY §8d quotes from a scratch script (depth 22, 60 000 degenerate splits)."""
+    _, aabbs = orc.create_n_cubes(10_000)
+    tree = orc.build(aabbs, parallel=False)
+    st = orc.tree_stats(tree.nodes, aabbs)
+    assert st["max_depth"] == 22 and st["degenerate_splits"] == 60_000
+    assert abs(st["mean_leaf_depth"] - 17.87) < 0.01
+    assert orc.check_tree(tree.nodes, aabbs) == 0
+    flat = orc.flatten(tree.nodes)
+    assert len(flat) == 359_998
+    rays = orc.create_rays(0, 20_000)
+    off, idx, _, stats = orc.traverse_flat(flat, aabbs, rays, threads=orc.max_threads())
+    assert stats["hits"] == 10_000  # first 5 000 rays start inside a cube and return exactly 2 candidates
+    assert np.all(np.diff(off)[:5000] == 2) and np.all(np.diff(off)[5000:] == 0)
