@@ -1,0 +1,146 @@
+"""ctypes binding of libbvh_mi355x.so (include/bvh_mi355x.h).
+
+The HIP engine is the only implementation: if the shared library is missing or a GPU call is made
+without a device, this module raises — there is no CPU fallback anywhere in the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libbvh_mi355x.so")
+
+OK, INVALID_ARG, HIP_ERROR, OOM, OVERFLOW, NO_DEVICE, DTYPE_MISMATCH, NOT_FLATTENED = range(8)
+F32, F64 = 0, 1
+HOST, DEVICE = 0, 1
+NONE = 0xFFFFFFFF
+TRAVERSE_T_SLICE = 1
+TRAVERSE_STATS = 2
+
+NODE_F32 = np.dtype([("l_min", "<f4", 3), ("l_max", "<f4", 3), ("r_min", "<f4", 3), ("r_max", "<f4", 3),
+                     ("parent", "<u4"), ("l", "<u4"), ("r", "<u4"), ("shape", "<u4")])
+NODE_F64 = np.dtype([("l_min", "<f8", 3), ("l_max", "<f8", 3), ("r_min", "<f8", 3), ("r_max", "<f8", 3),
+                     ("parent", "<u4"), ("l", "<u4"), ("r", "<u4"), ("shape", "<u4")])
+FLAT_F32 = np.dtype([("min", "<f4", 3), ("max", "<f4", 3), ("entry", "<u4"), ("exit", "<u4"), ("shape", "<u4")])
+FLAT_F64 = np.dtype([("min", "<f8", 3), ("max", "<f8", 3), ("entry", "<u4"), ("exit", "<u4"), ("shape", "<u4"),
+                     ("_pad", "<u4")])
+RAY_F32 = np.dtype([("o", "<f4", 3), ("d", "<f4", 3), ("inv", "<f4", 3)])
+RAY_F64 = np.dtype([("o", "<f8", 3), ("d", "<f8", 3), ("inv", "<f8", 3)])
+
+
+class BvhGpuError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"bvhgpu status {status}: {message}")
+        self.status = status
+
+
+class TraverseStats(C.Structure):
+    _fields_ = [("hits", C.c_uint64), ("visited", C.c_uint64), ("leaf_visits", C.c_uint64),
+                ("device_steps", C.c_uint64)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("build_ms", C.c_float), ("flatten_ms", C.c_float), ("traverse_kernel_ms", C.c_float),
+                ("traverse_total_ms", C.c_float)]
+
+
+# every symbol include/bvh_mi355x.h declares: (name, restype, argtypes)
+_vp, _sz, _i, _u = C.c_void_p, C.c_size_t, C.c_int, C.c_uint
+_pp = C.POINTER(C.c_void_p)
+SYMBOLS = [
+    ("bvhgpu_abi_version", _i, []),
+    ("bvhgpu_device_count", _i, [C.POINTER(_i)]),
+    ("bvhgpu_status_string", C.c_char_p, [_i]),
+    ("bvhgpu_create", _i, [_i, _vp, _pp]),
+    ("bvhgpu_destroy", None, [_vp]),
+    ("bvhgpu_last_error", C.c_char_p, [_vp]),
+    ("bvhgpu_synchronize", _i, [_vp]),
+    ("bvhgpu_stream", _vp, [_vp]),
+    ("bvhgpu_build_f32", _i, [_vp, _vp, _sz, _i, _pp]),
+    ("bvhgpu_build_f64", _i, [_vp, _vp, _sz, _i, _pp]),
+    ("bvhgpu_rebuild_f32", _i, [_vp, _vp, _sz, _i]),
+    ("bvhgpu_rebuild_f64", _i, [_vp, _vp, _sz, _i]),
+    ("bvhgpu_tree_destroy", None, [_vp]),
+    ("bvhgpu_tree_info", _i, [_vp, C.POINTER(_i), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
+    ("bvhgpu_tree_nodes", _i, [_vp, _vp, _i]),
+    ("bvhgpu_tree_shape_nodes", _i, [_vp, _vp, _i]),
+    ("bvhgpu_tree_build_levels", _i, [_vp, C.POINTER(_i)]),
+    ("bvhgpu_flatten", _i, [_vp]),
+    ("bvhgpu_flat_nodes", _i, [_vp, _vp, _i]),
+    ("bvhgpu_tree_from_flat_f32", _i, [_vp, _vp, _sz, _vp, _sz, _pp]),
+    ("bvhgpu_tree_from_flat_f64", _i, [_vp, _vp, _sz, _vp, _sz, _pp]),
+    ("bvhgpu_scene_nbytes", _i, [_vp, C.POINTER(_sz)]),
+    ("bvhgpu_scene_export", _i, [_vp, _vp, _i]),
+    ("bvhgpu_scene_import", _i, [_vp, _vp, _sz, _i, _pp]),
+    ("bvhgpu_rays_new_f32", _i, [_vp, _vp, _vp, _sz, _i, _vp, _i]),
+    ("bvhgpu_rays_new_f64", _i, [_vp, _vp, _vp, _sz, _i, _vp, _i]),
+    ("bvhgpu_gen_rays_f32", _i, [_vp, C.c_uint64, _sz, _vp, _vp]),
+    ("bvhgpu_gen_rays_f64", _i, [_vp, C.c_uint64, _sz, _vp, _vp]),
+    ("bvhgpu_traverse_f32", _i, [_vp, _vp, _sz, _i, _u, _pp]),
+    ("bvhgpu_traverse_f64", _i, [_vp, _vp, _sz, _i, _u, _pp]),
+    ("bvhgpu_hits_info", _i, [_vp, C.POINTER(_sz), C.POINTER(C.c_uint64), C.POINTER(TraverseStats)]),
+    ("bvhgpu_hits_fetch", _i, [_vp, _vp, _vp, _vp, _i]),
+    ("bvhgpu_hits_device", _i, [_vp, _pp, _pp, _pp]),
+    ("bvhgpu_hits_destroy", None, [_vp]),
+    ("bvhgpu_enable_timing", _i, [_vp, _i]),
+    ("bvhgpu_last_timings", _i, [_vp, C.POINTER(Timings)]),
+]
+
+_lib = None
+
+
+def load():
+    """Load the engine.  Raises ImportError with build instructions if the .so is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if os.environ.get("BVH_AMD_NO_TORCH") != "1":
+        # PyTorch-ROCm wheels bundle their own HIP/HSA runtime (torch/lib/libamdhip64.so, soname
+        # libamdhip64.so.7).  Two HIP runtimes in one process cannot both own the GPU, so when torch is
+        # installed it must be loaded FIRST; our library then binds to the already-loaded runtime by soname.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            f"{SO_PATH} is missing: the MI355X HIP engine has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `python bvh_amd/build_ext.py`). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(SO_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.bvhgpu_abi_version() != 1:
+        raise ImportError("libbvh_mi355x.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    load().bvhgpu_device_count(C.byref(n))
+    return int(n.value)
+
+
+def check(rc: int, ctx=None):
+    if rc == OK:
+        return
+    lib = load()
+    msg = lib.bvhgpu_last_error(ctx).decode() if True else ""
+    if not msg:
+        msg = lib.bvhgpu_status_string(rc).decode()
+    raise BvhGpuError(rc, msg)
+
+
+def ptr(a):
+    """c_void_p of a numpy array (host) or an int device address; None → NULL."""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return C.c_void_p(int(a))
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,468 @@
+"""Host-side mirror of the reference's operator surface for the hot path, over the C ABI.
+
+Names, argument meaning and error behaviour follow the Rust crate (paths under /root/reference/src):
+  Bounded.aabb()                     aabb/aabb_impl.rs:28-56
+  BHShape.set_bh_node_index / bh_node_index   bounding_hierarchy.rs:53-65
+  BoundingHierarchy.build / build_par / build_with_executor / traverse   bounding_hierarchy.rs:89-336
+  Bvh, Bvh.flatten, FlatBvh          bvh/bvh_impl.rs:27-119, flat_bvh.rs:240-431
+  Ray.new / intersects_aabb / intersection_slice_for_aabb   ray/ray_impl.rs:70-145
+Conventions kept: empty input → empty structure, no error (bvh_impl.rs:57-59); `traverse` returns the
+hit shapes themselves, in the reference's order; shapes are only borrowed.
+Everything that computes runs on the GPU through libbvh_mi355x.so; this file only marshals.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import (DEVICE, F32, F64, FLAT_F32, FLAT_F64, HOST, NODE_F32, NODE_F64, NONE, RAY_F32, RAY_F64,
+                   TRAVERSE_STATS, TRAVERSE_T_SLICE, BvhGpuError, check, ptr)
+
+
+def _sfx(dtype) -> str:
+    dt = np.dtype(dtype)
+    if dt == np.float32:
+        return "f32"
+    if dt == np.float64:
+        return "f64"
+    raise TypeError(f"BHValue must be f32 or f64, got {dt}")
+
+
+def _ray_dtype(s):
+    return RAY_F32 if s == "f32" else RAY_F64
+
+
+def _is_device_tensor(x) -> bool:
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+
+# ------------------------------------------------------------------------------------------------
+class Context:
+    """One GPU + one HIP stream + scratch (bvhgpu_ctx).  `stream` may be a raw hipStream_t
+    (e.g. torch.cuda.current_stream().cuda_stream) so that work is ordered with the caller's."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        lib = _lib.load()
+        if _lib.device_count() <= 0:
+            raise BvhGpuError(_lib.NO_DEVICE, "no MI355X / HIP device visible: the engine has no CPU fallback")
+        h = C.c_void_p()
+        check(lib.bvhgpu_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def synchronize(self):
+        check(_lib.load().bvhgpu_synchronize(self._h), self._h)
+
+    def enable_timing(self, on: bool = True):
+        check(_lib.load().bvhgpu_enable_timing(self._h, int(on)), self._h)
+
+    def last_timings(self) -> dict:
+        t = _lib.Timings()
+        check(_lib.load().bvhgpu_last_timings(self._h, C.byref(t)), self._h)
+        return dict(build_ms=t.build_ms, flatten_ms=t.flatten_ms, traverse_kernel_ms=t.traverse_kernel_ms,
+                    traverse_total_ms=t.traverse_total_ms)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().bvhgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+# ------------------------------------------------------------------------------------------------
+class Aabb:
+    """Aabb<T,3> {min, max} (aabb_impl.rs:10-16) as a host value type.  Only construction helpers
+    live here (a shape needs them to answer Bounded.aabb()); all hot-path arithmetic is on the GPU."""
+    __slots__ = ("min", "max")
+
+    def __init__(self, mn, mx, dtype=np.float32):
+        self.min = np.asarray(mn, dtype=dtype).reshape(3)
+        self.max = np.asarray(mx, dtype=dtype).reshape(3)
+
+    @staticmethod
+    def with_bounds(mn, mx, dtype=np.float32) -> "Aabb":  # aabb_impl.rs:97-99
+        return Aabb(mn, mx, dtype)
+
+    @staticmethod
+    def empty(dtype=np.float32) -> "Aabb":  # aabb_impl.rs:119-124
+        return Aabb([np.inf] * 3, [-np.inf] * 3, dtype)
+
+    def join(self, other: "Aabb") -> "Aabb":  # aabb_impl.rs:303-308
+        return Aabb(np.minimum(self.min, other.min), np.maximum(self.max, other.max), self.min.dtype)
+
+    def grow(self, p) -> "Aabb":  # aabb_impl.rs:375-380
+        p = np.asarray(p, dtype=self.min.dtype)
+        return Aabb(np.minimum(self.min, p), np.maximum(self.max, p), self.min.dtype)
+
+    def as6(self) -> np.ndarray:
+        return np.concatenate([self.min, self.max])
+
+    def __repr__(self):
+        return f"Aabb(min={self.min.tolist()}, max={self.max.tolist()})"
+
+
+class Bounded:
+    """trait Bounded (aabb_impl.rs:28-56)."""
+
+    def aabb(self) -> Aabb:
+        raise NotImplementedError
+
+
+class BHShape(Bounded):
+    """trait BHShape (bounding_hierarchy.rs:53-65)."""
+
+    def set_bh_node_index(self, index: int) -> None:
+        raise NotImplementedError
+
+    def bh_node_index(self) -> int:
+        raise NotImplementedError
+
+
+# ------------------------------------------------------------------------------------------------
+class RayBatch:
+    """A batch of Ray<T,3> (ray_impl.rs:17-29) in host memory (structured array) or in HBM."""
+
+    def __init__(self, n: int, dtype, host: Optional[np.ndarray] = None, device=None, device_ptr: int = 0):
+        self.n = int(n)
+        self.sfx = _sfx(dtype)
+        self.host = host          # numpy structured array or None
+        self.device = device      # object that owns the device memory (e.g. torch tensor) or None
+        self.device_ptr = int(device_ptr)
+
+    @property
+    def mem(self) -> int:
+        return DEVICE if self.host is None else HOST
+
+    def _ptr(self):
+        return ptr(self.device_ptr) if self.host is None else ptr(self.host)
+
+    @staticmethod
+    def new(origins, directions, dtype=np.float32, ctx: Optional[Context] = None) -> "RayBatch":
+        """Ray::new for every row (ray_impl.rs:70-80): normalise the direction, cache 1/d — on the GPU."""
+        ctx = ctx or default_context()
+        s = _sfx(dtype)
+        o = np.ascontiguousarray(origins, dtype=dtype).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=dtype).reshape(-1, 3)
+        if len(o) != len(d):
+            raise ValueError("origins and directions differ in length")
+        out = np.zeros(len(o), dtype=_ray_dtype(s))
+        fn = getattr(_lib.load(), f"bvhgpu_rays_new_{s}")
+        check(fn(ctx._h, ptr(o), ptr(d), len(o), HOST, ptr(out), HOST), ctx._h)
+        return RayBatch(len(o), dtype, host=out)
+
+    @staticmethod
+    def from_device(device_obj, n: int, dtype=np.float32) -> "RayBatch":
+        """Wrap rays already resident in HBM (torch uint8/float tensor holding n Ray structs)."""
+        return RayBatch(n, dtype, host=None, device=device_obj, device_ptr=device_obj.data_ptr())
+
+    @staticmethod
+    def generate(first: int, n: int, bounds, device_obj, dtype=np.float32, ctx: Optional[Context] = None) -> "RayBatch":
+        """The bench ray stream create_ray(seed 0) (testbase.rs:687-691, :825), rays [first, first+n),
+        written straight into `device_obj` (a torch tensor of >= n*sizeof(Ray) bytes on the GPU)."""
+        ctx = ctx or default_context()
+        s = _sfx(dtype)
+        b = np.ascontiguousarray(bounds, dtype=np.float32).reshape(6)
+        fn = getattr(_lib.load(), f"bvhgpu_gen_rays_{s}")
+        check(fn(ctx._h, C.c_uint64(first), n, ptr(b), ptr(device_obj.data_ptr())), ctx._h)
+        return RayBatch(n, dtype, host=None, device=device_obj, device_ptr=device_obj.data_ptr())
+
+
+class Ray:
+    """struct Ray (ray_impl.rs:17-29).  Ray(origin, direction) == Ray::new."""
+
+    def __init__(self, origin, direction, dtype=np.float32, ctx: Optional[Context] = None):
+        self._batch = RayBatch.new([origin], [direction], dtype, ctx)
+        r = self._batch.host[0]
+        self.origin, self.direction, self.inv_direction = r["o"].copy(), r["d"].copy(), r["inv"].copy()
+        self.dtype = np.dtype(dtype)
+
+    @staticmethod
+    def new(origin, direction, dtype=np.float32) -> "Ray":
+        return Ray(origin, direction, dtype)
+
+    def _probe(self, aabb: Aabb, want_t: bool):
+        # one-box scene: a single-shape Bvh traversed by this ray is exactly one
+        # Ray::intersects_aabb (flat_bvh.rs:411-418 / bvh_node.rs:314)
+        bvh = Bvh.from_aabbs(aabb.as6().reshape(1, 6).astype(self.dtype))
+        off, idx, ts, _ = bvh.flatten().traverse_batch(self._batch, want_t=want_t)
+        return (len(idx) == 1), (ts[0] if want_t and len(idx) else None)
+
+    def intersects_aabb(self, aabb: Aabb) -> bool:  # ray_impl.rs:105-110, intersect_default.rs:16-37
+        return self._probe(aabb, False)[0]
+
+    def intersection_slice_for_aabb(self, aabb: Aabb):  # ray_impl.rs:118-145
+        hit, ts = self._probe(aabb, True)
+        return (ts[0], ts[1]) if hit else None
+
+
+# ------------------------------------------------------------------------------------------------
+class _Hits:
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib.load().bvhgpu_hits_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class _TreeBase:
+    def __init__(self, ctx: Context, handle, sfx: str):
+        self.ctx = ctx
+        self._t = handle
+        self.sfx = sfx
+        self._hits = _Hits(ctx)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_t", None):
+                self._hits = None
+                _lib.load().bvhgpu_tree_destroy(self._t)
+                self._t = None
+        except Exception:
+            pass
+
+    def info(self) -> Tuple[int, int, int]:
+        n, nn, nf = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        dt = C.c_int()
+        check(_lib.load().bvhgpu_tree_info(self._t, C.byref(dt), C.byref(n), C.byref(nn), C.byref(nf)), self.ctx._h)
+        return int(n.value), int(nn.value), int(nf.value)
+
+    # ---- traversal -------------------------------------------------------------------------
+    def traverse_batch(self, rays: RayBatch, want_t: bool = False, stats: bool = False, fetch: bool = True):
+        """<FlatBvh as BoundingHierarchy>::traverse for a batch (flat_bvh.rs:396-431).
+        returns (offsets[n+1], indices[total], tslice[total,2]|None, stats dict)."""
+        if rays.sfx != self.sfx:
+            raise BvhGpuError(_lib.DTYPE_MISMATCH, "ray dtype differs from tree dtype")
+        lib = _lib.load()
+        flags = (TRAVERSE_T_SLICE if want_t else 0) | (TRAVERSE_STATS if stats else 0)
+        fn = getattr(lib, f"bvhgpu_traverse_{self.sfx}")
+        check(fn(self._t, rays._ptr(), rays.n, rays.mem, flags, C.byref(self._hits.h)), self.ctx._h)
+        total = C.c_uint64()
+        st = _lib.TraverseStats()
+        check(lib.bvhgpu_hits_info(self._hits.h, None, C.byref(total), C.byref(st)), self.ctx._h)
+        sd = dict(hits=int(st.hits), visited=int(st.visited), leaf_visits=int(st.leaf_visits),
+                  device_steps=int(st.device_steps))
+        if not fetch:
+            return None, None, None, sd
+        ft = np.float32 if self.sfx == "f32" else np.float64
+        offsets = np.zeros(rays.n + 1, dtype=np.uint32)
+        indices = np.zeros(total.value, dtype=np.uint32)
+        ts = np.zeros((total.value, 2), dtype=ft) if want_t else None
+        check(lib.bvhgpu_hits_fetch(self._hits.h, ptr(offsets), ptr(indices), ptr(ts), HOST), self.ctx._h)
+        return offsets, indices, ts, sd
+
+    def hits_device(self) -> Tuple[int, int]:
+        """device addresses of the last result's (offsets, indices) — valid until the next traverse."""
+        o, i, t = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(_lib.load().bvhgpu_hits_device(self._hits.h, C.byref(o), C.byref(i), C.byref(t)), self.ctx._h)
+        return int(o.value or 0), int(i.value or 0)
+
+    def traverse(self, query, shapes: Sequence) -> List:
+        """BoundingHierarchy::traverse (bounding_hierarchy.rs:246-250): the shapes whose AABB `query`
+        (a Ray) intersects, in the reference's order."""
+        if not isinstance(query, Ray):
+            raise NotImplementedError("the MI355X engine implements traverse for Ray queries "
+                                      "(IntersectsAabb for Aabb/Point/Ball are out of scope, SURVEY §2)")
+        _, idx, _, _ = self.traverse_batch(query._batch)
+        return [shapes[i] for i in idx.tolist()]
+
+    # ---- multi-GPU scene transport ---------------------------------------------------------
+    def scene_nbytes(self) -> int:
+        n = C.c_size_t()
+        check(_lib.load().bvhgpu_scene_nbytes(self._t, C.byref(n)), self.ctx._h)
+        return int(n.value)
+
+    def scene_export(self, dst) -> None:
+        """dst: torch uint8 tensor on the GPU (DEVICE) or a numpy uint8 array (HOST)."""
+        if _is_device_tensor(dst):
+            check(_lib.load().bvhgpu_scene_export(self._t, ptr(dst.data_ptr()), DEVICE), self.ctx._h)
+        else:
+            check(_lib.load().bvhgpu_scene_export(self._t, ptr(dst), HOST), self.ctx._h)
+
+
+class FlatBvh(_TreeBase):
+    """type FlatBvh = Vec<FlatNode> (flat_bvh.rs:254) resident in HBM."""
+
+    @staticmethod
+    def build(shapes: Sequence, dtype=np.float32, ctx: Optional[Context] = None) -> "FlatBvh":
+        return Bvh.build(shapes, dtype, ctx).flatten()  # flat_bvh.rs:328-331
+
+    @staticmethod
+    def build_par(shapes: Sequence, dtype=np.float32, ctx: Optional[Context] = None) -> "FlatBvh":
+        return Bvh.build_par(shapes, dtype, ctx).flatten()
+
+    @property
+    def nodes(self) -> np.ndarray:
+        """the FlatNode array in the reference's layout (flat_bvh.rs:17-46)."""
+        _, _, nf = self.info()
+        out = np.zeros(nf, dtype=FLAT_F32 if self.sfx == "f32" else FLAT_F64)
+        check(_lib.load().bvhgpu_flat_nodes(self._t, ptr(out), HOST), self.ctx._h)
+        return out
+
+    def __len__(self):
+        return self.info()[2]
+
+    @staticmethod
+    def from_flat_nodes(flat: np.ndarray, shape_aabbs: np.ndarray, ctx: Optional[Context] = None) -> "FlatBvh":
+        """Upload a FlatBvh produced elsewhere (e.g. by the Rust crate via flatten_custom)."""
+        ctx = ctx or default_context()
+        s = "f32" if flat.dtype == FLAT_F32 else "f64"
+        ft = np.float32 if s == "f32" else np.float64
+        sa = np.ascontiguousarray(shape_aabbs, dtype=ft).reshape(-1, 6)
+        flat = np.ascontiguousarray(flat)
+        h = C.c_void_p()
+        fn = getattr(_lib.load(), f"bvhgpu_tree_from_flat_{s}")
+        check(fn(ctx._h, ptr(flat), len(flat), ptr(sa), len(sa), C.byref(h)), ctx._h)
+        return FlatBvh(ctx, h, s)
+
+    @staticmethod
+    def scene_import(src, nbytes: int, ctx: Optional[Context] = None, reuse: Optional["FlatBvh"] = None) -> "FlatBvh":
+        """Import a scene blob (scene_export) — used on the peers after the RCCL broadcast.
+        `reuse`: a FlatBvh from an earlier scene_import whose HBM is overwritten in place."""
+        ctx = ctx or default_context()
+        h = reuse._t if reuse is not None else C.c_void_p()
+        if _is_device_tensor(src):
+            check(_lib.load().bvhgpu_scene_import(ctx._h, ptr(src.data_ptr()), nbytes, DEVICE, C.byref(h)), ctx._h)
+        else:
+            check(_lib.load().bvhgpu_scene_import(ctx._h, ptr(src), nbytes, HOST, C.byref(h)), ctx._h)
+        dt = C.c_int()
+        check(_lib.load().bvhgpu_tree_info(h, C.byref(dt), None, None, None), ctx._h)
+        if reuse is not None:
+            reuse.sfx = "f32" if dt.value == F32 else "f64"
+            return reuse
+        return FlatBvh(ctx, h, "f32" if dt.value == F32 else "f64")
+
+
+class Bvh(_TreeBase):
+    """struct Bvh {nodes: Vec<BvhNode>} (bvh_impl.rs:27-33), built and resident on the GPU."""
+
+    # ---- construction ----------------------------------------------------------------------
+    @staticmethod
+    def from_aabbs(aabbs, ctx: Optional[Context] = None) -> "Bvh":
+        """Build from an (n,6) array [min xyz, max xyz] (numpy → uploaded; torch GPU tensor → used in place)."""
+        ctx = ctx or default_context()
+        lib = _lib.load()
+        h = C.c_void_p()
+        if _is_device_tensor(aabbs):
+            import torch  # only needed when the caller already uses torch
+            s = "f32" if aabbs.dtype == torch.float32 else "f64"
+            n = aabbs.numel() // 6
+            check(getattr(lib, f"bvhgpu_build_{s}")(ctx._h, ptr(aabbs.data_ptr()), n, DEVICE, C.byref(h)), ctx._h)
+        else:
+            a = np.asarray(aabbs)
+            if a.dtype not in (np.float32, np.float64):
+                a = a.astype(np.float32)
+            s = _sfx(a.dtype)
+            a = np.ascontiguousarray(a).reshape(-1, 6)
+            check(getattr(lib, f"bvhgpu_build_{s}")(ctx._h, ptr(a), len(a), HOST, C.byref(h)), ctx._h)
+        return Bvh(ctx, h, s)
+
+    def rebuild(self, aabbs) -> "Bvh":
+        """Bvh::build again into the same device buffers (no allocation when n fits)."""
+        lib = _lib.load()
+        if _is_device_tensor(aabbs):
+            n = aabbs.numel() // 6
+            check(getattr(lib, f"bvhgpu_rebuild_{self.sfx}")(self._t, ptr(aabbs.data_ptr()), n, DEVICE), self.ctx._h)
+        else:
+            ft = np.float32 if self.sfx == "f32" else np.float64
+            a = np.ascontiguousarray(aabbs, dtype=ft).reshape(-1, 6)
+            check(getattr(lib, f"bvhgpu_rebuild_{self.sfx}")(self._t, ptr(a), len(a), HOST), self.ctx._h)
+        return self
+
+    @staticmethod
+    def build(shapes: Sequence, dtype=np.float32, ctx: Optional[Context] = None) -> "Bvh":
+        """Bvh::build (bvh_impl.rs:40-45).  Calls shape.aabb() ONCE per shape (the reference calls it
+        once per level, only observable for impure aabb()), builds on the GPU, then calls
+        shape.set_bh_node_index(leaf) for every shape (bvh_node.rs:102)."""
+        n = len(shapes)
+        a = np.empty((n, 6), dtype=dtype)
+        for i, s in enumerate(shapes):
+            a[i] = s.aabb().as6()
+        bvh = Bvh.from_aabbs(a, ctx)
+        if n:
+            for s, ni in zip(shapes, bvh.shape_nodes.tolist()):
+                s.set_bh_node_index(ni)
+        return bvh
+
+    @staticmethod
+    def build_par(shapes: Sequence, dtype=np.float32, ctx: Optional[Context] = None) -> "Bvh":
+        """BoundingHierarchy::build_par (bounding_hierarchy.rs:170-177): same tree; the GPU build is
+        the parallel build."""
+        return Bvh.build(shapes, dtype, ctx)
+
+    @staticmethod
+    def build_with_executor(shapes: Sequence, executor=None, dtype=np.float32, ctx: Optional[Context] = None) -> "Bvh":
+        """bvh_impl.rs:53-96.  The executor only chooses how sub-builds are scheduled on the CPU and
+        cannot change the result (node placement is arithmetic); the GPU schedules its own."""
+        return Bvh.build(shapes, dtype, ctx)
+
+    # ---- inspection ------------------------------------------------------------------------
+    @property
+    def nodes(self) -> np.ndarray:
+        """Vec<BvhNode> as a structured array (include/bvh_mi355x.h bvhgpu_node_*)."""
+        _, nn, _ = self.info()
+        out = np.zeros(nn, dtype=NODE_F32 if self.sfx == "f32" else NODE_F64)
+        check(_lib.load().bvhgpu_tree_nodes(self._t, ptr(out), HOST), self.ctx._h)
+        return out
+
+    @property
+    def shape_nodes(self) -> np.ndarray:
+        n, _, _ = self.info()
+        out = np.zeros(n, dtype=np.uint32)
+        check(_lib.load().bvhgpu_tree_shape_nodes(self._t, ptr(out), HOST), self.ctx._h)
+        return out
+
+    @property
+    def build_levels(self) -> int:
+        lv = C.c_int()
+        check(_lib.load().bvhgpu_tree_build_levels(self._t, C.byref(lv)), self.ctx._h)
+        return int(lv.value)
+
+    # ---- flatten ---------------------------------------------------------------------------
+    def flatten(self) -> "FlatBvh":
+        """Bvh::flatten (flat_bvh.rs:312-319).  The flat arrays live in the same device object."""
+        check(_lib.load().bvhgpu_flatten(self._t), self.ctx._h)
+        f = FlatBvh.__new__(FlatBvh)
+        f.ctx, f._t, f.sfx, f._hits = self.ctx, self._t, self.sfx, self._hits
+        f._owner = self          # shares the handle; the Bvh keeps ownership
+        f.__class__ = _FlatView
+        return f
+
+    def flatten_in_place(self) -> None:
+        check(_lib.load().bvhgpu_flatten(self._t), self.ctx._h)
+
+    def traverse(self, query, shapes: Sequence) -> List:
+        """Bvh::traverse (bvh_impl.rs:104-119): same hit list, same order as the flat traversal
+        (bvh_node.rs:288-319 visits the same boxes in the same order)."""
+        self.flatten_in_place()
+        return super().traverse(query, shapes)
+
+
+class _FlatView(FlatBvh):
+    """FlatBvh that borrows a Bvh's device object (so flatten() does not copy the tree)."""
+
+    def __del__(self):  # the owning Bvh destroys the handle
+        self._t = None

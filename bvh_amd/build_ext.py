@@ -1,0 +1,54 @@
+"""Build libbvh_mi355x.so (the C-ABI engine, include/bvh_mi355x.h) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box with the
+repo snapshot.  Flags that matter for bit-exact parity with the Rust reference:
+  -ffp-contract=off   no FMA contraction (every IEEE op is rounded separately, like rustc)
+  (no -ffast-math; hipcc's default keeps f32 divide / sqrt correctly rounded)
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libbvh_mi355x.so")
+SOURCES = ["capi.hip", "build.hip", "flatten.hip", "traverse.hip"]
+HEADERS = ["common.hpp", "engine.hpp", os.path.join("..", "..", "include", "bvh_mi355x.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def is_stale() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return OUT
+    cmd = [hipcc()] + FLAGS + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout + res.stderr)
+        raise RuntimeError("hipcc failed building libbvh_mi355x.so")
+    if verbose and res.stderr.strip():
+        sys.stderr.write(res.stderr)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,520 @@
+// capi.hip — the extern "C" boundary declared in include/bvh_mi355x.h.
+// Every entry point catches everything, records a message on the ctx and returns a status code.
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "engine.hpp"
+
+using namespace bvhgpu;
+
+namespace {
+
+thread_local std::string g_noctx_err;
+
+int fail(bvhgpu_ctx* ctx, int status, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_noctx_err = msg;
+    return status;
+}
+
+template <typename F> int guarded(bvhgpu_ctx* ctx, F&& f) {
+    try {
+        return f();
+    } catch (const HipFail& e) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s failed: %s (line %d)", e.what, hipGetErrorString(e.err), e.line);
+        if (e.what && std::strcmp(e.what, "OVERFLOW") == 0) return fail(ctx, BVHGPU_OVERFLOW, "more than 2^32-1 hits in one batch");
+        if (e.err == hipErrorOutOfMemory) return fail(ctx, BVHGPU_OOM, buf);
+        return fail(ctx, BVHGPU_HIP_ERROR, buf);
+    } catch (const std::bad_alloc&) {
+        return fail(ctx, BVHGPU_OOM, "host allocation failed");
+    } catch (...) {
+        return fail(ctx, BVHGPU_HIP_ERROR, "unknown exception");
+    }
+}
+
+void use_device(bvhgpu_ctx* ctx) { BVH_HIP(hipSetDevice(ctx->device)); }
+
+// bring a caller buffer to HBM: returns a device pointer (either the caller's or the ctx staging copy)
+const void* to_device(bvhgpu_ctx* ctx, const void* p, size_t bytes, int mem, DevBuf& stage) {
+    if (mem == BVHGPU_DEVICE || bytes == 0) return p;
+    stage.reserve(bytes);
+    BVH_HIP(hipMemcpyAsync(stage.p, p, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return stage.p;
+}
+
+void copy_out(bvhgpu_ctx* ctx, void* dst, const void* src_dev, size_t bytes, int mem) {
+    if (!bytes) return;
+    BVH_HIP(hipMemcpyAsync(dst, src_dev, bytes, mem == BVHGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                           ctx->stream));
+    BVH_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+void free_tree_buffers(bvhgpu_tree* t) {
+    t->aabbs.release(); t->nodes.release(); t->node_start.release(); t->node_count.release();
+    t->shape_node.release(); t->flat.release(); t->trav.release();
+    t->idx[0].release(); t->idx[1].release(); t->bk.release();
+    t->big[0].release(); t->big[1].release(); t->small.release();
+    t->stats[0].release(); t->stats[1].release();
+    t->tile_item[0].release(); t->tile_item[1].release(); t->tile_cnt.release(); t->ctr.release();
+}
+
+constexpr size_t MAX_SHAPES = (0xFFFFFFFFull - 1) / 3;  // flat indices are u32 (flat_bvh.rs:136)
+
+template <typename T> int do_build(bvhgpu_tree* t, const T* aabbs, size_t n, int mem) {
+    bvhgpu_ctx* ctx = t->ctx;
+    if (n && !aabbs) return fail(ctx, BVHGPU_INVALID_ARG, "aabbs is NULL");
+    if (n > MAX_SHAPES) return fail(ctx, BVHGPU_OVERFLOW, "too many shapes for u32 flat indices");
+    if (mem != BVHGPU_HOST && mem != BVHGPU_DEVICE) return fail(ctx, BVHGPU_INVALID_ARG, "bad mem kind");
+    use_device(ctx);
+    if (ctx->timing) BVH_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    const T* dev = aabbs;
+    if (n && mem == BVHGPU_HOST) {  // upload straight into the tree's own copy
+        t->aabbs.reserve(n * 6 * sizeof(T));
+        BVH_HIP(hipMemcpyAsync(t->aabbs.p, aabbs, n * 6 * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        dev = t->aabbs.as<T>();
+    }
+    build_tree<T>(t, dev, n);
+    if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[1], ctx->stream)); ctx->ev_set |= 1u; }
+    return BVHGPU_OK;
+}
+
+template <typename T> int new_build(bvhgpu_ctx* ctx, const T* aabbs, size_t n, int mem, bvhgpu_tree** out) {
+    if (!ctx || !out) return fail(ctx, BVHGPU_INVALID_ARG, "ctx/out is NULL");
+    *out = nullptr;
+    bvhgpu_tree* t = new bvhgpu_tree();
+    t->ctx = ctx;
+    t->dtype = Traits<T>::dtype;
+    int rc = guarded(ctx, [&] { return do_build<T>(t, aabbs, n, mem); });
+    if (rc != BVHGPU_OK) { free_tree_buffers(t); delete t; return rc; }
+    *out = t;
+    return BVHGPU_OK;
+}
+
+template <typename T>
+int do_traverse(bvhgpu_tree* tree, const typename Traits<T>::Ray* rays, size_t n_rays, int mem, unsigned flags,
+                bvhgpu_hits** hits) {
+    if (!tree) return BVHGPU_INVALID_ARG;
+    bvhgpu_ctx* ctx = tree->ctx;
+    if (!hits) return fail(ctx, BVHGPU_INVALID_ARG, "hits is NULL");
+    if (tree->dtype != Traits<T>::dtype) return fail(ctx, BVHGPU_DTYPE_MISMATCH, "tree dtype differs from ray dtype");
+    if (!tree->flattened) return fail(ctx, BVHGPU_NOT_FLATTENED, "call bvhgpu_flatten first");
+    if (n_rays && !rays) return fail(ctx, BVHGPU_INVALID_ARG, "rays is NULL");
+    if (n_rays >= 0xFFFFFFFFull) return fail(ctx, BVHGPU_OVERFLOW, "more than 2^32-2 rays in one batch");
+    return guarded(ctx, [&] {
+        use_device(ctx);
+        bvhgpu_hits* h = *hits;
+        if (!h) h = new bvhgpu_hits();
+        *hits = h;
+        const auto* dev = static_cast<const typename Traits<T>::Ray*>(
+            to_device(ctx, rays, n_rays * sizeof(typename Traits<T>::Ray), mem, ctx->upload));
+        traverse_batch<T>(tree, dev, n_rays, flags, h);
+        return (int)BVHGPU_OK;
+    });
+}
+
+template <typename T>
+int do_rays_new(bvhgpu_ctx* ctx, const T* origins, const T* dirs, size_t n, int mem_in, typename Traits<T>::Ray* out,
+                int mem_out) {
+    if (!ctx) return BVHGPU_INVALID_ARG;
+    if (n && (!origins || !dirs || !out)) return fail(ctx, BVHGPU_INVALID_ARG, "NULL argument");
+    return guarded(ctx, [&] {
+        use_device(ctx);
+        using Ray = typename Traits<T>::Ray;
+        const size_t vb = n * 3 * sizeof(T);
+        const T* o = origins; const T* d = dirs;
+        Ray* outd = out;
+        size_t need = (mem_in == BVHGPU_HOST ? 2 * vb : 0) + (mem_out == BVHGPU_HOST ? n * sizeof(Ray) : 0);
+        ctx->upload.reserve(need + 64);
+        char* base = ctx->upload.as<char>();
+        if (mem_in == BVHGPU_HOST) {
+            BVH_HIP(hipMemcpyAsync(base, origins, vb, hipMemcpyHostToDevice, ctx->stream));
+            BVH_HIP(hipMemcpyAsync(base + vb, dirs, vb, hipMemcpyHostToDevice, ctx->stream));
+            o = reinterpret_cast<const T*>(base); d = reinterpret_cast<const T*>(base + vb);
+            base += 2 * vb;
+        }
+        if (mem_out == BVHGPU_HOST) outd = reinterpret_cast<Ray*>(base);
+        rays_new<T>(ctx, o, d, n, outd);
+        if (mem_out == BVHGPU_HOST) copy_out(ctx, out, outd, n * sizeof(Ray), BVHGPU_HOST);
+        return (int)BVHGPU_OK;
+    });
+}
+
+// ---- FlatBvh upload: convert the reference layout to the engine layout on the host (a marshalling
+// step, like the AABB gather), keeping nav+leaf pairs un-folded unless their boxes are bit-identical.
+template <typename T>
+int tree_from_flat(bvhgpu_ctx* ctx, const typename Traits<T>::Flat* flat, size_t n_flat, const T* shape_aabbs,
+                          size_t n, bvhgpu_tree** out) {
+    if (!ctx || !out) return fail(ctx, BVHGPU_INVALID_ARG, "ctx/out is NULL");
+    *out = nullptr;
+    if ((n_flat && !flat) || (n && !shape_aabbs)) return fail(ctx, BVHGPU_INVALID_ARG, "NULL argument");
+    if (n_flat >= 0xFFFFFFFFull) return fail(ctx, BVHGPU_OVERFLOW, "flat array too long");
+    // validate indices; every entry maps 1:1 to a traversal entry (no folding: the uploaded shapes
+    // may have moved since the build, flat_bvh.rs:411-418 re-tests shape.aabb())
+    std::vector<TravNode<T>> trav(n_flat);
+    for (size_t i = 0; i < n_flat; i++) {
+        const auto& f = flat[i];
+        TravNode<T> tn;
+        std::memset(&tn, 0, sizeof tn);
+        if (f.entry == NONE) {  // leaf entry
+            if (f.shape >= n) return fail(ctx, BVHGPU_INVALID_ARG, "flat leaf refers to a shape out of range");
+            if (f.exit != i + 1) return fail(ctx, BVHGPU_INVALID_ARG, "flat leaf exit_index must be index+1");
+            const T* sb = shape_aabbs + 6 * (size_t)f.shape;
+            for (int k = 0; k < 3; k++) { tn.mn[k] = sb[k]; tn.mx[k] = sb[3 + k]; }
+            tn.exit = (uint32_t)(i + 1);
+            tn.shape = f.shape;
+        } else {
+            if (f.entry != i + 1 || f.exit <= i || f.exit > n_flat)
+                return fail(ctx, BVHGPU_INVALID_ARG, "flat navigator entry/exit out of range");
+            for (int k = 0; k < 3; k++) { tn.mn[k] = f.min[k]; tn.mx[k] = f.max[k]; }
+            tn.exit = f.exit;
+            tn.shape = NONE;
+        }
+        trav[i] = tn;
+    }
+    bvhgpu_tree* t = new bvhgpu_tree();
+    t->ctx = ctx; t->dtype = Traits<T>::dtype; t->n = n; t->n_nodes = 0; t->n_flat = n_flat; t->n_trav = n_flat;
+    int rc = guarded(ctx, [&] {
+        use_device(ctx);
+        t->aabbs.reserve(n * 6 * sizeof(T) + 16);
+        t->trav.reserve(n_flat * sizeof(TravNode<T>) + 16);
+        t->flat.reserve(n_flat * sizeof(typename Traits<T>::Flat) + 16);
+        if (n) BVH_HIP(hipMemcpyAsync(t->aabbs.p, shape_aabbs, n * 6 * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        if (n_flat) {
+            BVH_HIP(hipMemcpyAsync(t->trav.p, trav.data(), n_flat * sizeof(TravNode<T>), hipMemcpyHostToDevice, ctx->stream));
+            BVH_HIP(hipMemcpyAsync(t->flat.p, flat, n_flat * sizeof(typename Traits<T>::Flat), hipMemcpyHostToDevice, ctx->stream));
+        }
+        BVH_HIP(hipStreamSynchronize(ctx->stream));
+        return (int)BVHGPU_OK;
+    });
+    if (rc != BVHGPU_OK) { free_tree_buffers(t); delete t; return rc; }
+    t->built = false; t->flattened = true; t->unfolded = true;
+    *out = t;
+    return BVHGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bvhgpu_abi_version(void) { return BVHGPU_ABI_VERSION; }
+
+int bvhgpu_device_count(int* out) {
+    if (!out) return BVHGPU_INVALID_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *out = 0; (void)hipGetLastError(); return BVHGPU_OK; }
+    *out = n;
+    return BVHGPU_OK;
+}
+
+const char* bvhgpu_status_string(int s) {
+    switch (s) {
+        case BVHGPU_OK: return "ok";
+        case BVHGPU_INVALID_ARG: return "invalid argument";
+        case BVHGPU_HIP_ERROR: return "HIP error";
+        case BVHGPU_OOM: return "out of memory";
+        case BVHGPU_OVERFLOW: return "index overflow";
+        case BVHGPU_NO_DEVICE: return "no MI355X / HIP device available";
+        case BVHGPU_DTYPE_MISMATCH: return "dtype mismatch";
+        case BVHGPU_NOT_FLATTENED: return "tree not flattened";
+        default: return "unknown status";
+    }
+}
+
+int bvhgpu_create(int device, void* stream, bvhgpu_ctx** out) {
+    if (!out) return BVHGPU_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(nullptr, BVHGPU_NO_DEVICE, "no HIP device"); }
+    if (device < 0 || device >= n) return fail(nullptr, BVHGPU_INVALID_ARG, "device index out of range");
+    bvhgpu_ctx* ctx = new bvhgpu_ctx();
+    ctx->device = device;
+    int rc = guarded(ctx, [&] {
+        BVH_HIP(hipSetDevice(device));
+        if (stream) { ctx->stream = static_cast<hipStream_t>(stream); ctx->own_stream = false; }
+        else { BVH_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+        hipDeviceProp_t prop;
+        BVH_HIP(hipGetDeviceProperties(&prop, device));
+        ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        for (auto& e : ctx->ev) BVH_HIP(hipEventCreate(&e));
+        BVH_HIP(hipHostMalloc(&ctx->pinned, 4096, hipHostMallocDefault));
+        return (int)BVHGPU_OK;
+    });
+    if (rc != BVHGPU_OK) { g_noctx_err = ctx->err; delete ctx; return rc; }
+    *out = ctx;
+    return BVHGPU_OK;
+}
+
+void bvhgpu_destroy(bvhgpu_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->upload.release();
+    ctx->counters.release();
+    for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* bvhgpu_last_error(const bvhgpu_ctx* ctx) { return ctx ? ctx->err.c_str() : g_noctx_err.c_str(); }
+
+int bvhgpu_synchronize(bvhgpu_ctx* ctx) {
+    if (!ctx) return BVHGPU_INVALID_ARG;
+    return guarded(ctx, [&] { BVH_HIP(hipStreamSynchronize(ctx->stream)); return (int)BVHGPU_OK; });
+}
+
+void* bvhgpu_stream(bvhgpu_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int bvhgpu_build_f32(bvhgpu_ctx* ctx, const float* aabbs, size_t n, int mem, bvhgpu_tree** out) {
+    return new_build<float>(ctx, aabbs, n, mem, out);
+}
+int bvhgpu_build_f64(bvhgpu_ctx* ctx, const double* aabbs, size_t n, int mem, bvhgpu_tree** out) {
+    return new_build<double>(ctx, aabbs, n, mem, out);
+}
+int bvhgpu_rebuild_f32(bvhgpu_tree* t, const float* aabbs, size_t n, int mem) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    if (t->dtype != BVHGPU_F32) return fail(t->ctx, BVHGPU_DTYPE_MISMATCH, "tree is f64");
+    return guarded(t->ctx, [&] { return do_build<float>(t, aabbs, n, mem); });
+}
+int bvhgpu_rebuild_f64(bvhgpu_tree* t, const double* aabbs, size_t n, int mem) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    if (t->dtype != BVHGPU_F64) return fail(t->ctx, BVHGPU_DTYPE_MISMATCH, "tree is f32");
+    return guarded(t->ctx, [&] { return do_build<double>(t, aabbs, n, mem); });
+}
+
+void bvhgpu_tree_destroy(bvhgpu_tree* t) {
+    if (!t) return;
+    if (t->ctx) { (void)hipSetDevice(t->ctx->device); (void)hipStreamSynchronize(t->ctx->stream); }
+    free_tree_buffers(t);
+    delete t;
+}
+
+int bvhgpu_tree_info(const bvhgpu_tree* t, int* dtype, size_t* n_shapes, size_t* n_nodes, size_t* n_flat) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    if (dtype) *dtype = t->dtype;
+    if (n_shapes) *n_shapes = t->n;
+    if (n_nodes) *n_nodes = t->n_nodes;
+    if (n_flat) *n_flat = t->n_flat;
+    return BVHGPU_OK;
+}
+
+int bvhgpu_tree_nodes(bvhgpu_tree* t, void* out, int mem) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    if (!t->built) return fail(t->ctx, BVHGPU_INVALID_ARG, "tree has no node array (imported scene)");
+    if (t->n_nodes && !out) return fail(t->ctx, BVHGPU_INVALID_ARG, "out is NULL");
+    return guarded(t->ctx, [&] {
+        use_device(t->ctx);
+        size_t sz = t->dtype == BVHGPU_F32 ? sizeof(bvhgpu_node_f32) : sizeof(bvhgpu_node_f64);
+        copy_out(t->ctx, out, t->nodes.p, t->n_nodes * sz, mem);
+        return (int)BVHGPU_OK;
+    });
+}
+
+int bvhgpu_tree_shape_nodes(bvhgpu_tree* t, uint32_t* out, int mem) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    if (!t->built) return fail(t->ctx, BVHGPU_INVALID_ARG, "tree has no node array (imported scene)");
+    if (t->n && !out) return fail(t->ctx, BVHGPU_INVALID_ARG, "out is NULL");
+    return guarded(t->ctx, [&] {
+        use_device(t->ctx);
+        copy_out(t->ctx, out, t->shape_node.p, t->n * 4, mem);
+        return (int)BVHGPU_OK;
+    });
+}
+
+int bvhgpu_tree_build_levels(const bvhgpu_tree* t, int* levels) {
+    if (!t || !levels) return BVHGPU_INVALID_ARG;
+    *levels = t->levels;
+    return BVHGPU_OK;
+}
+
+int bvhgpu_flatten(bvhgpu_tree* t) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    if (!t->built) return fail(t->ctx, BVHGPU_INVALID_ARG, "tree has no node array (imported scene)");
+    bvhgpu_ctx* ctx = t->ctx;
+    return guarded(ctx, [&] {
+        use_device(ctx);
+        if (ctx->timing) BVH_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+        if (t->dtype == BVHGPU_F32) flatten_tree<float>(t); else flatten_tree<double>(t);
+        if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[3], ctx->stream)); ctx->ev_set |= 2u; }
+        return (int)BVHGPU_OK;
+    });
+}
+
+int bvhgpu_flat_nodes(bvhgpu_tree* t, void* out, int mem) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    if (!t->flattened || !t->built) return fail(t->ctx, BVHGPU_NOT_FLATTENED, "call bvhgpu_flatten first");
+    if (t->n_flat && !out) return fail(t->ctx, BVHGPU_INVALID_ARG, "out is NULL");
+    return guarded(t->ctx, [&] {
+        use_device(t->ctx);
+        size_t sz = t->dtype == BVHGPU_F32 ? sizeof(bvhgpu_flat_f32) : sizeof(bvhgpu_flat_f64);
+        copy_out(t->ctx, out, t->flat.p, t->n_flat * sz, mem);
+        return (int)BVHGPU_OK;
+    });
+}
+
+int bvhgpu_tree_from_flat_f32(bvhgpu_ctx* ctx, const bvhgpu_flat_f32* flat, size_t n_flat, const float* shape_aabbs, size_t n,
+                              bvhgpu_tree** out) {
+    return tree_from_flat<float>(ctx, flat, n_flat, shape_aabbs, n, out);
+}
+int bvhgpu_tree_from_flat_f64(bvhgpu_ctx* ctx, const bvhgpu_flat_f64* flat, size_t n_flat, const double* shape_aabbs, size_t n,
+                              bvhgpu_tree** out) {
+    return tree_from_flat<double>(ctx, flat, n_flat, shape_aabbs, n, out);
+}
+
+// ---- scene blob: header | traversal array | shape AABBs ----
+struct SceneHeader { uint32_t magic, dtype; uint64_t n, n_trav; uint32_t unfolded, _pad; uint64_t trav_bytes, aabb_bytes; };
+static constexpr uint32_t SCENE_MAGIC = 0x42564833u;  // "BVH3"
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+int bvhgpu_scene_nbytes(const bvhgpu_tree* t, size_t* nbytes) {
+    if (!t || !nbytes) return BVHGPU_INVALID_ARG;
+    if (!t->flattened) return BVHGPU_NOT_FLATTENED;
+    size_t tsz = t->dtype == BVHGPU_F32 ? sizeof(TravNode<float>) : sizeof(TravNode<double>);
+    size_t ssz = t->dtype == BVHGPU_F32 ? 4 : 8;
+    *nbytes = 256 + align256(t->n_trav * tsz) + align256(t->n * 6 * ssz);
+    return BVHGPU_OK;
+}
+
+int bvhgpu_scene_export(bvhgpu_tree* t, void* dst, int mem) {
+    if (!t || !dst) return BVHGPU_INVALID_ARG;
+    if (!t->flattened) return fail(t->ctx, BVHGPU_NOT_FLATTENED, "call bvhgpu_flatten first");
+    bvhgpu_ctx* ctx = t->ctx;
+    return guarded(ctx, [&] {
+        use_device(ctx);
+        size_t tsz = t->dtype == BVHGPU_F32 ? sizeof(TravNode<float>) : sizeof(TravNode<double>);
+        size_t ssz = t->dtype == BVHGPU_F32 ? 4 : 8;
+        SceneHeader* h = reinterpret_cast<SceneHeader*>(ctx->pinned);
+        std::memset(h, 0, 256);
+        h->magic = SCENE_MAGIC; h->dtype = (uint32_t)t->dtype; h->n = t->n; h->n_trav = t->n_trav;
+        h->unfolded = t->unfolded ? 1u : 0u;
+        h->trav_bytes = t->n_trav * tsz; h->aabb_bytes = t->n * 6 * ssz;
+        char* d = static_cast<char*>(dst);
+        const hipMemcpyKind kd = mem == BVHGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        BVH_HIP(hipMemcpyAsync(d, h, 256, mem == BVHGPU_DEVICE ? hipMemcpyHostToDevice : hipMemcpyHostToHost, ctx->stream));
+        if (h->trav_bytes) BVH_HIP(hipMemcpyAsync(d + 256, t->trav.p, h->trav_bytes, kd, ctx->stream));
+        if (h->aabb_bytes) BVH_HIP(hipMemcpyAsync(d + 256 + align256(h->trav_bytes), t->aabbs.p, h->aabb_bytes, kd, ctx->stream));
+        BVH_HIP(hipStreamSynchronize(ctx->stream));  // the pinned header page is reused by the next call
+        return (int)BVHGPU_OK;
+    });
+}
+
+int bvhgpu_scene_import(bvhgpu_ctx* ctx, const void* src, size_t nbytes, int mem, bvhgpu_tree** out) {
+    if (!ctx || !out || !src) return fail(ctx, BVHGPU_INVALID_ARG, "NULL argument");
+    if (nbytes < 256) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob too small");
+    bvhgpu_tree* given = *out;
+    if (given && (given->built || given->ctx != ctx))
+        return fail(ctx, BVHGPU_INVALID_ARG, "*out must be NULL or a tree from bvhgpu_scene_import on this ctx");
+    bvhgpu_tree* t = given ? given : new bvhgpu_tree();
+    t->ctx = ctx;
+    int rc = guarded(ctx, [&] {
+        use_device(ctx);
+        SceneHeader* h = reinterpret_cast<SceneHeader*>(ctx->pinned);
+        const char* s = static_cast<const char*>(src);
+        BVH_HIP(hipMemcpyAsync(h, s, 256, mem == BVHGPU_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, ctx->stream));
+        BVH_HIP(hipStreamSynchronize(ctx->stream));
+        if (h->magic != SCENE_MAGIC || h->dtype > 1) return fail(ctx, BVHGPU_INVALID_ARG, "not a bvhgpu scene blob");
+        if (256 + align256(h->trav_bytes) + align256(h->aabb_bytes) > nbytes) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob truncated");
+        t->dtype = (int)h->dtype; t->n = h->n; t->n_trav = h->n_trav; t->n_nodes = 0; t->n_flat = 0;
+        t->unfolded = h->unfolded != 0;
+        const size_t tb = h->trav_bytes, ab = h->aabb_bytes;
+        t->trav.reserve(tb + 16);
+        t->aabbs.reserve(ab + 16);
+        const hipMemcpyKind kd = mem == BVHGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        if (tb) BVH_HIP(hipMemcpyAsync(t->trav.p, s + 256, tb, kd, ctx->stream));
+        if (ab) BVH_HIP(hipMemcpyAsync(t->aabbs.p, s + 256 + align256(tb), ab, kd, ctx->stream));
+        if (mem != BVHGPU_DEVICE) BVH_HIP(hipStreamSynchronize(ctx->stream));
+        t->built = false; t->flattened = true;
+        return (int)BVHGPU_OK;
+    });
+    if (rc != BVHGPU_OK) { if (!given) { free_tree_buffers(t); delete t; } return rc; }
+    *out = t;
+    return BVHGPU_OK;
+}
+
+// ---- rays ----
+int bvhgpu_rays_new_f32(bvhgpu_ctx* ctx, const float* o, const float* d, size_t n, int mem_in, bvhgpu_ray_f32* out, int mem_out) {
+    return do_rays_new<float>(ctx, o, d, n, mem_in, out, mem_out);
+}
+int bvhgpu_rays_new_f64(bvhgpu_ctx* ctx, const double* o, const double* d, size_t n, int mem_in, bvhgpu_ray_f64* out, int mem_out) {
+    return do_rays_new<double>(ctx, o, d, n, mem_in, out, mem_out);
+}
+int bvhgpu_gen_rays_f32(bvhgpu_ctx* ctx, uint64_t first, size_t n, const float bounds[6], bvhgpu_ray_f32* out_dev) {
+    if (!ctx || !bounds || (n && !out_dev)) return fail(ctx, BVHGPU_INVALID_ARG, "NULL argument");
+    if (n >= 0xFFFFFFFFull) return fail(ctx, BVHGPU_OVERFLOW, "too many rays in one call");
+    return guarded(ctx, [&] { use_device(ctx); gen_rays_f32(ctx, first, n, bounds, out_dev); return (int)BVHGPU_OK; });
+}
+int bvhgpu_gen_rays_f64(bvhgpu_ctx* ctx, uint64_t first, size_t n, const float bounds[6], bvhgpu_ray_f64* out_dev) {
+    if (!ctx || !bounds || (n && !out_dev)) return fail(ctx, BVHGPU_INVALID_ARG, "NULL argument");
+    if (n >= 0xFFFFFFFFull) return fail(ctx, BVHGPU_OVERFLOW, "too many rays in one call");
+    return guarded(ctx, [&] { use_device(ctx); gen_rays_f64(ctx, first, n, bounds, out_dev); return (int)BVHGPU_OK; });
+}
+
+// ---- traverse ----
+int bvhgpu_traverse_f32(bvhgpu_tree* tree, const bvhgpu_ray_f32* rays, size_t n_rays, int mem, unsigned flags, bvhgpu_hits** hits) {
+    return do_traverse<float>(tree, rays, n_rays, mem, flags, hits);
+}
+int bvhgpu_traverse_f64(bvhgpu_tree* tree, const bvhgpu_ray_f64* rays, size_t n_rays, int mem, unsigned flags, bvhgpu_hits** hits) {
+    return do_traverse<double>(tree, rays, n_rays, mem, flags, hits);
+}
+
+int bvhgpu_hits_info(const bvhgpu_hits* h, size_t* n_rays, uint64_t* total, bvhgpu_traverse_stats* stats) {
+    if (!h) return BVHGPU_INVALID_ARG;
+    if (n_rays) *n_rays = h->n_rays;
+    if (total) *total = h->total;
+    if (stats) *stats = h->stats;
+    return BVHGPU_OK;
+}
+
+int bvhgpu_hits_fetch(bvhgpu_hits* h, uint32_t* offsets, uint32_t* indices, void* tslice, int mem) {
+    if (!h || !h->ctx) return BVHGPU_INVALID_ARG;
+    bvhgpu_ctx* ctx = h->ctx;
+    if (tslice && !(h->flags & BVHGPU_TRAVERSE_T_SLICE)) return fail(ctx, BVHGPU_INVALID_ARG, "traverse was run without BVHGPU_TRAVERSE_T_SLICE");
+    return guarded(ctx, [&] {
+        use_device(ctx);
+        if (offsets) copy_out(ctx, offsets, h->offsets.p, (h->n_rays + 1) * 4, mem);
+        if (indices && h->total) copy_out(ctx, indices, h->indices.p, h->total * 4, mem);
+        if (tslice && h->total) copy_out(ctx, tslice, h->tslice.p, h->total * 2 * (h->dtype == BVHGPU_F32 ? 4 : 8), mem);
+        return (int)BVHGPU_OK;
+    });
+}
+
+int bvhgpu_hits_device(const bvhgpu_hits* h, const uint32_t** offsets, const uint32_t** indices, const void** tslice) {
+    if (!h) return BVHGPU_INVALID_ARG;
+    if (offsets) *offsets = h->offsets.as<uint32_t>();
+    if (indices) *indices = h->indices.as<uint32_t>();
+    if (tslice) *tslice = (h->flags & BVHGPU_TRAVERSE_T_SLICE) ? h->tslice.p : nullptr;
+    return BVHGPU_OK;
+}
+
+void bvhgpu_hits_destroy(bvhgpu_hits* h) {
+    if (!h) return;
+    if (h->ctx) { (void)hipSetDevice(h->ctx->device); (void)hipStreamSynchronize(h->ctx->stream); }
+    h->counts.release(); h->offsets.release(); h->pool.release(); h->pool_t.release();
+    h->indices.release(); h->tslice.release(); h->blocksums.release(); h->ctr.release();
+    delete h;
+}
+
+int bvhgpu_enable_timing(bvhgpu_ctx* ctx, int on) {
+    if (!ctx) return BVHGPU_INVALID_ARG;
+    ctx->timing = on != 0;
+    return BVHGPU_OK;
+}
+int bvhgpu_last_timings(bvhgpu_ctx* ctx, bvhgpu_timings* out) {
+    if (!ctx || !out) return BVHGPU_INVALID_ARG;
+    return guarded(ctx, [&] {
+        use_device(ctx);
+        BVH_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->ev_set & 1u) (void)hipEventElapsedTime(&ctx->last.build_ms, ctx->ev[0], ctx->ev[1]);
+        if (ctx->ev_set & 2u) (void)hipEventElapsedTime(&ctx->last.flatten_ms, ctx->ev[2], ctx->ev[3]);
+        if (ctx->ev_set & 4u) {
+            (void)hipEventElapsedTime(&ctx->last.traverse_kernel_ms, ctx->ev[4], ctx->ev[5]);
+            (void)hipEventElapsedTime(&ctx->last.traverse_total_ms, ctx->ev[4], ctx->ev[6]);
+        }
+        *out = ctx->last;
+        return (int)BVHGPU_OK;
+    });
+}
+
+}  // extern "C"

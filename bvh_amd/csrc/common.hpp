@@ -1,0 +1,202 @@
+// common.hpp — shared device/host definitions of the MI355X BVH engine (gfx950, wave64).
+//
+// Arithmetic discipline (DESIGN.md §"Floating point"): every + - * / sqrt on the path is ONE
+// correctly rounded IEEE-754 operation, exactly like the Rust reference.  This file is compiled
+// with -ffp-contract=off (no FMA contraction) and without fast-math; hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt keeps `/` and sqrt correctly rounded.  min/max
+// reductions are exact, so they may be re-associated freely (atomics, scans, shuffles).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cfloat>
+#include <cmath>
+
+#include "../../include/bvh_mi355x.h"
+
+namespace bvhgpu {
+
+constexpr uint32_t NONE = BVHGPU_NONE;
+constexpr int NUM_BUCKETS = 6;        // reference: src/bvh/bucket.rs:5
+constexpr int WAVE = 64;              // gfx950 wavefront
+constexpr int SMALL_MAX = 64;         // segments <= one wave are finished by the wave-subtree kernel
+constexpr int TILE = 1024;            // positions per workgroup tile in the level-synchronous tier
+constexpr int STAT_KEYS = 12;         // aabb min3,max3, centroid min3,max3
+
+// ------------------------------------------------------------------------------------------------
+// per-scalar-type traits
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Traits;
+
+template <> struct Traits<float> {
+    using Key = uint32_t;
+    using Node = bvhgpu_node_f32;
+    using Flat = bvhgpu_flat_f32;
+    using Ray = bvhgpu_ray_f32;
+    static constexpr int dtype = BVHGPU_F32;
+    __host__ __device__ static constexpr float eps() { return FLT_EPSILON; }  // T::epsilon(), bvh_node.rs:114
+    __host__ __device__ static float inf() { return INFINITY; }
+    // monotone float -> unsigned map (IEEE-754-2019 total order on NaN-free data: -0 < +0)
+    __host__ __device__ static Key key(float f) {
+        uint32_t b;
+        __builtin_memcpy(&b, &f, 4);
+        return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+    }
+    __host__ __device__ static float unkey(Key k) {
+        uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+        float f;
+        __builtin_memcpy(&f, &b, 4);
+        return f;
+    }
+    static constexpr Key KEY_POS_INF = 0xFF800000u;  // key(+inf): identity of min
+    static constexpr Key KEY_NEG_INF = 0x007FFFFFu;  // key(-inf): identity of max
+};
+
+template <> struct Traits<double> {
+    using Key = unsigned long long;
+    using Node = bvhgpu_node_f64;
+    using Flat = bvhgpu_flat_f64;
+    using Ray = bvhgpu_ray_f64;
+    static constexpr int dtype = BVHGPU_F64;
+    __host__ __device__ static constexpr double eps() { return DBL_EPSILON; }
+    __host__ __device__ static double inf() { return INFINITY; }
+    __host__ __device__ static Key key(double f) {
+        unsigned long long b;
+        __builtin_memcpy(&b, &f, 8);
+        return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+    }
+    __host__ __device__ static double unkey(Key k) {
+        unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+        double f;
+        __builtin_memcpy(&f, &b, 8);
+        return f;
+    }
+    static constexpr Key KEY_POS_INF = 0xFFF0000000000000ull;
+    static constexpr Key KEY_NEG_INF = 0x000FFFFFFFFFFFFFull;
+};
+
+// ------------------------------------------------------------------------------------------------
+// engine-private traversal node ("folded" pre-order array, DESIGN.md §"Traversal layout"):
+// one entry per non-root tree node; on a slab hit go to i+1, on a miss go to `exit`; an entry
+// whose `shape` != NONE reports that shape when hit.  32 B (f32) / 64 B (f64), naturally aligned
+// so a lane fetches it with two (four) 16-byte loads.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct TravNode;
+template <> struct __attribute__((aligned(32))) TravNode<float> {
+    float mn[3];
+    uint32_t exit;
+    float mx[3];
+    uint32_t shape;
+};
+template <> struct __attribute__((aligned(64))) TravNode<double> {
+    double mn[3];
+    double mx[3];
+    uint32_t exit;
+    uint32_t shape;
+    uint64_t _pad;
+};
+static_assert(sizeof(TravNode<float>) == 32, "trav f32");
+static_assert(sizeof(TravNode<double>) == 64, "trav f64");
+
+// work item of the builder: one tree node still to be split (BvhNodeBuildArgs, bvh_node.rs:437-446)
+template <typename T> struct Item {
+    uint32_t ni;       // node_index
+    uint32_t parent;   // parent_index
+    uint32_t start;    // first position of its index slice
+    uint32_t count;    // indices.len()
+    uint32_t tile_base;
+    uint32_t parity;   // which idx buffer holds its slice
+    uint32_t _r0, _r1;
+    T A[6];            // aabb_bounds
+    T C[6];            // centroid_bounds
+};
+
+// ------------------------------------------------------------------------------------------------
+// exact Aabb helpers (each cites src/aabb/aabb_impl.rs)
+// ------------------------------------------------------------------------------------------------
+template <typename T> __host__ __device__ inline T tmin(T a, T b) {  // inf (:305); -0 < +0
+    return (a < b || (a == b && signbit(a))) ? a : b;
+}
+template <typename T> __host__ __device__ inline T tmax(T a, T b) {  // sup (:306)
+    return (a > b || (a == b && !signbit(a))) ? a : b;
+}
+// center = min*0.5 + max*0.5 (:501-504) — two multiplies and one add, never (min+max)*0.5
+template <typename T> __host__ __device__ inline T center1(T mn, T mx) {
+    T lo = mn * (T)0.5;
+    T hi = mx * (T)0.5;
+    return lo + hi;
+}
+// surface_area = 2 * ((sx*sx + sy*sy) + sz*sz) (:551-554 with nalgebra's 3-vector dot)
+template <typename T> __host__ __device__ inline T surface_area(const T* b) {
+    T sx = b[3] - b[0], sy = b[4] - b[1], sz = b[5] - b[2];
+    T xx = sx * sx, yy = sy * sy, zz = sz * sz;
+    T d = xx + yy;
+    d = d + zz;
+    return (T)2 * d;
+}
+// largest_axis = size.imax(): first strict maximum (:594-596)
+template <typename T> __host__ __device__ inline int largest_axis(const T* b) {
+    T s0 = b[3] - b[0], s1 = b[4] - b[1], s2 = b[5] - b[2];
+    int a = 0;
+    T m = s0;
+    if (s1 > m) { m = s1; a = 1; }
+    if (s2 > m) { m = s2; a = 2; }
+    return a;
+}
+// bucket index (bvh_node.rs:210-217): trunc(((c - cmin) / ext) * (T(6) - T(0.01)))
+template <typename T> __host__ __device__ inline int bucket_of(T c, T cmin, T ext) {
+    const T K = (T)NUM_BUCKETS - (T)0.01;
+    T rel = (c - cmin) / ext;
+    T scaled = rel * K;
+    return (int)scaled;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ray / AABB slab test (src/ray/intersect_default.rs:16-37) — bit-exact boolean
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ bool slab_hit(const T o[3], const T inv[3], const T mn[3], const T mx[3], T& tmin_out,
+                                         T& tmax_out) {
+    T l0 = (mn[0] - o[0]) * inv[0], h0 = (mx[0] - o[0]) * inv[0];
+    T l1 = (mn[1] - o[1]) * inv[1], h1 = (mx[1] - o[1]) * inv[1];
+    T l2 = (mn[2] - o[2]) * inv[2], h2 = (mx[2] - o[2]) * inv[2];
+    // has_nan(lbr) | has_nan(rtr) -> miss (:22-28).  x != x is the NaN test.
+    bool nan = (l0 != l0) | (h0 != h0) | (l1 != l1) | (h1 != h1) | (l2 != l2) | (h2 != h2);
+    // NaN-free from here: min/max are exact and order-free
+    T a0 = l0 < h0 ? l0 : h0, b0 = l0 < h0 ? h0 : l0;
+    T a1 = l1 < h1 ? l1 : h1, b1 = l1 < h1 ? h1 : l1;
+    T a2 = l2 < h2 ? l2 : h2, b2 = l2 < h2 ? h2 : l2;
+    T tmn = a0 > a1 ? a0 : a1;
+    tmn = tmn > a2 ? tmn : a2;
+    T tmx = b0 < b1 ? b0 : b1;
+    tmx = tmx < b2 ? tmx : b2;
+    T z = tmn > (T)0 ? tmn : (T)0;  // fast_max(tmin, 0) (utils.rs:52-54)
+    tmin_out = z;                   // intersection_slice_for_aabb's tmin (ray_impl.rs:135)
+    tmax_out = tmx;
+    return !nan && (tmx >= z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave64 helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    int l = lane_id();
+    return l == 0 ? 0ull : (~0ull >> (64 - l));
+}
+__device__ __forceinline__ unsigned long long mask_range(int lo, int hi) {  // bits [lo, hi)
+    unsigned long long h = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+    unsigned long long l = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
+    return h & ~l;
+}
+
+// error plumbing -------------------------------------------------------------------------------
+struct HipFail { hipError_t err; const char* what; int line; };
+#define BVH_HIP(x)                                                     \
+    do {                                                               \
+        hipError_t _e = (x);                                           \
+        if (_e != hipSuccess) throw ::bvhgpu::HipFail{_e, #x, __LINE__}; \
+    } while (0)
+
+}  // namespace bvhgpu

@@ -1,0 +1,119 @@
+// engine.hpp — host-side objects behind the opaque C handles, and the per-phase entry points
+// implemented in build.hip / flatten.hip / traverse.hip.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace bvhgpu {
+
+// RAII-less device buffer that only ever grows (no allocation on the steady-state hot loop)
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            throw HipFail{e, "hipMalloc", __LINE__};
+        }
+        cap = want;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename U> U* as() const { return reinterpret_cast<U*>(p); }
+};
+
+}  // namespace bvhgpu
+
+struct bvhgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    int n_cu = 256;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[8] = {};
+    unsigned ev_set = 0;  // bit0 build pair recorded, bit1 flatten, bit2 traverse
+    bvhgpu_timings last = {0, 0, 0, 0};
+    // scratch
+    bvhgpu::DevBuf upload;    // staging for host→device inputs (aabbs / rays)
+    bvhgpu::DevBuf counters;  // small device counters
+    void* pinned = nullptr;   // 4 KiB pinned host page for tiny D2H reads
+};
+
+struct bvhgpu_tree {
+    bvhgpu_ctx* ctx = nullptr;
+    int dtype = BVHGPU_F32;
+    size_t n = 0;         // shapes
+    size_t n_nodes = 0;   // 2n-1
+    size_t n_flat = 0;    // 3n-2 (1 if n==1)
+    size_t n_trav = 0;    // 2n-2 (1 if n==1)
+    bool built = false;     // has nodes / shape_node (false for imported scenes)
+    bool flattened = false; // has trav (+ flat if built)
+    bool unfolded = false;  // trav mirrors an uploaded FlatBvh 1:1 (nav and leaf entries kept apart)
+    int levels = 0;
+    // persistent device arrays
+    bvhgpu::DevBuf aabbs;       // n * 6 T
+    bvhgpu::DevBuf nodes;       // n_nodes * Node
+    bvhgpu::DevBuf node_start;  // n_nodes * u32   (leaves before node = first sorted position)
+    bvhgpu::DevBuf node_count;  // n_nodes * u32   (shapes under node)
+    bvhgpu::DevBuf shape_node;  // n * u32
+    bvhgpu::DevBuf flat;        // n_flat * Flat     (reference layout, for export/parity)
+    bvhgpu::DevBuf trav;        // n_trav * TravNode (engine layout, what traversal reads)
+    // build scratch (kept for rebuild)
+    bvhgpu::DevBuf idx[2];      // n * u32 ping-pong permutation
+    bvhgpu::DevBuf bk;          // n * u8 bucket per position
+    bvhgpu::DevBuf big[2];      // Item queues of the level-synchronous tier
+    bvhgpu::DevBuf small;       // Item queue of the wave-subtree tier
+    bvhgpu::DevBuf stats[2];    // per big item: 6 x (12 keys) + 6 counts
+    bvhgpu::DevBuf tile_item[2];
+    bvhgpu::DevBuf tile_cnt;    // per tile 6 x u32 (counts, then exclusive offsets)
+    bvhgpu::DevBuf ctr;         // counters
+};
+
+struct bvhgpu_hits {
+    bvhgpu_ctx* ctx = nullptr;
+    int dtype = BVHGPU_F32;
+    size_t n_rays = 0;
+    uint64_t total = 0;
+    unsigned flags = 0;
+    bvhgpu_traverse_stats stats = {0, 0, 0, 0};
+    bvhgpu::DevBuf counts;   // n_rays+1 u32 (counts, scanned in place into offsets)
+    bvhgpu::DevBuf offsets;  // n_rays+1 u32
+    bvhgpu::DevBuf pool;     // hit records (ray, k, shape)
+    bvhgpu::DevBuf pool_t;   // 2 T per record
+    bvhgpu::DevBuf indices;  // total u32
+    bvhgpu::DevBuf tslice;   // total * 2 T
+    bvhgpu::DevBuf blocksums;
+    bvhgpu::DevBuf ctr;      // [0] pool count (u64) [1] visited [2] leaf_visits [3] device_steps [4] ray ticket
+    size_t pool_cap = 0;
+};
+
+namespace bvhgpu {
+
+// build.hip
+template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t n);
+// flatten.hip
+template <typename T> void flatten_tree(bvhgpu_tree* t);
+// traverse.hip
+template <typename T>
+void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, unsigned flags,
+                    bvhgpu_hits* h);
+template <typename T>
+void rays_new(bvhgpu_ctx* ctx, const T* origins_dev, const T* dirs_dev, size_t n, typename Traits<T>::Ray* out_dev);
+void gen_rays_f32(bvhgpu_ctx* ctx, uint64_t first, size_t n, const float bounds[6], bvhgpu_ray_f32* out_dev);
+void gen_rays_f64(bvhgpu_ctx* ctx, uint64_t first, size_t n, const float bounds[6], bvhgpu_ray_f64* out_dev);
+
+}  // namespace bvhgpu

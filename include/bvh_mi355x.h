@@ -1,0 +1,175 @@
+/*
+ * bvh_mi355x.h — C ABI of libbvh_mi355x.so: the MI355X (gfx950 / CDNA4) engine for the hot path
+ * of the Rust crate `bvh` 0.12.0 (svenstaro/bvh): SAH build → flatten → batched ray traversal.
+ *
+ * The reference has no FFI of its own (pure Rust); its extension points for this path are the
+ * `BoundingHierarchy` trait (src/bounding_hierarchy.rs:89-336), `Bvh::flatten_custom`
+ * (src/flat_bvh.rs:240-251) and `build_with_executor` (src/bvh/bvh_impl.rs:53-56).  Each entry
+ * point below names the reference interface it replaces (paths relative to the crate root).  The
+ * Rust-side binding a maintainer would add (a `GpuBvh` type that implements `BoundingHierarchy`
+ * over these symbols) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C types only; every function returns a bvhgpu_status (0 = OK) and never throws or
+ *    aborts across the boundary; bvhgpu_last_error(ctx) gives the text of the last failure.
+ *  - "mem" arguments say where a caller buffer lives: BVHGPU_HOST (pageable or pinned host
+ *    memory) or BVHGPU_DEVICE (HBM of the ctx's GPU, e.g. a torch tensor's data_ptr()).
+ *  - all work is enqueued on the ctx's HIP stream; host-visible results are complete when the
+ *    call returns (the call synchronises the stream), device-side results are ordered on the stream.
+ *  - a ctx is not internally locked: one ctx per host thread.  Trees are immutable after
+ *    build/flatten and may be traversed from several ctxs of the same device concurrently.
+ *  - Semantics are bit-exact with the reference for indices/topology: NUM_BUCKETS
+ *    = 6 (src/bvh/bucket.rs:5), pre-order node placement (src/bvh/bvh_node.rs:138-142), stable
+ *    bucket-major index rewrite (:250-272), strict-< first-wins SAH argmin (:239), surface_area =
+ *    2*dot(size,size) (src/aabb/aabb_impl.rs:551-554), NaN-in-slab = miss
+ *    (src/ray/intersect_default.rs:22-28).  Inputs are assumed NaN-free, as in the reference.
+ */
+#ifndef BVH_MI355X_H
+#define BVH_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BVHGPU_ABI_VERSION 1
+#define BVHGPU_NONE 0xFFFFFFFFu /* u32::MAX marker (flat_bvh.rs:51-53, :124, :137) */
+
+typedef enum {
+    BVHGPU_OK = 0,
+    BVHGPU_INVALID_ARG = 1,
+    BVHGPU_HIP_ERROR = 2,
+    BVHGPU_OOM = 3,
+    BVHGPU_OVERFLOW = 4,   /* > (2^32-2)/3 shapes (flat_bvh.rs:136 would truncate silently) or > 2^32-1 hits */
+    BVHGPU_NO_DEVICE = 5,
+    BVHGPU_DTYPE_MISMATCH = 6,
+    BVHGPU_NOT_FLATTENED = 7
+} bvhgpu_status;
+
+typedef enum { BVHGPU_F32 = 0, BVHGPU_F64 = 1 } bvhgpu_dtype;
+typedef enum { BVHGPU_HOST = 0, BVHGPU_DEVICE = 1 } bvhgpu_mem;
+
+/* traversal flags */
+#define BVHGPU_TRAVERSE_T_SLICE 1u /* also return (tmin,tmax) per hit: Ray::intersection_slice_for_aabb (ray_impl.rs:118-145) */
+#define BVHGPU_TRAVERSE_STATS 2u   /* also count reference-equivalent loop iterations (flat_bvh.rs:408) */
+
+/* ---- POD layouts (little-endian, natural alignment, no packing pragmas) ---- */
+
+/* Aabb<T,3> (aabb_impl.rs:10-16) is passed as 6 scalars: min x,y,z, max x,y,z. */
+
+/* enum BvhNode<T,3> (bvh_node.rs:21-47) as a POD.
+ * Node: shape == BVHGPU_NONE; l,r = child_l_index, child_r_index; l_min..r_max = child AABBs.
+ * Leaf: shape = shape_index; l = r = BVHGPU_NONE; AABB fields are zero. */
+typedef struct { float l_min[3], l_max[3], r_min[3], r_max[3]; uint32_t parent, l, r, shape; } bvhgpu_node_f32;  /*  64 B */
+typedef struct { double l_min[3], l_max[3], r_min[3], r_max[3]; uint32_t parent, l, r, shape; } bvhgpu_node_f64; /* 112 B */
+
+/* struct FlatNode<T,3> (flat_bvh.rs:17-46), same field order.  Leaf entries carry
+ * Aabb::empty() = (+inf,-inf) exactly like flat_bvh.rs:133. */
+typedef struct { float min[3], max[3]; uint32_t entry, exit, shape; } bvhgpu_flat_f32;                 /* 36 B */
+typedef struct { double min[3], max[3]; uint32_t entry, exit, shape, _pad; } bvhgpu_flat_f64;          /* 64 B */
+
+/* struct Ray<T,3> (ray_impl.rs:17-29), same field order: origin, direction (normalised), inv_direction. */
+typedef struct { float o[3], d[3], inv[3]; } bvhgpu_ray_f32;   /* 36 B */
+typedef struct { double o[3], d[3], inv[3]; } bvhgpu_ray_f64;  /* 72 B */
+
+typedef struct bvhgpu_ctx bvhgpu_ctx;
+typedef struct bvhgpu_tree bvhgpu_tree;
+typedef struct bvhgpu_hits bvhgpu_hits;
+
+typedef struct {
+    uint64_t hits;        /* total shapes returned                                                  */
+    uint64_t visited;     /* reference loop iterations (flat_bvh.rs:408) = slab tests; STATS flag   */
+    uint64_t leaf_visits; /* of which leaf entries (second test of a shape AABB, :411-418); STATS   */
+    uint64_t device_steps;/* node visits this engine actually performed (folded layout); STATS      */
+} bvhgpu_traverse_stats;
+
+/* ---- context ---- */
+int bvhgpu_abi_version(void);
+int bvhgpu_device_count(int *out);
+const char *bvhgpu_status_string(int status);
+/* One ctx = one GPU + one stream + scratch.  stream == NULL → the ctx creates its own stream;
+ * otherwise `stream` is a hipStream_t owned by the caller (e.g. torch's current stream). */
+int bvhgpu_create(int device, void *stream, bvhgpu_ctx **out);
+void bvhgpu_destroy(bvhgpu_ctx *ctx);
+const char *bvhgpu_last_error(const bvhgpu_ctx *ctx);
+int bvhgpu_synchronize(bvhgpu_ctx *ctx);
+void *bvhgpu_stream(bvhgpu_ctx *ctx); /* the hipStream_t work is enqueued on */
+
+/* ---- build: replaces Bvh::build / Bvh::build_par / build_with_executor (bvh_impl.rs:40-96,
+ * bounding_hierarchy.rs:158-177) once the caller has gathered shape.aabb() for every shape
+ * (aabb_impl.rs:28-56) into `aabbs` = n x [min xyz, max xyz].  n == 0 → valid empty tree
+ * (bvh_impl.rs:57-59).  The caller keeps `aabbs`; the tree owns its own HBM copy. ---- */
+int bvhgpu_build_f32(bvhgpu_ctx *ctx, const float *aabbs, size_t n, int mem, bvhgpu_tree **out);
+int bvhgpu_build_f64(bvhgpu_ctx *ctx, const double *aabbs, size_t n, int mem, bvhgpu_tree **out);
+/* Rebuild in place (same dtype, n <= capacity of the first build): no allocation on the hot loop. */
+int bvhgpu_rebuild_f32(bvhgpu_tree *tree, const float *aabbs, size_t n, int mem);
+int bvhgpu_rebuild_f64(bvhgpu_tree *tree, const double *aabbs, size_t n, int mem);
+void bvhgpu_tree_destroy(bvhgpu_tree *tree);
+
+int bvhgpu_tree_info(const bvhgpu_tree *tree, int *dtype, size_t *n_shapes, size_t *n_nodes, size_t *n_flat);
+/* Vec<BvhNode> (bvh_impl.rs:27-33): 2n-1 entries of bvhgpu_node_f32/_f64. */
+int bvhgpu_tree_nodes(bvhgpu_tree *tree, void *out, int mem);
+/* the argument of BHShape::set_bh_node_index for every shape (bvh_node.rs:102; bounding_hierarchy.rs:53-65). */
+int bvhgpu_tree_shape_nodes(bvhgpu_tree *tree, uint32_t *out, int mem);
+/* number of level-synchronous passes the last build needed (diagnostic). */
+int bvhgpu_tree_build_levels(const bvhgpu_tree *tree, int *levels);
+
+/* ---- flatten: replaces Bvh::flatten / flatten_custom (flat_bvh.rs:240-251, 312-319).  Produces the
+ * reference-layout FlatNode array (3n-2 entries) and the engine's own traversal array in HBM. ---- */
+int bvhgpu_flatten(bvhgpu_tree *tree);
+int bvhgpu_flat_nodes(bvhgpu_tree *tree, void *out, int mem);
+/* Upload a FlatBvh built elsewhere (e.g. by the Rust crate through flatten_custom with a #[repr(C)]
+ * constructor) together with the shapes' current AABBs; replaces FlatBvh ownership (flat_bvh.rs:254). */
+int bvhgpu_tree_from_flat_f32(bvhgpu_ctx *ctx, const bvhgpu_flat_f32 *flat, size_t n_flat, const float *shape_aabbs,
+                              size_t n, bvhgpu_tree **out);
+int bvhgpu_tree_from_flat_f64(bvhgpu_ctx *ctx, const bvhgpu_flat_f64 *flat, size_t n_flat, const double *shape_aabbs,
+                              size_t n, bvhgpu_tree **out);
+
+/* ---- scene transport for multi-GPU: one contiguous blob (traversal array + shape AABBs) that the
+ * caller broadcasts (RCCL via torch.distributed / ncclBroadcast) and imports on the peers.  A tree
+ * imported this way supports traversal only.  For bvhgpu_scene_import *out may point to NULL (a
+ * tree is allocated) or to a tree a previous bvhgpu_scene_import returned (its HBM is reused). ---- */
+int bvhgpu_scene_nbytes(const bvhgpu_tree *tree, size_t *nbytes);
+int bvhgpu_scene_export(bvhgpu_tree *tree, void *dst, int mem);
+int bvhgpu_scene_import(bvhgpu_ctx *ctx, const void *src, size_t nbytes, int mem, bvhgpu_tree **out);
+
+/* ---- rays ---- */
+/* Ray::new (ray_impl.rs:70-80) for a batch: normalise, cache 1/d.  origins/dirs: n x 3. */
+int bvhgpu_rays_new_f32(bvhgpu_ctx *ctx, const float *origins, const float *dirs, size_t n, int mem_in,
+                        bvhgpu_ray_f32 *out, int mem_out);
+int bvhgpu_rays_new_f64(bvhgpu_ctx *ctx, const double *origins, const double *dirs, size_t n, int mem_in,
+                        bvhgpu_ray_f64 *out, int mem_out);
+/* The bench harness' ray stream create_ray(seed, bounds) (testbase.rs:687-691, seed 0 at :825),
+ * rays [first, first+n) generated directly in HBM (`out` is device memory). */
+int bvhgpu_gen_rays_f32(bvhgpu_ctx *ctx, uint64_t first, size_t n, const float bounds[6], bvhgpu_ray_f32 *out_dev);
+/* same stream widened to f64 AFTER generation (f32 origin/target → f64 Ray::new), for the f64 config. */
+int bvhgpu_gen_rays_f64(bvhgpu_ctx *ctx, uint64_t first, size_t n, const float bounds[6], bvhgpu_ray_f64 *out_dev);
+
+/* ---- traverse: replaces <FlatBvh as BoundingHierarchy>::traverse (flat_bvh.rs:396-431) and, by the
+ * equivalence of bvh_node.rs:288-319, Bvh::traverse (bvh_impl.rs:104-119), for a BATCH of rays.
+ * Result = CSR: offsets[n_rays+1], indices[total]; ray i's shapes are indices[offsets[i]..offsets[i+1])
+ * in the reference's order (flat-array / DFS left-first order).
+ * *hits may point to NULL (a result object is allocated) or to a previous result (buffers reused). ---- */
+int bvhgpu_traverse_f32(bvhgpu_tree *tree, const bvhgpu_ray_f32 *rays, size_t n_rays, int mem, unsigned flags,
+                        bvhgpu_hits **hits);
+int bvhgpu_traverse_f64(bvhgpu_tree *tree, const bvhgpu_ray_f64 *rays, size_t n_rays, int mem, unsigned flags,
+                        bvhgpu_hits **hits);
+int bvhgpu_hits_info(const bvhgpu_hits *hits, size_t *n_rays, uint64_t *total, bvhgpu_traverse_stats *stats);
+/* copy out; indices / tslice may be NULL.  tslice: 2 scalars of the tree's dtype per hit (flag T_SLICE). */
+int bvhgpu_hits_fetch(bvhgpu_hits *hits, uint32_t *offsets, uint32_t *indices, void *tslice, int mem);
+/* borrow the device arrays (valid until the next traverse into / destroy of this result). */
+int bvhgpu_hits_device(const bvhgpu_hits *hits, const uint32_t **offsets, const uint32_t **indices, const void **tslice);
+void bvhgpu_hits_destroy(bvhgpu_hits *hits);
+
+/* ---- timing hook used by bench.py: HIP-event time (ms) of the kernels of the last call of each
+ * phase on this ctx's stream (build / flatten / traverse main kernel / traverse total). ---- */
+typedef struct { float build_ms, flatten_ms, traverse_kernel_ms, traverse_total_ms; } bvhgpu_timings;
+int bvhgpu_enable_timing(bvhgpu_ctx *ctx, int on);
+int bvhgpu_last_timings(bvhgpu_ctx *ctx, bvhgpu_timings *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BVH_MI355X_H */

@@ -1,0 +1,213 @@
+"""CPU-only checks (no compute calls): the C-ABI library loads and exports every symbol
+include/bvh_mi355x.h declares, POD layouts match the header, errors are reported (never a silent CPU
+fallback), the input generators equal the oracle's, and the N>1 path works over gloo (world_size 2).
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "bvh_mi355x.h")
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()  # hipcc cross-compiles gfx950 without a GPU
+    from bvh_amd import _lib
+    return _lib
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(bvhgpu_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = built.load()
+    declared = _declared_functions()
+    assert len(declared) >= 30
+    bound = {name for name, _, _ in built.SYMBOLS}
+    assert set(declared) == bound, set(declared) ^ bound
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported by libbvh_mi355x.so"
+    nm = subprocess.run(["nm", "-D", "--defined-only", built.SO_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (bvhgpu_[a-z0-9_]+)", nm))
+    assert set(declared) <= exported
+    assert lib.bvhgpu_abi_version() == 1
+
+
+def test_library_contains_gfx950_code_object(built):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o",
+                          f"--input={built.SO_PATH}"], capture_output=True, text=True)
+    blob = open(built.SO_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for kern in (b"k_traverse", b"k_small", b"k_bin", b"k_select", b"k_scatter", b"k_flatten", b"k_gen_rays"):
+        assert kern in blob, kern
+
+
+def test_pod_layouts_match_header(built):
+    assert built.NODE_F32.itemsize == 64 and built.NODE_F64.itemsize == 112
+    assert built.FLAT_F32.itemsize == 36 and built.FLAT_F64.itemsize == 64
+    assert built.RAY_F32.itemsize == 36 and built.RAY_F64.itemsize == 72
+    # the same layouts compile to the same sizes with a C compiler
+    prog = r'''
+#include <stdio.h>
+#include "bvh_mi355x.h"
+int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(bvhgpu_node_f32), sizeof(bvhgpu_node_f64),
+ sizeof(bvhgpu_flat_f32), sizeof(bvhgpu_flat_f64), sizeof(bvhgpu_ray_f32), sizeof(bvhgpu_ray_f64),
+ sizeof(bvhgpu_traverse_stats), sizeof(bvhgpu_timings)); return 0;}
+'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(prog)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = subprocess.check_output([exe], text=True).split()
+    assert sizes == ["64", "112", "36", "64", "36", "72", "32", "16"]
+    assert C.sizeof(built.TraverseStats) == 32 and C.sizeof(built.Timings) == 16
+    # oracle layouts are the same PODs (tests byte-compare across the two)
+    from oracle import orc
+    assert orc.NODE_F32 == built.NODE_F32 and orc.FLAT_F32 == built.FLAT_F32 and orc.RAY_F32 == built.RAY_F32
+    assert orc.NODE_F64 == built.NODE_F64 and orc.FLAT_F64 == built.FLAT_F64 and orc.RAY_F64 == built.RAY_F64
+
+
+def test_no_device_is_an_error_not_a_fallback(built, gpu_available):
+    if gpu_available:
+        pytest.skip("a GPU is visible here")
+    import bvh_amd
+    assert bvh_amd.device_count() == 0
+    h = C.c_void_p()
+    rc = built.load().bvhgpu_create(0, None, C.byref(h))
+    assert rc == built.NO_DEVICE and not h.value
+    assert b"device" in built.load().bvhgpu_status_string(rc)
+    with pytest.raises(bvh_amd.BvhGpuError):
+        bvh_amd.Context(0)
+    with pytest.raises(bvh_amd.BvhGpuError):
+        bvh_amd.Bvh.from_aabbs(np.zeros((4, 6), np.float32))
+    # NULL handles are rejected, not dereferenced
+    assert built.load().bvhgpu_flatten(None) == built.INVALID_ARG
+    assert built.load().bvhgpu_tree_info(None, None, None, None, None) == built.INVALID_ARG
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    code = ("import sys; sys.path.insert(0, %r); import bvh_amd._lib as L; L.SO_PATH = %r; L._lib = None\n"
+            "try:\n    L.load()\nexcept ImportError as e:\n    print('IMPORTERROR', 'no CPU fallback' in str(e).lower() or 'fallback' in str(e))\n"
+            % (ROOT, str(tmp_path / "nope.so")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, BVH_AMD_NO_TORCH="1"))
+    assert "IMPORTERROR True" in out.stdout, out.stdout + out.stderr
+
+
+def test_product_never_imports_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "bvh_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                for pat in (r"^\s*(from|import)\s+oracle", r"liboracle", r"\borc_[a-z]", r"#include[^\n]*oracle", r"\borc\."):
+                    assert not re.search(pat, text, flags=re.M), (os.path.join(dirpath, f), pat)
+    assert not re.search(r"liboracle|orc_", open(HEADER).read())
+    # and the engine does not link it
+    ldd = subprocess.run(["ldd", os.path.join(pkg, "libbvh_mi355x.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in ldd
+
+
+def test_generators_equal_oracle():
+    from bvh_amd import testbase as tb
+    from oracle import orc
+    t, a = tb.create_n_cubes(1000)
+    t2, a2 = orc.create_n_cubes(1000)
+    assert t.tobytes() == t2.tobytes() and a.tobytes() == a2.tobytes()
+    assert tb.generate_aligned_boxes_aabbs().tobytes() == orc.aligned_boxes().tobytes()
+    boxes = tb.generate_aligned_boxes()
+    assert [b.id for b in boxes] == list(range(-10, 11))
+    assert np.array_equal(np.stack([b.aabb().as6() for b in boxes]), orc.aligned_boxes())
+    tri = tb.Triangle(t[5, 0], t[5, 1], t[5, 2])
+    assert np.array_equal(tri.aabb().as6(), a[5])
+    # next_point3_at seeks: draw j of the seed-0 stream
+    pts = tb.next_point3_at(np.array([1, 2, 3, 2_000_001], dtype=np.uint64), tb.default_bounds())
+    r = orc.create_rays(0, 1)
+    assert np.array_equal(pts[0], r[0]["o"])
+    r2 = orc.create_rays(1_000_000, 1)
+    assert np.array_equal(pts[3], r2[0]["o"])
+
+
+def test_shard_ranges():
+    from bvh_amd import dist as bdist
+    R = 1000
+    spans = [bdist.shard_range(r, 8, R) for r in range(8)]
+    assert spans[0] == (0, R) and spans[7] == (7 * R, R)
+    assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(7))
+    with pytest.raises(ValueError):
+        bdist.shard_range(8, 8, R)
+
+
+_GLOO_WORKER = r'''
+import os, sys, pickle
+import numpy as np
+sys.path.insert(0, %(root)r)
+os.environ["BVH_AMD_NO_TORCH"] = "0"
+import torch
+import torch.distributed as dist
+from bvh_amd import dist as bdist, testbase as tb
+from oracle import orc
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=world)
+R = 1500
+_, aabbs = tb.create_n_cubes(60)
+# rank 0 owns the scene (stands in for build+flatten+scene_export); the peers get it by ONE broadcast
+if rank == 0:
+    flat = orc.flatten(orc.build(aabbs).nodes)
+    payload = np.frombuffer(flat.tobytes() + aabbs.tobytes(), dtype=np.uint8).copy()
+else:
+    payload = None
+n = bdist.broadcast_nbytes(len(payload) if rank == 0 else 0, "cpu", 0)
+blob = torch.from_numpy(payload) if rank == 0 else torch.empty(n, dtype=torch.uint8)
+bdist.broadcast_scene(blob, 0)
+raw = blob.numpy().tobytes()
+nflat = 3 * len(aabbs) - 2
+flat = np.frombuffer(raw[:nflat * 36], dtype=orc.FLAT_F32)
+sa = np.frombuffer(raw[nflat * 36:], dtype=np.float32).reshape(-1, 6)
+first, cnt = bdist.shard_range(rank, world, R)
+rays = orc.create_rays(first, cnt)
+off, idx, _, st = orc.traverse_flat(flat, sa, rays)
+pickle.dump((first, off, idx), open(%(out)r + str(rank), "wb"))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_sharding_matches_single_process(tmp_path):
+    """world_size 2 over gloo on CPU: one scene broadcast, rays sharded, per-rank hit lists concatenate
+    to exactly the single-process result (the oracle stands in for the GPU traversal here)."""
+    import pickle
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "res")
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER % dict(root=ROOT, port=port, out=out))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    for p in procs:
+        so, se = p.communicate(timeout=300)
+        assert p.returncode == 0, se.decode()[-2000:]
+    from bvh_amd import testbase as tb
+    from oracle import orc
+    _, aabbs = tb.create_n_cubes(60)
+    flat = orc.flatten(orc.build(aabbs).nodes)
+    off, idx, _, _ = orc.traverse_flat(flat, aabbs, orc.create_rays(0, 3000))
+    parts = [pickle.load(open(out + str(r), "rb")) for r in range(2)]
+    assert parts[0][0] == 0 and parts[1][0] == 1500
+    cat_idx = np.concatenate([parts[0][2], parts[1][2]])
+    cat_off = np.concatenate([parts[0][1][:-1], parts[1][1] + parts[0][1][-1]])
+    assert np.array_equal(cat_idx, idx) and np.array_equal(cat_off, off)
