@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256) void k_hits_scatter(const HitRec* __restrict__
                                                       const unsigned long long* __restrict__ ctr,
                                                       unsigned long long pool_cap, const uint32_t* __restrict__ offsets,
                                                       uint32_t* __restrict__ indices, T* __restrict__ tslice) {
-    unsigned long long n = ctr[0];
-    if (n > pool_cap) n = pool_cap;
+    const unsigned long long n = ctr[0];
+    if (n > pool_cap) return;  // pool overflowed: indices[] is too small as well; the host grows both and replays
     for (unsigned long long j = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; j < n;
          j += (unsigned long long)gridDim.x * blockDim.x) {
         const HitRec h = pool[j];
