@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libbvh_mi355x.so")
+SO_PATH = os.environ.get("BVH_AMD_SO") or os.path.join(HERE, "libbvh_mi355x.so")  # BVH_AMD_SO: developer profiling builds only
 
 OK, INVALID_ARG, HIP_ERROR, OOM, OVERFLOW, NO_DEVICE, DTYPE_MISMATCH, NOT_FLATTENED = range(8)
 F32, F64 = 0, 1

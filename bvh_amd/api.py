@@ -12,7 +12,9 @@ Everything that computes runs on the GPU through libbvh_mi355x.so; this file onl
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import weakref
 from typing import Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -35,6 +37,28 @@ def _ray_dtype(s):
     return RAY_F32 if s == "f32" else RAY_F64
 
 
+# Native handles must be released while the HIP runtime is still alive: at interpreter shutdown the
+# runtime's own static destructors may already have run when Python finalises leftover objects.
+_live = weakref.WeakSet()
+_closing = False
+
+
+def _shutdown():
+    global _closing
+    for kind in ("_Hits", "tree", "Context"):
+        for obj in list(_live):
+            k = type(obj).__name__
+            if (kind == "tree" and k not in ("_Hits", "Context")) or k == kind:
+                try:
+                    obj.close()
+                except Exception:
+                    pass
+    _closing = True
+
+
+atexit.register(_shutdown)
+
+
 def _is_device_tensor(x) -> bool:
     return hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and bool(x.is_cuda)
 
@@ -52,6 +76,7 @@ class Context:
         check(lib.bvhgpu_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
         self._h = h
         self.device = int(device)
+        _live.add(self)
 
     def synchronize(self):
         check(_lib.load().bvhgpu_synchronize(self._h), self._h)
@@ -66,9 +91,9 @@ class Context:
                     traverse_total_ms=t.traverse_total_ms)
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not _closing:
             _lib.load().bvhgpu_destroy(self._h)
-            self._h = None
+        self._h = None
 
     def __del__(self):
         try:
@@ -218,12 +243,16 @@ class _Hits:
     def __init__(self, ctx: Context):
         self.ctx = ctx
         self.h = C.c_void_p()
+        _live.add(self)
+
+    def close(self):
+        if getattr(self, "h", None) and not _closing:
+            _lib.load().bvhgpu_hits_destroy(self.h)
+        self.h = None
 
     def __del__(self):
         try:
-            if self.h:
-                _lib.load().bvhgpu_hits_destroy(self.h)
-                self.h = None
+            self.close()
         except Exception:
             pass
 
@@ -234,13 +263,19 @@ class _TreeBase:
         self._t = handle
         self.sfx = sfx
         self._hits = _Hits(ctx)
+        _live.add(self)
+
+    def close(self):
+        if getattr(self, "_t", None):
+            if getattr(self, "_hits", None) is not None:
+                self._hits.close()
+            if not _closing:
+                _lib.load().bvhgpu_tree_destroy(self._t)
+        self._t = None
 
     def __del__(self):
         try:
-            if getattr(self, "_t", None):
-                self._hits = None
-                _lib.load().bvhgpu_tree_destroy(self._t)
-                self._t = None
+            self.close()
         except Exception:
             pass
 
@@ -464,5 +499,8 @@ class Bvh(_TreeBase):
 class _FlatView(FlatBvh):
     """FlatBvh that borrows a Bvh's device object (so flatten() does not copy the tree)."""
 
-    def __del__(self):  # the owning Bvh destroys the handle
+    def close(self):  # the owning Bvh destroys the handle
+        self._t = None
+
+    def __del__(self):
         self._t = None

@@ -16,8 +16,11 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libbvh_mi355x.so")
 SOURCES = ["capi.hip", "build.hip", "flatten.hip", "traverse.hip"]
 HEADERS = ["common.hpp", "engine.hpp", os.path.join("..", "..", "include", "bvh_mi355x.h")]
+# -fno-slp-vectorize: ROCm 7.2's SLP vectoriser + gfx950 instruction selection crash (SIGSEGV in
+# constrainRegClass) on the integer-key min/max folds of sah_select(); packed v_pk_* VALU ops are no
+# gain for this code anyway (MI355X_MICROARCH.md, "packed f32 VALU ... an anti-lever").
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc() -> str:

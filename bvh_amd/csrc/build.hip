@@ -26,7 +26,14 @@
 namespace bvhgpu {
 
 constexpr int MAXLV = 96;        // counter slots (levels beyond reuse the last two, host-synchronised)
-constexpr int CTR_SMALL = 0;     // u32: number of small items
+constexpr int CTR_SMALL = 0;     // u32: number of small items (<= 64 shapes, wave-subtree tier)
+constexpr int CTR_MID = 1;       // u32: number of mid items (65 .. MID_MAX shapes, workgroup tier)
+constexpr int MID_THREADS = 512;  // workgroup tier: one 8-wave workgroup per node (256 VGPRs per lane available)
+template <typename T> struct MidCfg {
+    static constexpr int MAXN = sizeof(T) == 4 ? 4096 : 2048;  // shapes one workgroup can hold (LDS: 24/48 B each)
+    static constexpr int PPT = MAXN / MID_THREADS;             // consecutive positions owned by a thread
+    static constexpr int MAXSUB = MAXN / 64;                   // > MAXN/65 simultaneously active sub-nodes
+};
 constexpr int CTR_LEVEL0 = 16;   // u32 pairs (n_items, n_tiles) per level slot
 constexpr size_t ROOTKEY_OFF = 1024;  // byte offset of the 12 root keys inside the ctr buffer
 
@@ -47,6 +54,7 @@ template <typename T> struct BuildArgs {
     uint32_t* idx[2];
     uint8_t* bk;
     Item<T>* big[2];
+    Item<T>* mid;
     Item<T>* small;
     ItemStats<T>* stats[2];
     uint32_t* tile_item[2];
@@ -88,9 +96,17 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T>
         }
     }
 #pragma unroll
-    for (int j = 0; j < STAT_KEYS; j++) {
-        if (key_is_min(j)) atomicMin(&sk[j], loc[j]);
-        else atomicMax(&sk[j], loc[j]);
+    for (int j = 0; j < STAT_KEYS; j++) {  // wave butterfly first: one LDS atomic per wave, not per lane
+        Key v = loc[j];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            Key u = __shfl_xor(v, d);
+            v = key_is_min(j) ? (u < v ? u : v) : (u > v ? u : v);
+        }
+        if (lane_id() == 0) {
+            if (key_is_min(j)) atomicMin(&sk[j], v);
+            else atomicMax(&sk[j], v);
+        }
     }
     __syncthreads();
     if (threadIdx.x < STAT_KEYS) {
@@ -115,9 +131,11 @@ __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, ui
     const int npar = next_level & 1;
     uint32_t slot = 0, tb = 0;
     const bool is_small = count <= (uint32_t)SMALL_MAX;
+    const bool is_mid = !is_small && count <= (uint32_t)MidCfg<T>::MAXN;
     const uint32_t ntile = (count + TILE - 1) / TILE;
     if (lane == 0) {
         if (is_small) slot = atomicAdd(&a.ctr[CTR_SMALL], 1u);
+        else if (is_mid) slot = atomicAdd(&a.ctr[CTR_MID], 1u);
         else {
             slot = atomicAdd(&a.ctr[CTR_LEVEL0 + 2 * nslot], 1u);
             tb = atomicAdd(&a.ctr[CTR_LEVEL0 + 2 * nslot + 1], ntile);
@@ -125,13 +143,13 @@ __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, ui
     }
     slot = __shfl(slot, 0);
     tb = __shfl(tb, 0);
-    Item<T>* it = is_small ? &a.small[slot] : &a.big[npar][slot];
+    Item<T>* it = is_small ? &a.small[slot] : (is_mid ? &a.mid[slot] : &a.big[npar][slot]);
     if (lane == 0) {
         it->ni = ni; it->parent = parent; it->start = start; it->count = count;
         it->tile_base = tb; it->parity = (uint32_t)npar; it->_r0 = 0; it->_r1 = 0;
     }
     if (lane < 6) { it->A[lane] = A[lane]; it->C[lane] = C[lane]; }
-    if (!is_small) {
+    if (!is_small && !is_mid) {
         for (uint32_t j = lane; j < ntile; j += WAVE) a.tile_item[npar][tb + j] = slot;
         init_stats<T>(&a.stats[npar][slot], lane);
     }
@@ -160,14 +178,17 @@ template <typename T> __global__ __launch_bounds__(64) void k_root(BuildArgs<T> 
 // ------------------------------------------------------------------------------------------------
 // tier 1 / bin
 // ------------------------------------------------------------------------------------------------
+constexpr int BIN_REP = 16;  // LDS replicas of the tile statistics: lanes l and l+16.. share one, so a wave's
+                             // same-address atomic conflicts drop from ~64/6 to ~4/6 per instruction
 template <typename T> __global__ __launch_bounds__(256) void k_bin(BuildArgs<T> a, int level) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
     const int slot = lvl_slot(level), par = level & 1;
     const uint32_t ntiles = a.ctr[CTR_LEVEL0 + 2 * slot + 1];
-    __shared__ Key sk[NUM_BUCKETS * STAT_KEYS];
-    __shared__ uint32_t sc[NUM_BUCKETS];
+    __shared__ Key sk[BIN_REP][NUM_BUCKETS * STAT_KEYS];
+    __shared__ uint32_t sc[BIN_REP][NUM_BUCKETS];
     const uint32_t* idx = a.idx[par];
+    const int rep = threadIdx.x & (BIN_REP - 1);
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const uint32_t item_id = a.tile_item[par][t];
         const Item<T>* it = &a.big[par][item_id];
@@ -182,9 +203,9 @@ template <typename T> __global__ __launch_bounds__(256) void k_bin(BuildArgs<T> 
         const T ext = C[3 + ax] - C[ax];                // :108
         const bool degen = ext < Tr::eps();             // :114
         const uint32_t half = count / 2;                // :117
-        for (int j = threadIdx.x; j < NUM_BUCKETS * STAT_KEYS; j += 256)
-            sk[j] = key_is_min(j % STAT_KEYS) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
-        if (threadIdx.x < NUM_BUCKETS) sc[threadIdx.x] = 0;
+        for (int j = threadIdx.x; j < BIN_REP * NUM_BUCKETS * STAT_KEYS; j += 256)
+            (&sk[0][0])[j] = key_is_min(j % STAT_KEYS) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
+        if (threadIdx.x < BIN_REP * NUM_BUCKETS) (&sc[0][0])[threadIdx.x] = 0;
         __syncthreads();
         for (uint32_t p = p0 + threadIdx.x; p < pend; p += 256) {
             const uint32_t s = idx[p];
@@ -199,7 +220,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_bin(BuildArgs<T> 
             if (degen) bkt = (p - start) < half ? 0 : 1;   // halves in CURRENT order (:117)
             else bkt = bucket_of(c[ax], cmin, ext);        // :210-217
             a.bk[p] = (uint8_t)bkt;
-            Key* kk = sk + bkt * STAT_KEYS;                // Bucket::add_aabb (utils.rs:81-85)
+            Key* kk = &sk[rep][bkt * STAT_KEYS];           // Bucket::add_aabb (utils.rs:81-85)
 #pragma unroll
             for (int k = 0; k < 3; k++) {
                 atomicMin(&kk[k], Tr::key(bx[k]));
@@ -208,19 +229,28 @@ template <typename T> __global__ __launch_bounds__(256) void k_bin(BuildArgs<T> 
                 atomicMin(&kk[6 + k], kc);
                 atomicMax(&kk[9 + k], kc);
             }
-            atomicAdd(&sc[bkt], 1u);
+            atomicAdd(&sc[rep][bkt], 1u);
         }
         __syncthreads();
         ItemStats<T>* gs = &a.stats[par][item_id];
         if (threadIdx.x < NUM_BUCKETS) {
-            a.tile_cnt[t * NUM_BUCKETS + threadIdx.x] = sc[threadIdx.x];
-            if (sc[threadIdx.x]) atomicAdd(&gs->cnt[threadIdx.x], sc[threadIdx.x]);
+            uint32_t c = 0;
+#pragma unroll
+            for (int r = 0; r < BIN_REP; r++) c += sc[r][threadIdx.x];
+            sc[0][threadIdx.x] = c;   // only this thread reads/writes column threadIdx.x here
+            a.tile_cnt[t * NUM_BUCKETS + threadIdx.x] = c;
+            if (c) atomicAdd(&gs->cnt[threadIdx.x], c);
         }
+        __syncthreads();
         if (threadIdx.x < NUM_BUCKETS * STAT_KEYS) {
             const int j = threadIdx.x;
-            if (sc[j / STAT_KEYS]) {
-                if (key_is_min(j % STAT_KEYS)) atomicMin(&gs->k[j], sk[j]);
-                else atomicMax(&gs->k[j], sk[j]);
+            if (sc[0][j / STAT_KEYS]) {
+                Key v = sk[0][j];
+                const bool mn = key_is_min(j % STAT_KEYS);
+#pragma unroll
+                for (int r = 1; r < BIN_REP; r++) { const Key u = sk[r][j]; v = mn ? (u < v ? u : v) : (u > v ? u : v); }
+                if (mn) atomicMin(&gs->k[j], v);
+                else atomicMax(&gs->k[j], v);
             }
         }
         __syncthreads();
@@ -242,6 +272,99 @@ template <typename T> __device__ __forceinline__ void box_join(T* a, const T* b)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// SAH split selection from the 6 bucket statistics (bvh_node.rs:224-247).  keys: 6 x 12 integer keys
+// (aabb min3 max3, centroid min3 max3), cnts: 6 counts.  In the degenerate branch (:114-124) "bucket"
+// 0 / 1 are the two halves of the index list and the split is forced between them, which reproduces
+// joint_aabb_of_shapes of each half (:118-119).  Returns n_left; fills child bounds and cnt[].
+// ------------------------------------------------------------------------------------------------
+template <typename T, typename KeyPtr, typename CntPtr>
+__device__ __forceinline__ uint32_t sah_select(KeyPtr keys, CntPtr cnts, const T* A, bool degen, uint32_t* cnt, T* AL,
+                                               T* CL, T* AR, T* CR) {
+    using Tr = Traits<T>;
+    using Key = typename Tr::Key;
+    // Joins are exact, so fold(empty, join) over buckets 0..s / s+1..5 (utils.rs:88-94) equals running
+    // prefix / suffix joins; they are done on the monotone integer keys (one v_min/v_max_u32 each, and
+    // the -0 < +0 order of the float joins for free) and decoded only where a float is needed.
+    Key pa[NUM_BUCKETS][6], sa[NUM_BUCKETS][6];   // aabb prefix (buckets 0..b) / suffix (b..5) joins
+#pragma unroll
+    for (int b = 0; b < NUM_BUCKETS; b++) {
+        cnt[b] = cnts[b];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { pa[b][k] = keys[b * STAT_KEYS + k]; sa[b][k] = pa[b][k]; }
+    }
+#pragma unroll
+    for (int b = 1; b < NUM_BUCKETS; b++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            pa[b][k] = pa[b][k] < pa[b - 1][k] ? pa[b][k] : pa[b - 1][k];
+            pa[b][3 + k] = pa[b][3 + k] > pa[b - 1][3 + k] ? pa[b][3 + k] : pa[b - 1][3 + k];
+        }
+    }
+#pragma unroll
+    for (int b = NUM_BUCKETS - 2; b >= 0; b--) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            sa[b][k] = sa[b][k] < sa[b + 1][k] ? sa[b][k] : sa[b + 1][k];
+            sa[b][3 + k] = sa[b][3 + k] > sa[b + 1][3 + k] ? sa[b][3 + k] : sa[b + 1][3 + k];
+        }
+    }
+    T min_cost = Tr::inf();
+    int best = -1;   // no winner (NaN/inf costs): the reference keeps min_bucket = 0 and EMPTY child bounds (:225-230)
+    const T sa_parent = surface_area(A);
+    uint32_t ln = 0, total = 0;
+#pragma unroll
+    for (int b = 0; b < NUM_BUCKETS; b++) total += cnt[b];
+#pragma unroll
+    for (int s = 0; s < NUM_BUCKETS - 1; s++) {
+        ln += cnt[s];
+        T la[6], ra[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { la[k] = Tr::unkey(pa[s][k]); ra[k] = Tr::unkey(sa[s + 1][k]); }
+        T cl = (T)ln * surface_area(la);
+        T cr = (T)(total - ln) * surface_area(ra);
+        T num = cl + cr;
+        T cost = num / sa_parent;                               // :236-238
+        bool take = degen ? (s == 0) : (cost < min_cost);       // strict <, first wins (:239)
+        if (take) { min_cost = cost; best = s; }
+    }
+    if (best < 0) {
+        box_empty(AL); box_empty(CL); box_empty(AR); box_empty(CR);
+        return cnt[0];
+    }
+    // child bounds of the winning split: aabb from the running joins, centroid bounds joined now
+    Key cl_[6], cr_[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        cl_[k] = key_is_min(k) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
+        cr_[k] = cl_[k];
+    }
+    uint32_t nl = 0;
+#pragma unroll
+    for (int b = 0; b < NUM_BUCKETS; b++) {
+        const bool left = b <= best;
+        if (left) nl += cnt[b];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const Key v = keys[b * STAT_KEYS + 6 + k];
+            const Key jl = key_is_min(k) ? (v < cl_[k] ? v : cl_[k]) : (v > cl_[k] ? v : cl_[k]);
+            const Key jr = key_is_min(k) ? (v < cr_[k] ? v : cr_[k]) : (v > cr_[k] ? v : cr_[k]);
+            cl_[k] = left ? jl : cl_[k];
+            cr_[k] = left ? cr_[k] : jr;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        // pa/sa are indexed by a run-time `best`: select with a compare chain, not a dynamic register index
+        Key l = pa[0][k], r = sa[1][k];
+#pragma unroll
+        for (int s = 1; s < NUM_BUCKETS - 1; s++) { if (best == s) { l = pa[s][k]; r = sa[s + 1][k]; } }
+        AL[k] = Tr::unkey(l); AR[k] = Tr::unkey(r);
+        CL[k] = Tr::unkey(cl_[k]); CR[k] = Tr::unkey(cr_[k]);
+    }
+    return nl;
+}
+
 template <typename T> __global__ __launch_bounds__(256) void k_select(BuildArgs<T> a, int level) {
     using Tr = Traits<T>;
     const int slot = lvl_slot(level), par = level & 1;
@@ -261,48 +384,8 @@ template <typename T> __global__ __launch_bounds__(256) void k_select(BuildArgs<
         const bool degen = ext < Tr::eps();
 
         uint32_t cnt[NUM_BUCKETS];
-        T ba[NUM_BUCKETS][6], bc[NUM_BUCKETS][6];
-#pragma unroll
-        for (int b = 0; b < NUM_BUCKETS; b++) {
-            cnt[b] = st->cnt[b];
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                ba[b][k] = Tr::unkey(st->k[b * STAT_KEYS + k]);
-                bc[b][k] = Tr::unkey(st->k[b * STAT_KEYS + 6 + k]);
-            }
-        }
-        // candidate splits (bvh_node.rs:224-247); in the degenerate branch (:114-124) "bucket" 0/1 are
-        // the two halves and the split is forced between them (joint_aabb_of_shapes of each half)
-        int best = 0;
-        T min_cost = Tr::inf();
         T AL[6], CL[6], AR[6], CR[6];
-        box_empty(AL); box_empty(CL); box_empty(AR); box_empty(CR);
-        // if no candidate ever wins (NaN/inf costs) the reference keeps min_bucket = 0 and EMPTY child
-        // bounds (bvh_node.rs:225-230,250): replicate
-        uint32_t nl = cnt[0];
-        const T sa_parent = surface_area(A);
-#pragma unroll
-        for (int s = 0; s < NUM_BUCKETS - 1; s++) {
-            uint32_t ln = 0, rn = 0;
-            T la[6], lc[6], ra[6], rc[6];
-            box_empty(la); box_empty(lc); box_empty(ra); box_empty(rc);
-#pragma unroll
-            for (int b = 0; b < NUM_BUCKETS; b++) {
-                if (b <= s) { ln += cnt[b]; box_join(la, ba[b]); box_join(lc, bc[b]); }
-                else { rn += cnt[b]; box_join(ra, ba[b]); box_join(rc, bc[b]); }
-            }
-            T cl = (T)ln * surface_area(la);
-            T cr = (T)rn * surface_area(ra);
-            T num = cl + cr;
-            T cost = num / sa_parent;
-            bool take = degen ? (s == 0) : (cost < min_cost);
-            if (take) {
-                best = s; min_cost = cost; nl = ln;
-#pragma unroll
-                for (int k = 0; k < 6; k++) { AL[k] = la[k]; CL[k] = lc[k]; AR[k] = ra[k]; CR[k] = rc[k]; }
-            }
-        }
-        (void)best;
+        const uint32_t nl = sah_select<T>(st->k, st->cnt, A, degen, cnt, AL, CL, AR, CR);
         const uint32_t li = ni + 1;                 // :140
         const uint32_t ri = li + (2 * nl - 1);      // :138,142
         if (lane == 0) {
@@ -391,6 +474,369 @@ template <typename T> __global__ __launch_bounds__(256) void k_scatter(BuildArgs
 }
 
 // ------------------------------------------------------------------------------------------------
+// mid tier — one workgroup finishes a whole node of 65 .. MidCfg<T>::MAXN shapes down to <= 64-shape
+// sub-nodes, level by level, entirely in LDS: the node's index slice AND its shapes' AABBs are
+// loaded once and then only permuted in LDS.  Same-address LDS atomics were the bottleneck of a
+// first version (13 per shape per level), so statistics are taken AFTER the stable sort, where every
+// (sub-node, bucket) is one contiguous run:
+//   1 bucket   : every thread owns PPT consecutive positions: bucket id per shape (bvh_node.rs:204-217)
+//   2 sort     : block-wide exclusive scan of packed one-hot bucket counters → stable bucket-major rank
+//                inside the sub-node (:250-272); shapes (index + AABB) move through registers
+//   3 stats    : thread-serial join over its positions, then a wave-level SEGMENTED scan (head flags)
+//                over the 64 per-thread partials; only run tails touch the LDS statistics (key atomics,
+//                practically conflict-free)
+//   4 select   : lane s of wave 0 runs the SAH selection of sub-node s (:224-247), writes its BvhNode,
+//                creates next-level sub-nodes; <= 64-shape children go to the global wave-tier queue
+//                with ONE aggregated atomic per level
+// ------------------------------------------------------------------------------------------------
+
+template <typename T> struct MidSub {
+    uint32_t start, count, ni, parent;  // start is relative to the item's first position
+    T A[6], C[6];
+    T cmin, ext;
+    uint32_t ax, degen, half, nl;
+    uint32_t base[NUM_BUCKETS + 1];     // exclusive bucket offsets inside the sub-node; base[6] = count
+    uint32_t child[2];                  // next-level sub-node ids, NONE if the child left the workgroup
+    unsigned long long scan0_lo, scanE_lo;  // packed counters before the first / after the last position
+    uint32_t scan0_hi, scanE_hi;
+};
+
+template <typename T> __device__ __forceinline__ void midsub_derive(MidSub<T>* m) {
+    const int ax = largest_axis(m->C);                     // bvh_node.rs:107
+    m->ax = (uint32_t)ax;
+    m->cmin = m->C[ax];
+    m->ext = m->C[3 + ax] - m->C[ax];                      // :108
+    m->degen = (m->ext < Traits<T>::eps()) ? 1u : 0u;      // :114
+    m->half = m->count / 2;                                // :117
+}
+
+struct Packed { unsigned long long lo; uint32_t hi; };  // six 16-bit counters: buckets 0..3 | 4..5
+__device__ __forceinline__ Packed packed_onehot(int b) {
+    Packed p;
+    p.lo = b < 4 ? (1ull << (16 * b)) : 0ull;
+    p.hi = (b >= 4 && b < 6) ? (1u << (16 * (b - 4))) : 0u;
+    return p;
+}
+__device__ __forceinline__ uint32_t packed_field(unsigned long long lo, uint32_t hi, int b) {
+    return b < 4 ? (uint32_t)((lo >> (16 * b)) & 0xFFFFull) : ((hi >> (16 * (b - 4))) & 0xFFFFu);
+}
+
+#ifdef BVH_PROFILE_MID
+__device__ unsigned long long g_mid_prof[8];
+#define MID_T0() long long _t0 = clock64()
+#define MID_T(i) do { long long _t1 = clock64(); if (tid == 0 && blockIdx.x == 0) { atomicAdd(&g_mid_prof[i], (unsigned long long)(_t1 - _t0)); if (i == 5) atomicAdd(&g_mid_prof[0], 1ull); } _t0 = _t1; } while (0)
+#else
+#define MID_T0()
+#define MID_T(i)
+#endif
+
+template <typename T> __global__ __launch_bounds__(MID_THREADS) void k_mid(BuildArgs<T> a, uint32_t first) {
+    using Tr = Traits<T>;
+    using Key = typename Tr::Key;
+    constexpr int MAXN = MidCfg<T>::MAXN, PPT = MidCfg<T>::PPT, MAXSUB = MidCfg<T>::MAXSUB;
+    constexpr uint8_t SEG_NONE = 0xFFu;
+    __shared__ __attribute__((aligned(16))) T s_box[MAXN * 6];
+    __shared__ uint32_t s_idx[MAXN];
+    __shared__ uint8_t s_seg[MAXN];
+    __shared__ MidSub<T> s_sub[2][MAXSUB];
+    __shared__ Key s_keys[MAXSUB * NUM_BUCKETS * STAT_KEYS];
+    __shared__ unsigned long long s_wlo[MID_THREADS / WAVE];
+    __shared__ uint32_t s_whi[MID_THREADS / WAVE];
+    __shared__ uint32_t s_nsub;
+
+    const uint32_t n_mid = a.ctr[CTR_MID];
+    const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const unsigned long long lt = lanemask_lt();
+
+    for (uint32_t item_id = first + blockIdx.x; item_id < n_mid; item_id += gridDim.x) {
+        const Item<T>* it = &a.mid[item_id];
+        const uint32_t istart = it->start, count = it->count;
+        const uint32_t* gsrc = a.idx[it->parity];
+        uint32_t* gdst = a.idx[it->parity ^ 1];   // where the <= 64-shape children's slices are left
+        const uint32_t out_parity = it->parity ^ 1;
+        __syncthreads();  // previous item fully done with LDS
+        for (uint32_t p = tid; p < (uint32_t)MAXN; p += MID_THREADS) {
+            if (p < count) {
+                const uint32_t shp = gsrc[istart + p];
+                const T* b = a.aabbs + 6 * (size_t)shp;
+                s_idx[p] = shp;
+                s_seg[p] = 0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) s_box[6 * p + k] = b[k];
+            } else {
+                s_seg[p] = SEG_NONE;
+            }
+        }
+        if (tid == 0) {
+            MidSub<T>* m = &s_sub[0][0];
+            m->start = 0; m->count = count; m->ni = it->ni; m->parent = it->parent;
+            for (int k = 0; k < 6; k++) { m->A[k] = it->A[k]; m->C[k] = it->C[k]; }
+            midsub_derive(m);
+            s_nsub = 1;
+        }
+        int cur = 0;
+        __syncthreads();
+        uint32_t nsub = 1;
+        while (nsub) {
+            MID_T0();
+            // ---- reset statistics (consumed in phase 3, two barriers away)
+            for (uint32_t j = tid; j < nsub * NUM_BUCKETS * STAT_KEYS; j += MID_THREADS)
+                s_keys[j] = key_is_min(j % STAT_KEYS) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
+            // ---- phase 1: bucket id of every owned position (bvh_node.rs:204-217)
+            T bx[PPT][6];
+            uint32_t sid[PPT];
+            int sg[PPT], bk[PPT];
+#pragma unroll
+            for (int j = 0; j < PPT; j++) {
+                const uint32_t p = tid * PPT + j;
+                sg[j] = (int)s_seg[p];
+                bk[j] = 7;
+                sid[j] = 0;
+                if (sg[j] != SEG_NONE) {
+                    const MidSub<T>* m = &s_sub[cur][sg[j]];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) bx[j][k] = s_box[6 * p + k];
+                    sid[j] = s_idx[p];
+                    const uint32_t ax = m->ax;
+                    const T mn = ax == 0 ? bx[j][0] : (ax == 1 ? bx[j][1] : bx[j][2]);
+                    const T mx = ax == 0 ? bx[j][3] : (ax == 1 ? bx[j][4] : bx[j][5]);
+                    if (m->degen) bk[j] = (p - m->start) < m->half ? 0 : 1;          // :117
+                    else bk[j] = bucket_of(center1(mn, mx), m->cmin, m->ext);        // :210-217
+                }
+            }
+            // ---- phase 2: stable bucket-major sort inside every sub-node (:250-272)
+            Packed mine; mine.lo = 0; mine.hi = 0;
+#pragma unroll
+            for (int j = 0; j < PPT; j++) { Packed o = packed_onehot(bk[j]); mine.lo += o.lo; mine.hi += o.hi; }
+            unsigned long long ilo = mine.lo; uint32_t ihi = mine.hi;   // inclusive wave scan
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                unsigned long long ul = __shfl_up(ilo, d);
+                uint32_t uh = __shfl_up(ihi, d);
+                if (lane >= d) { ilo += ul; ihi += uh; }
+            }
+            if (lane == WAVE - 1) { s_wlo[wv] = ilo; s_whi[wv] = ihi; }
+            __syncthreads();
+            MID_T(1);
+            unsigned long long rlo = ilo - mine.lo; uint32_t rhi = ihi - mine.hi;
+            for (int w2 = 0; w2 < wv; w2++) { rlo += s_wlo[w2]; rhi += s_whi[w2]; }
+            unsigned long long plo[PPT]; uint32_t phi[PPT];
+#pragma unroll
+            for (int j = 0; j < PPT; j++) {
+                const uint32_t p = tid * PPT + j;
+                plo[j] = rlo; phi[j] = rhi;
+                if (sg[j] != SEG_NONE) {
+                    MidSub<T>* m = &s_sub[cur][sg[j]];
+                    if (p == m->start) { m->scan0_lo = rlo; m->scan0_hi = rhi; }
+                    Packed o = packed_onehot(bk[j]); rlo += o.lo; rhi += o.hi;
+                    if (p == m->start + m->count - 1) { m->scanE_lo = rlo; m->scanE_hi = rhi; }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < PPT; j++) {
+                if (sg[j] == SEG_NONE) continue;
+                const uint32_t p = tid * PPT + j;
+                MidSub<T>* m = &s_sub[cur][sg[j]];
+                const unsigned long long l0 = m->scan0_lo, lE = m->scanE_lo;
+                const uint32_t h0 = m->scan0_hi, hE = m->scanE_hi;
+                uint32_t acc = 0, mybase = 0;
+                uint32_t basev[NUM_BUCKETS + 1];
+#pragma unroll
+                for (int b = 0; b < NUM_BUCKETS; b++) {
+                    basev[b] = acc;
+                    if (b == bk[j]) mybase = acc;
+                    acc += packed_field(lE, hE, b) - packed_field(l0, h0, b);
+                }
+                basev[NUM_BUCKETS] = acc;
+                if (p == m->start) {
+#pragma unroll
+                    for (int b = 0; b <= NUM_BUCKETS; b++) m->base[b] = basev[b];
+                }
+                const uint32_t rank = packed_field(plo[j], phi[j], bk[j]) - packed_field(l0, h0, bk[j]);
+                const uint32_t dest = m->start + mybase + rank;
+#pragma unroll
+                for (int k = 0; k < 6; k++) s_box[6 * dest + k] = bx[j][k];
+                s_idx[dest] = sid[j];
+            }
+            __syncthreads();
+            MID_T(2);
+            // ---- phase 3: per-(sub-node, bucket) statistics over the sorted order (utils.rs:81-85)
+            {
+                Key curv[STAT_KEYS], firstv[STAT_KEYS];
+                int cur_key = -1, first_key = -1;
+                bool have_first = false;
+#pragma unroll
+                for (int k = 0; k < STAT_KEYS; k++) { curv[k] = key_is_min(k) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF; firstv[k] = curv[k]; }
+#pragma unroll
+                for (int j = 0; j < PPT; j++) {
+                    if (sg[j] == SEG_NONE) continue;
+                    const uint32_t p = tid * PPT + j;
+                    const MidSub<T>* m = &s_sub[cur][sg[j]];
+                    const uint32_t rel = p - m->start;
+                    int b = 0;
+#pragma unroll
+                    for (int k = 1; k < NUM_BUCKETS; k++) b += (rel >= m->base[k]) ? 1 : 0;
+                    const int key = sg[j] * 8 + b;
+                    Key v[STAT_KEYS];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const T mn = s_box[6 * p + k], mx = s_box[6 * p + 3 + k];
+                        v[k] = Tr::key(mn); v[3 + k] = Tr::key(mx);
+                        v[6 + k] = Tr::key(center1(mn, mx)); v[9 + k] = v[6 + k];
+                    }
+                    if (key != cur_key) {
+                        if (cur_key >= 0) {
+                            if (!have_first) {
+                                have_first = true; first_key = cur_key;
+#pragma unroll
+                                for (int k = 0; k < STAT_KEYS; k++) firstv[k] = curv[k];
+                            } else {  // a run that starts and ends inside this thread
+                                Key* kk = s_keys + ((cur_key >> 3) * NUM_BUCKETS + (cur_key & 7)) * STAT_KEYS;
+#pragma unroll
+                                for (int k = 0; k < STAT_KEYS; k++) { if (key_is_min(k)) atomicMin(&kk[k], curv[k]); else atomicMax(&kk[k], curv[k]); }
+                            }
+                        }
+                        cur_key = key;
+#pragma unroll
+                        for (int k = 0; k < STAT_KEYS; k++) curv[k] = v[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < STAT_KEYS; k++) curv[k] = key_is_min(k) ? (v[k] < curv[k] ? v[k] : curv[k]) : (v[k] > curv[k] ? v[k] : curv[k]);
+                    }
+                }
+                // wave-level segmented inclusive scan over the threads' last runs
+                const int fk = have_first ? first_key : cur_key;
+                const int prev_last = __shfl_up(cur_key, 1);
+                const bool cont_prev = lane > 0 && fk >= 0 && fk == prev_last;
+                bool hf = have_first || !cont_prev;
+                Key sv[STAT_KEYS];
+#pragma unroll
+                for (int k = 0; k < STAT_KEYS; k++) sv[k] = curv[k];
+#pragma unroll
+                for (int d = 1; d < WAVE; d <<= 1) {
+                    const int tf = __shfl_up((int)hf, d);
+                    const bool take = lane >= d && !hf;
+#pragma unroll
+                    for (int k = 0; k < STAT_KEYS; k++) {
+                        const Key u = __shfl_up(sv[k], d);
+                        const Key j2 = key_is_min(k) ? (u < sv[k] ? u : sv[k]) : (u > sv[k] ? u : sv[k]);
+                        sv[k] = take ? j2 : sv[k];
+                    }
+                    hf = take ? (tf != 0) : hf;
+                }
+                // the first run of a multi-run thread ends here: join the carry of the previous lane, flush
+                {
+                    const bool need = have_first && cont_prev;
+#pragma unroll
+                    for (int k = 0; k < STAT_KEYS; k++) {
+                        const Key c = __shfl_up(sv[k], 1);
+                        const Key j2 = key_is_min(k) ? (c < firstv[k] ? c : firstv[k]) : (c > firstv[k] ? c : firstv[k]);
+                        firstv[k] = need ? j2 : firstv[k];
+                    }
+                    if (have_first) {
+                        Key* kk = s_keys + ((first_key >> 3) * NUM_BUCKETS + (first_key & 7)) * STAT_KEYS;
+#pragma unroll
+                        for (int k = 0; k < STAT_KEYS; k++) { if (key_is_min(k)) atomicMin(&kk[k], firstv[k]); else atomicMax(&kk[k], firstv[k]); }
+                    }
+                }
+                // the last run is flushed by the last lane it reaches inside this wave
+                const int next_cont = __shfl_down((int)cont_prev, 1);
+                if (cur_key >= 0 && (lane == WAVE - 1 || !next_cont)) {
+                    Key* kk = s_keys + ((cur_key >> 3) * NUM_BUCKETS + (cur_key & 7)) * STAT_KEYS;
+#pragma unroll
+                    for (int k = 0; k < STAT_KEYS; k++) { if (key_is_min(k)) atomicMin(&kk[k], sv[k]); else atomicMax(&kk[k], sv[k]); }
+                }
+            }
+            __syncthreads();
+            MID_T(3);
+            // ---- phase 4: select (wave 0; lane s owns sub-node s)
+            if (wv == 0) {
+                const bool has = (uint32_t)lane < nsub;
+                MidSub<T>* m = &s_sub[cur][has ? lane : 0];
+                uint32_t cnt[NUM_BUCKETS];
+                T AL[6], CL[6], AR[6], CR[6];
+                uint32_t nl = 1, cl = 0, cr = 0;
+                if (has) {
+                    uint32_t cin[NUM_BUCKETS];
+#pragma unroll
+                    for (int b = 0; b < NUM_BUCKETS; b++) cin[b] = m->base[b + 1] - m->base[b];
+                    nl = sah_select<T>(s_keys + lane * NUM_BUCKETS * STAT_KEYS, cin, m->A, m->degen != 0, cnt, AL, CL, AR, CR);
+                    cl = nl; cr = m->count - nl;
+                    const uint32_t ni = m->ni, li = ni + 1, ri = li + (2 * nl - 1);  // bvh_node.rs:138-142
+                    typename Tr::Node* nd = &a.nodes[ni];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        nd->l_min[k] = AL[k]; nd->l_max[k] = AL[3 + k];
+                        nd->r_min[k] = AR[k]; nd->r_max[k] = AR[3 + k];
+                    }
+                    nd->parent = m->parent; nd->l = li; nd->r = ri; nd->shape = NONE;
+                    a.node_start[ni] = istart + m->start;
+                    a.node_count[ni] = m->count;
+                    m->nl = nl;
+                }
+                const bool subL = has && cl > (uint32_t)SMALL_MAX, subR = has && cr > (uint32_t)SMALL_MAX;
+                const bool smL = has && !subL, smR = has && !subR;
+                const unsigned long long mL = __ballot(subL), mR = __ballot(subR);
+                const unsigned long long qL = __ballot(smL), qR = __ballot(smR);
+                const uint32_t idL = (uint32_t)(__popcll(mL & lt) + __popcll(mR & lt));
+                const uint32_t idR = idL + (subL ? 1u : 0u);
+                const uint32_t nsmall = (uint32_t)(__popcll(qL) + __popcll(qR));
+                uint32_t sbase = 0;
+                if (lane == 0 && nsmall) sbase = atomicAdd(&a.ctr[CTR_SMALL], nsmall);
+                sbase = __shfl(sbase, 0);
+                const uint32_t slL = sbase + (uint32_t)(__popcll(qL & lt) + __popcll(qR & lt));
+                const uint32_t slR = slL + (smL ? 1u : 0u);
+                if (has) {
+                    const uint32_t ni = m->ni, li = ni + 1, ri = li + (2 * nl - 1);
+                    m->child[0] = subL ? idL : NONE;
+                    m->child[1] = subR ? idR : NONE;
+                    for (int side = 0; side < 2; side++) {
+                        const bool is_sub = side ? subR : subL;
+                        const uint32_t cstart = side ? m->start + nl : m->start;
+                        const uint32_t ccount = side ? cr : cl;
+                        const uint32_t cni = side ? ri : li;
+                        const T* CA = side ? AR : AL;
+                        const T* CC = side ? CR : CL;
+                        if (is_sub) {
+                            MidSub<T>* c = &s_sub[cur ^ 1][side ? idR : idL];
+                            c->start = cstart; c->count = ccount; c->ni = cni; c->parent = ni;
+#pragma unroll
+                            for (int k = 0; k < 6; k++) { c->A[k] = CA[k]; c->C[k] = CC[k]; }
+                            midsub_derive(c);
+                        } else {
+                            Item<T>* g = &a.small[side ? slR : slL];
+                            g->ni = cni; g->parent = ni; g->start = istart + cstart; g->count = ccount;
+                            g->tile_base = 0; g->parity = out_parity; g->_r0 = 0; g->_r1 = 0;
+#pragma unroll
+                            for (int k = 0; k < 6; k++) { g->A[k] = CA[k]; g->C[k] = CC[k]; }
+                        }
+                    }
+                }
+                if (lane == 0) s_nsub = (uint32_t)(__popcll(mL) + __popcll(mR));
+            }
+            __syncthreads();
+            MID_T(4);
+            // ---- phase 5: positions follow their sub-node's child; slices of children that leave the
+            //      workgroup (<= 64 shapes) are written to the global index buffer for the wave tier
+#pragma unroll
+            for (int j = 0; j < PPT; j++) {
+                if (sg[j] == SEG_NONE) continue;
+                const uint32_t p = tid * PPT + j;
+                const MidSub<T>* m = &s_sub[cur][sg[j]];
+                const uint32_t ch = m->child[(p - m->start) < m->nl ? 0 : 1];
+                if (ch != NONE) s_seg[p] = (uint8_t)ch;
+                else { s_seg[p] = SEG_NONE; gdst[istart + p] = s_idx[p]; }
+            }
+            __syncthreads();
+            MID_T(5);
+            cur ^= 1;
+            nsub = s_nsub;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // tier 2 — wave-subtree kernel
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float push_lane(float v, int dst) {
@@ -406,12 +852,14 @@ __device__ __forceinline__ double push_lane(double v, int dst) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T> a, uint32_t n_small) {
+template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T> a, uint32_t first) {
     using Tr = Traits<T>;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (wave >= n_small) return;
+    const uint32_t n_small = a.ctr[CTR_SMALL];
+    const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const int lane = lane_id();
     const unsigned long long lt = lanemask_lt();
+    for (uint32_t wave = first + wave0; wave < n_small; wave += nwaves) {
     const Item<T>* it = &a.small[wave];
     const uint32_t istart = it->start;
     const int n = (int)it->count;
@@ -555,6 +1003,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
             for (int k = 0; k < 6; k++) Cb[k] = Cn[k];
         }
     }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -572,7 +1021,9 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     t->levels = 0;
     if (n == 0) { t->built = true; return; }
 
-    const size_t max_big = n / (SMALL_MAX + 1) + 2;
+    constexpr size_t MID_MAX = (size_t)MidCfg<T>::MAXN;
+    const size_t max_big = n / (MID_MAX + 1) + 2;       // simultaneously active nodes with > MID_MAX shapes
+    const size_t max_mid = n / (SMALL_MAX + 1) + 2;     // nodes with 65..MID_MAX shapes whose parent was larger
     const size_t max_tiles = n / TILE + max_big + 2;
     t->aabbs.reserve(n * 6 * sizeof(T));
     t->nodes.reserve(t->n_nodes * sizeof(typename Tr::Node));
@@ -587,6 +1038,7 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
         t->stats[i].reserve(max_big * sizeof(ItemStats<T>));
         t->tile_item[i].reserve(max_tiles * 4);
     }
+    t->mid.reserve(max_mid * sizeof(Item<T>));
     t->small.reserve((n + 1) * sizeof(Item<T>));
     t->tile_cnt.reserve(max_tiles * NUM_BUCKETS * 4);
     t->ctr.reserve(ROOTKEY_OFF + STAT_KEYS * sizeof(Key));
@@ -603,6 +1055,7 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     a.idx[0] = t->idx[0].as<uint32_t>(); a.idx[1] = t->idx[1].as<uint32_t>();
     a.bk = t->bk.as<uint8_t>();
     a.big[0] = t->big[0].as<Item<T>>(); a.big[1] = t->big[1].as<Item<T>>();
+    a.mid = t->mid.as<Item<T>>();
     a.small = t->small.as<Item<T>>();
     a.stats[0] = t->stats[0].as<ItemStats<T>>(); a.stats[1] = t->stats[1].as<ItemStats<T>>();
     a.tile_item[0] = t->tile_item[0].as<uint32_t>(); a.tile_item[1] = t->tile_item[1].as<uint32_t>();
@@ -612,49 +1065,65 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     a.n = (uint32_t)n;
 
     hipLaunchKernelGGL(k_init<T>, dim3(1), dim3(256), 0, st, a);
-
-    const int prep_grid = (int)std::min<size_t>((n + 255) / 256, (size_t)ctx->n_cu * 4);
+    const int prep_grid = (int)std::min<size_t>((n + 1023) / 1024, 256);
     hipLaunchKernelGGL(k_prep<T>, dim3(prep_grid), dim3(256), 0, st, a);
     hipLaunchKernelGGL(k_root<T>, dim3(1), dim3(64), 0, st, a);
 
     const int tile_grid = (int)std::min<size_t>(max_tiles, 2048);
     const int sel_grid = (int)std::min<size_t>((max_big + 3) / 4, 1024);
+    const int mid_grid = (int)std::min<size_t>(max_mid, (size_t)ctx->n_cu);
+    const int small_grid = (int)std::min<size_t>((n + 3) / 4, (size_t)ctx->n_cu * 8);
     uint32_t* pin = reinterpret_cast<uint32_t*>(ctx->pinned);
+    auto run_level = [&](int L) {
+        hipLaunchKernelGGL(k_bin<T>, dim3(tile_grid), dim3(256), 0, st, a, L);
+        hipLaunchKernelGGL(k_select<T>, dim3(sel_grid), dim3(256), 0, st, a, L);
+        hipLaunchKernelGGL(k_scatter<T>, dim3(tile_grid), dim3(256), 0, st, a, L);
+    };
+    // Optimistic schedule with no host round trip: enough level-synchronous passes for a balanced
+    // tree, then the workgroup tier over everything queued so far, then the wave tier.  ONE readback
+    // at the end checks that nothing is left in the level queue; unbalanced trees continue from there.
     int level = 0;
-    uint32_t n_small = 0;
-    if (n > (size_t)SMALL_MAX) {
-        // optimistic batch of levels without host round-trips, then one check; unbalanced trees
-        // continue level by level
-        int fixed = 3;
-        for (size_t m = n; m > (size_t)SMALL_MAX; m = (m + 1) / 2) fixed++;
+    if (n > (size_t)MID_MAX) {
+        int fixed = 2;
+        for (size_t m = n; m > (size_t)MID_MAX; m = (m + 1) / 2) fixed++;
         if (fixed > MAXLV - 4) fixed = MAXLV - 4;
-        auto run_level = [&](int L) {
-            hipLaunchKernelGGL(k_bin<T>, dim3(tile_grid), dim3(256), 0, st, a, L);
-            hipLaunchKernelGGL(k_select<T>, dim3(sel_grid), dim3(256), 0, st, a, L);
-            hipLaunchKernelGGL(k_scatter<T>, dim3(tile_grid), dim3(256), 0, st, a, L);
-        };
         for (; level < fixed; level++) run_level(level);
+    }
+    uint32_t mid_done = 0, small_done = 0;
+    while (true) {
+        if (n > (size_t)SMALL_MAX) hipLaunchKernelGGL(k_mid<T>, dim3(mid_grid), dim3(MID_THREADS), 0, st, a, mid_done);
+        hipLaunchKernelGGL(k_small<T>, dim3(small_grid), dim3(256), 0, st, a, small_done);
+        BVH_HIP(hipMemcpyAsync(pin, a.ctr, ROOTKEY_OFF, hipMemcpyDeviceToHost, st));
+        BVH_HIP(hipStreamSynchronize(st));
+        BVH_HIP(hipGetLastError());
+        mid_done = pin[CTR_MID];
+        small_done = pin[CTR_SMALL];
+        if (n <= (size_t)MID_MAX || pin[CTR_LEVEL0 + 2 * lvl_slot(level)] == 0) break;
+        // slow path: the level queue is not empty yet — one more level per host round trip
         while (true) {
-            BVH_HIP(hipMemcpyAsync(pin, a.ctr, ROOTKEY_OFF, hipMemcpyDeviceToHost, st));
-            BVH_HIP(hipStreamSynchronize(st));
-            n_small = pin[CTR_SMALL];
-            uint32_t pending = pin[CTR_LEVEL0 + 2 * lvl_slot(level)];
-            if (pending == 0) break;
             if (level + 1 >= MAXLV - 2)  // recycle the slot the next level will append to
                 BVH_HIP(hipMemsetAsync(a.ctr + CTR_LEVEL0 + 2 * lvl_slot(level + 1), 0, 8, st));
             run_level(level);
             level++;
+            BVH_HIP(hipMemcpyAsync(pin, a.ctr, ROOTKEY_OFF, hipMemcpyDeviceToHost, st));
+            BVH_HIP(hipStreamSynchronize(st));
+            if (pin[CTR_LEVEL0 + 2 * lvl_slot(level)] == 0) break;
         }
-        // trailing empty levels of the optimistic batch do not count
-        while (level > 0 && level - 1 < MAXLV - 2 && pin[CTR_LEVEL0 + 2 * (level - 1)] == 0) level--;
-    } else {
-        n_small = 1;
     }
-    t->levels = level;
-    if (n_small) hipLaunchKernelGGL(k_small<T>, dim3((n_small + 3) / 4), dim3(256), 0, st, a, n_small);
-    BVH_HIP(hipGetLastError());
+    // diagnostic: number of level-synchronous passes that had work
+    int used = level;
+    while (used > 0 && used - 1 < MAXLV - 2 && pin[CTR_LEVEL0 + 2 * (used - 1)] == 0) used--;
+    t->levels = used;
     t->built = true;
 }
+
+#ifdef BVH_PROFILE_MID
+void debug_mid_prof(unsigned long long* out, bool reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mid_prof), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mid_prof), z, sizeof z); }
+}
+#endif
 
 template void build_tree<float>(bvhgpu_tree*, const float*, size_t);
 template void build_tree<double>(bvhgpu_tree*, const double*, size_t);

@@ -54,7 +54,7 @@ void free_tree_buffers(bvhgpu_tree* t) {
     t->aabbs.release(); t->nodes.release(); t->node_start.release(); t->node_count.release();
     t->shape_node.release(); t->flat.release(); t->trav.release();
     t->idx[0].release(); t->idx[1].release(); t->bk.release();
-    t->big[0].release(); t->big[1].release(); t->small.release();
+    t->big[0].release(); t->big[1].release(); t->mid.release(); t->small.release();
     t->stats[0].release(); t->stats[1].release();
     t->tile_item[0].release(); t->tile_item[1].release(); t->tile_cnt.release(); t->ctr.release();
 }
@@ -194,6 +194,10 @@ int tree_from_flat(bvhgpu_ctx* ctx, const typename Traits<T>::Flat* flat, size_t
 }
 
 }  // namespace
+
+#ifdef BVH_PROFILE_MID
+namespace bvhgpu { void debug_mid_prof(unsigned long long* out, bool reset); }
+#endif
 
 extern "C" {
 
@@ -516,5 +520,9 @@ int bvhgpu_last_timings(bvhgpu_ctx* ctx, bvhgpu_timings* out) {
         return (int)BVHGPU_OK;
     });
 }
+
+#ifdef BVH_PROFILE_MID
+void bvhgpu_debug_mid_prof(unsigned long long* out, int reset) { bvhgpu::debug_mid_prof(out, reset != 0); }
+#endif
 
 }  // extern "C"

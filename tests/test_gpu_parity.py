@@ -167,16 +167,32 @@ def test_parity_degenerate_and_collisions(eng, orc, dtype):
 
 
 def test_parity_unbalanced_deep_tree(eng, orc):
-    """exponentially spaced boxes: SAH peels a few shapes per level → far more levels than the
-    optimistic batch, exercising the host-synchronised continuation of the level loop."""
-    n = 3000
-    x = np.float32(1.02) ** np.arange(n, dtype=np.float32)
+    """exponentially spaced boxes: SAH peels a few hundred shapes per level → far more level-synchronous
+    passes than the optimistic batch, exercising the host-synchronised continuation of the level loop
+    (and re-launches of the workgroup and wave tiers for the items queued late)."""
+    n = 12000
+    x = np.float32(1.004) ** np.arange(n, dtype=np.float32)
     lo = np.stack([x, np.zeros(n, np.float32), np.zeros(n, np.float32)], axis=1)
     aabbs = np.concatenate([lo, lo + np.float32(0.5)], axis=1).astype(np.float32)
     o = np.zeros((64, 3), np.float32); o[:, 1] = 0.25; o[:, 2] = 0.25; o[:, 0] = -1
     d = np.tile(np.array([1, 0, 0], np.float32), (64, 1))
     bvh, *_ = _full_parity(eng, orc, aabbs, orc.make_rays(o, d), 1e-5)
-    assert bvh.build_levels > 20
+    assert bvh.build_levels >= 5  # optimistic batch for n = 12 000 is 4 passes: the continuation ran
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [4095, 4096, 4097, 8193, 30000])
+def test_parity_mid_tier_boundaries(eng, orc, n, dtype):
+    """sizes around MID_MAX = 4096 (workgroup tier) with clustered data so sub-node sizes vary widely."""
+    rng = np.random.default_rng(n)
+    centres = rng.uniform(-1000, 1000, size=(37, 3))
+    which = rng.integers(0, 37, size=n)
+    lo = (centres[which] + rng.normal(scale=rng.uniform(0.01, 30, size=(37, 1))[which], size=(n, 3))).astype(dtype)
+    ext = rng.uniform(0, 2, size=(n, 3)).astype(dtype)
+    aabbs = np.concatenate([lo, lo + ext], axis=1)
+    o = rng.uniform(-1100, 1100, size=(500, 3)).astype(dtype)
+    d = rng.normal(size=(500, 3)).astype(dtype)
+    _full_parity(eng, orc, aabbs, orc.make_rays(o, d, dtype), 1e-5 if dtype == np.float32 else 1e-12)
 
 
 def test_rebuild_and_determinism(eng, orc):
