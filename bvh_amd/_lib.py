@@ -39,7 +39,7 @@ class BvhGpuError(RuntimeError):
 
 class TraverseStats(C.Structure):
     _fields_ = [("hits", C.c_uint64), ("visited", C.c_uint64), ("leaf_visits", C.c_uint64),
-                ("device_steps", C.c_uint64)]
+                ("device_steps", C.c_uint64), ("wave_steps", C.c_uint64)]
 
 
 class Timings(C.Structure):
@@ -87,7 +87,10 @@ SYMBOLS = [
     ("bvhgpu_hits_destroy", None, [_vp]),
     ("bvhgpu_enable_timing", _i, [_vp, _i]),
     ("bvhgpu_last_timings", _i, [_vp, C.POINTER(Timings)]),
+    ("bvhgpu_set_tuning", _i, [_vp, _i, _i]),
+    ("bvhgpu_get_tuning", _i, [_vp, _i, C.POINTER(_i)]),
 ]
+TUNE_TRAVERSE_VARIANT, TUNE_TRAVERSE_WAVES_PER_CU, TUNE_TRAVERSE_REFILL_MIN = 0, 1, 2
 
 _lib = None
 

@@ -90,6 +90,10 @@ class Context:
         return dict(build_ms=t.build_ms, flatten_ms=t.flatten_ms, traverse_kernel_ms=t.traverse_kernel_ms,
                     traverse_total_ms=t.traverse_total_ms)
 
+    def set_tuning(self, knob: int, value: int):
+        """performance knobs (include/bvh_mi355x.h bvhgpu_tune); results never change."""
+        check(_lib.load().bvhgpu_set_tuning(self._h, int(knob), int(value)), self._h)
+
     def close(self):
         if getattr(self, "_h", None) and not _closing:
             _lib.load().bvhgpu_destroy(self._h)
@@ -299,7 +303,7 @@ class _TreeBase:
         st = _lib.TraverseStats()
         check(lib.bvhgpu_hits_info(self._hits.h, None, C.byref(total), C.byref(st)), self.ctx._h)
         sd = dict(hits=int(st.hits), visited=int(st.visited), leaf_visits=int(st.leaf_visits),
-                  device_steps=int(st.device_steps))
+                  device_steps=int(st.device_steps), wave_steps=int(st.wave_steps))
         if not fetch:
             return None, None, None, sd
         ft = np.float32 if self.sfx == "f32" else np.float64

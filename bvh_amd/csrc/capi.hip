@@ -52,7 +52,7 @@ void copy_out(bvhgpu_ctx* ctx, void* dst, const void* src_dev, size_t bytes, int
 
 void free_tree_buffers(bvhgpu_tree* t) {
     t->aabbs.release(); t->nodes.release(); t->node_start.release(); t->node_count.release();
-    t->shape_node.release(); t->flat.release(); t->trav.release();
+    t->shape_node.release(); t->flat.release(); t->trav.release(); t->slot_entry.release(); t->node_slot.release();
     t->idx[0].release(); t->idx[1].release(); t->bk.release();
     t->big[0].release(); t->big[1].release(); t->mid.release(); t->small.release();
     t->stats[0].release(); t->stats[1].release();
@@ -168,9 +168,38 @@ int tree_from_flat(bvhgpu_ctx* ctx, const typename Traits<T>::Flat* flat, size_t
                 return fail(ctx, BVHGPU_INVALID_ARG, "flat navigator entry/exit out of range");
             for (int k = 0; k < 3; k++) { tn.mn[k] = f.min[k]; tn.mx[k] = f.max[k]; }
             tn.exit = f.exit;
-            tn.shape = NONE;
+            tn.shape = TRAV_INNER | SLOT_NONE;
         }
         trav[i] = tn;
+    }
+    // top-of-tree slots (heap numbers, flatten.hip k_top_slots) for the LDS-resident part of traversal:
+    // an entry's first child follows it directly, its second child sits at the first child's exit.
+    constexpr uint32_t SLOTS = TopCfg<T>::SLOTS;
+    std::vector<uint32_t> slot_entry(SLOTS, NONE);
+    {
+        struct Frame { size_t index; uint32_t exit, heap, kids; };
+        std::vector<Frame> stack;
+        std::vector<uint32_t> heap(n_flat, SLOT_NONE);
+        stack.push_back(Frame{(size_t)-1, (uint32_t)n_flat, 1u, 0u});
+        bool binary = true;
+        for (size_t i = 0; i < n_flat && binary; i++) {
+            while (stack.size() > 1 && stack.back().exit <= i) stack.pop_back();
+            Frame& par = stack.back();
+            if (++par.kids > 2) { binary = false; break; }
+            const uint32_t h = std::min<uint32_t>(2u * par.heap + (par.kids - 1u), SLOT_NONE);
+            heap[i] = h;
+            if (flat[i].entry != NONE) stack.push_back(Frame{i, flat[i].exit, h, 0u});
+        }
+        if (binary) {
+            for (size_t i = 0; i < n_flat; i++) {
+                if (heap[i] < SLOTS) slot_entry[heap[i]] = (uint32_t)i;
+                if (flat[i].entry != NONE) {
+                    const uint32_t ex = flat[i].exit;
+                    const uint32_t es = (ex < n_flat && heap[ex] < SLOTS) ? heap[ex] : SLOT_NONE;
+                    trav[i].shape = TRAV_INNER | es;
+                }
+            }
+        }
     }
     bvhgpu_tree* t = new bvhgpu_tree();
     t->ctx = ctx; t->dtype = Traits<T>::dtype; t->n = n; t->n_nodes = 0; t->n_flat = n_flat; t->n_trav = n_flat;
@@ -179,6 +208,8 @@ int tree_from_flat(bvhgpu_ctx* ctx, const typename Traits<T>::Flat* flat, size_t
         t->aabbs.reserve(n * 6 * sizeof(T) + 16);
         t->trav.reserve(n_flat * sizeof(TravNode<T>) + 16);
         t->flat.reserve(n_flat * sizeof(typename Traits<T>::Flat) + 16);
+        t->slot_entry.reserve(SLOTS * 4);
+        BVH_HIP(hipMemcpyAsync(t->slot_entry.p, slot_entry.data(), SLOTS * 4, hipMemcpyHostToDevice, ctx->stream));
         if (n) BVH_HIP(hipMemcpyAsync(t->aabbs.p, shape_aabbs, n * 6 * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
         if (n_flat) {
             BVH_HIP(hipMemcpyAsync(t->trav.p, trav.data(), n_flat * sizeof(TravNode<T>), hipMemcpyHostToDevice, ctx->stream));
@@ -519,6 +550,17 @@ int bvhgpu_last_timings(bvhgpu_ctx* ctx, bvhgpu_timings* out) {
         *out = ctx->last;
         return (int)BVHGPU_OK;
     });
+}
+
+int bvhgpu_set_tuning(bvhgpu_ctx* ctx, int knob, int value) {
+    if (!ctx || knob < 0 || knob >= BVHGPU_TUNE_COUNT) return BVHGPU_INVALID_ARG;
+    ctx->tune[knob] = value;
+    return BVHGPU_OK;
+}
+int bvhgpu_get_tuning(const bvhgpu_ctx* ctx, int knob, int* value) {
+    if (!ctx || !value || knob < 0 || knob >= BVHGPU_TUNE_COUNT) return BVHGPU_INVALID_ARG;
+    *value = ctx->tune[knob];
+    return BVHGPU_OK;
 }
 
 #ifdef BVH_PROFILE_MID

@@ -42,6 +42,7 @@ struct bvhgpu_ctx {
     bool own_stream = false;
     std::string err;
     int n_cu = 256;
+    int tune[BVHGPU_TUNE_COUNT] = {0, 32, 1, 16384, 1, 0, 0, 0};  // bvhgpu_set_tuning defaults
     // timing
     bool timing = false;
     hipEvent_t ev[8] = {};
@@ -72,6 +73,8 @@ struct bvhgpu_tree {
     bvhgpu::DevBuf shape_node;  // n * u32
     bvhgpu::DevBuf flat;        // n_flat * Flat     (reference layout, for export/parity)
     bvhgpu::DevBuf trav;        // n_trav * TravNode (engine layout, what traversal reads)
+    bvhgpu::DevBuf slot_entry;  // TopCfg::SLOTS * u32: traversal entry held in LDS slot s (NONE = unused slot)
+    bvhgpu::DevBuf node_slot;   // n_nodes * u16: LDS slot of the node's traversal entry (SLOT_NONE = not resident)
     // build scratch (kept for rebuild)
     bvhgpu::DevBuf idx[2];      // n * u32 ping-pong permutation
     bvhgpu::DevBuf bk;          // n * u8 bucket per position
@@ -90,7 +93,7 @@ struct bvhgpu_hits {
     size_t n_rays = 0;
     uint64_t total = 0;
     unsigned flags = 0;
-    bvhgpu_traverse_stats stats = {0, 0, 0, 0};
+    bvhgpu_traverse_stats stats = {0, 0, 0, 0, 0};
     bvhgpu::DevBuf counts;   // n_rays+1 u32 (counts, scanned in place into offsets)
     bvhgpu::DevBuf offsets;  // n_rays+1 u32
     bvhgpu::DevBuf pool;     // hit records (ray, k, shape)

@@ -58,20 +58,24 @@ __global__ __launch_bounds__(256) void k_traverse(const TravNode<T>* __restrict_
     }
     uint32_t i = active ? 0u : n_trav;
     uint32_t cnt = 0;
-    unsigned long long steps = 0, leaf_steps = 0;
+    unsigned long long steps = 0, leaf_steps = 0, wsteps = 0;
+    // wave-uniform: every ray of this wave is finite → the NaN-free slab test (common.hpp) is exact
+    const bool fast = !WITH_T && !__any(active && !ray_is_finite<T>(o, inv));
     while (true) {
         const bool run = i < n_trav;
         if (!__any(run)) break;
         bool rec = false;
         uint32_t shape = NONE;
         T t0 = 0, t1 = 0;
+        if (STATS) wsteps++;
         if (run) {
             const NodeRegs<T> nd = load_node(nodes + i);
-            const bool hit = slab_hit<T>(o, inv, nd.mn, nd.mx, t0, t1);
+            const bool hit = fast ? slab_hit_finite<T>(o, inv, nd.mn, nd.mx) : slab_hit<T>(o, inv, nd.mn, nd.mx, t0, t1);
             shape = nd.shape;
-            rec = hit && (shape != NONE);
-            i = hit ? i + 1 : nd.exit;
-            if (STATS) { steps++; leaf_steps += (shape != NONE) ? 1 : 0; }
+            const bool leaf = trav_is_leaf(shape);
+            rec = hit && leaf;
+            i = hit ? i + 1 : nd.exit;   // a leaf's exit IS i+1
+            if (STATS) { steps++; leaf_steps += leaf ? 1 : 0; }
         }
         const unsigned long long m = __ballot(rec);
         if (m) {
@@ -99,7 +103,290 @@ __global__ __launch_bounds__(256) void k_traverse(const TravNode<T>* __restrict_
             steps += __shfl_down(steps, d);
             leaf_steps += __shfl_down(leaf_steps, d);
         }
-        if (lane == 0) { atomicAdd(&ctr[1], steps); atomicAdd(&ctr[2], leaf_steps); }
+        if (lane == 0) { atomicAdd(&ctr[1], steps); atomicAdd(&ctr[2], leaf_steps); atomicAdd(&ctr[4], wsteps); }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// persistent variant: a wave owns a contiguous range of rays and keeps its 64 lanes busy — a lane whose
+// ray has left the tree takes the next ray of the range (wave-uniform cursor, no atomics, no LDS).
+// With one ray per lane for the whole launch a wave runs until its LONGEST ray ends (E[max of 64] is
+// ~2.7x the mean walk length on the 120k-triangle scene); with refill a wave-step does useful work in
+// almost every lane.  Hit records go to the pool in per-wave CHUNKs: one global atomic per 64 records
+// instead of one per wave-step with a hit (hit-heavy scenes would serialise on that one address);
+// the unused tail of a chunk is marked invalid (ray == NONE) for k_hits_scatter.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t POOL_CHUNK = 64;  // >= 64: one wave-step reports at most 64 hits
+
+template <typename T, bool WITH_T, bool STATS>
+__global__ __launch_bounds__(256) void k_traverse_persist(const TravNode<T>* __restrict__ nodes, uint32_t n_trav,
+                                                          const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_rays,
+                                                          uint32_t rays_per_wave, uint32_t refill_min,
+                                                          uint32_t* __restrict__ counts, HitRec* __restrict__ pool,
+                                                          T* __restrict__ pool_t, unsigned long long pool_cap,
+                                                          unsigned long long* __restrict__ ctr) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = lane_id();
+    const unsigned long long lt = lanemask_lt();
+    const unsigned long long b0 = (unsigned long long)wave * rays_per_wave;
+    const unsigned long long b1 = b0 + rays_per_wave;
+    uint32_t next = (uint32_t)(b0 < n_rays ? b0 : n_rays);      // wave-uniform cursor into the range
+    const uint32_t end = (uint32_t)(b1 < n_rays ? b1 : n_rays);
+    next = __builtin_amdgcn_readfirstlane(next);
+    T o[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
+    uint32_t r = NONE, i = n_trav, cnt = 0;
+    bool fin = true;               // this lane's ray has only finite components (NaN-free slab test is exact)
+    unsigned long long cpos = 0;   // wave-uniform: next free slot of this wave's pool chunk
+    uint32_t cleft = 0;            // wave-uniform: free slots left in it
+    unsigned long long steps = 0, leaf_steps = 0, wsteps = 0;
+    while (true) {
+        bool run = i < n_trav;
+        const unsigned long long idle = __ballot(!run);
+        if (idle) {
+            if (!run && r != NONE) { counts[r] = cnt; r = NONE; }   // the ray's Vec is complete
+            const uint32_t nidle = (uint32_t)__popcll(idle);
+            if (next < end && nidle >= refill_min) {
+                const uint32_t mine = next + (uint32_t)__popcll(idle & lt);
+                if (!run && mine < end) {
+                    r = mine;
+                    const typename Traits<T>::Ray* rp = rays + r;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { o[k] = rp->o[k]; inv[k] = rp->inv[k]; }
+                    i = 0; cnt = 0; run = true;
+                    fin = ray_is_finite<T>(o, inv);
+                }
+                next = (end - next) < nidle ? end : next + nidle;
+            }
+            if (!__any(run)) break;   // nothing in flight and the range is exhausted
+        }
+        bool rec = false;
+        uint32_t shape = NONE;
+        T t0 = 0, t1 = 0;
+        if (STATS) wsteps++;
+        const bool fast = !WITH_T && !__any(run && !fin);   // wave-uniform
+        if (run) {
+            const NodeRegs<T> nd = load_node(nodes + i);
+            const bool hit = fast ? slab_hit_finite<T>(o, inv, nd.mn, nd.mx) : slab_hit<T>(o, inv, nd.mn, nd.mx, t0, t1);
+            shape = nd.shape;
+            const bool leaf = trav_is_leaf(shape);
+            rec = hit && leaf;
+            i = hit ? i + 1 : nd.exit;   // a leaf's exit IS i+1
+            if (STATS) { steps++; leaf_steps += leaf ? 1 : 0; }
+        }
+        const unsigned long long m = __ballot(rec);
+        if (m) {
+            const uint32_t h = (uint32_t)__popcll(m);
+            if (h > cleft) {   // wave-uniform: start a new chunk, invalidate what is left of the old one
+                if ((uint32_t)lane < cleft && cpos + lane < pool_cap) pool[cpos + lane].ray = NONE;
+                unsigned int blo = 0, bhi = 0;
+                if (lane == 0) {
+                    unsigned long long b = atomicAdd(&ctr[0], (unsigned long long)POOL_CHUNK);
+                    blo = (unsigned int)b; bhi = (unsigned int)(b >> 32);
+                }
+                blo = __builtin_amdgcn_readfirstlane(blo); bhi = __builtin_amdgcn_readfirstlane(bhi);
+                cpos = ((unsigned long long)bhi << 32) | blo;
+                cleft = POOL_CHUNK;
+            }
+            if (rec) {
+                const unsigned long long slot = cpos + __popcll(m & lt);
+                if (slot < pool_cap) {
+                    HitRec hr; hr.ray = r; hr.k = cnt; hr.shape = shape;
+                    pool[slot] = hr;
+                    if (WITH_T) { pool_t[2 * slot] = t0; pool_t[2 * slot + 1] = t1; }
+                }
+                cnt++;
+            }
+            cpos += h; cleft -= h;
+        }
+    }
+    if ((uint32_t)lane < cleft && cpos + lane < pool_cap) pool[cpos + lane].ray = NONE;
+    if (STATS) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            steps += __shfl_down(steps, d);
+            leaf_steps += __shfl_down(leaf_steps, d);
+        }
+        if (lane == 0) { atomicAdd(&ctr[1], steps); atomicAdd(&ctr[2], leaf_steps); atomicAdd(&ctr[4], wsteps); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-resident top of the tree.  On the 120k-triangle scene 85 % of all box tests touch the first 12
+// levels of the tree (4095 entries) and the vector L1 — one tag lookup per lane per 16-byte load for
+// these scattered reads — is the unit that saturates.  One 1024-thread workgroup per CU copies the
+// entries whose heap number is below TopCfg<T>::SLOTS into LDS (split into 16-byte planes so that a
+// ds_read_b128 of 16 lanes spreads over all 16 bank quads) and every lane tracks the slot of its
+// current entry: descend → 2*slot, miss → the exit's slot carried in the entry's spare word.  A lane
+// outside the resident set (deep in the tree, or after a leaf) reads HBM/L2 as before and re-enters
+// the resident set through the same word.  Waves are persistent with ray refill as above.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct TopLds;
+template <> struct TopLds<float> {
+    static constexpr uint32_t K = TopCfg<float>::SLOTS;
+    float4 lo[K], hi[K];
+    __device__ __forceinline__ void store(uint32_t q, const TravNode<float>* g) {
+        const float4* p = reinterpret_cast<const float4*>(g);
+        lo[q] = p[0]; hi[q] = p[1];
+    }
+    __device__ __forceinline__ NodeRegs<float> load(uint32_t q) const {
+        const float4 a = lo[q], b = hi[q];
+        NodeRegs<float> r;
+        r.mn[0] = a.x; r.mn[1] = a.y; r.mn[2] = a.z; r.exit = __float_as_uint(a.w);
+        r.mx[0] = b.x; r.mx[1] = b.y; r.mx[2] = b.z; r.shape = __float_as_uint(b.w);
+        return r;
+    }
+};
+template <> struct TopLds<double> {
+    static constexpr uint32_t K = TopCfg<double>::SLOTS;
+    double2 a[K], b[K], c[K];
+    uint2 d[K];
+    __device__ __forceinline__ void store(uint32_t q, const TravNode<double>* g) {
+        const double2* p = reinterpret_cast<const double2*>(g);
+        a[q] = p[0]; b[q] = p[1]; c[q] = p[2];
+        const unsigned long long es = (unsigned long long)__double_as_longlong(p[3].x);
+        d[q] = make_uint2((uint32_t)(es & 0xFFFFFFFFull), (uint32_t)(es >> 32));
+    }
+    __device__ __forceinline__ NodeRegs<double> load(uint32_t q) const {
+        const double2 x = a[q], y = b[q], z = c[q];
+        const uint2 w = d[q];
+        NodeRegs<double> r;
+        r.mn[0] = x.x; r.mn[1] = x.y; r.mn[2] = y.x;
+        r.mx[0] = y.y; r.mx[1] = z.x; r.mx[2] = z.y;
+        r.exit = w.x; r.shape = w.y;
+        return r;
+    }
+};
+
+constexpr int LDS_THREADS = 1024;
+
+// R rays per lane: one wave-step issues the node fetches of R independent walks before it waits, so a
+// workgroup of 16 waves keeps 16*R fetches per SIMD-quad in flight (the walk is a dependent chain of
+// ~750 ns steps; with the top of the tree in LDS almost every step still has a few lanes deep in the
+// tree that read L2, and only memory-level parallelism hides that).
+template <typename T, bool WITH_T, bool STATS, int R>
+__global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>* __restrict__ nodes, uint32_t n_trav,
+                                                               const uint32_t* __restrict__ slot_entry, uint32_t first_slot,
+                                                               const typename Traits<T>::Ray* __restrict__ rays,
+                                                               uint32_t n_rays, uint32_t rays_per_wave, uint32_t refill_min,
+                                                               uint32_t* __restrict__ counts, HitRec* __restrict__ pool,
+                                                               T* __restrict__ pool_t, unsigned long long pool_cap,
+                                                               unsigned long long* __restrict__ ctr) {
+    constexpr uint32_t K = TopLds<T>::K;
+    __shared__ TopLds<T> top;
+    for (uint32_t q = threadIdx.x; q < K; q += LDS_THREADS) {
+        const uint32_t e = slot_entry[q];
+        if (e != NONE) top.store(q, nodes + e);
+    }
+    __syncthreads();
+
+    const uint32_t wave = (blockIdx.x * LDS_THREADS + threadIdx.x) >> 6;
+    const int lane = lane_id();
+    const unsigned long long lt = lanemask_lt();
+    const unsigned long long b0 = (unsigned long long)wave * rays_per_wave;
+    const unsigned long long b1 = b0 + rays_per_wave;
+    uint32_t next = (uint32_t)(b0 < n_rays ? b0 : n_rays);
+    const uint32_t end = (uint32_t)(b1 < n_rays ? b1 : n_rays);
+    next = __builtin_amdgcn_readfirstlane(next);
+    T o[R][3], inv[R][3];
+    uint32_t r[R], i[R], cnt[R], slot[R];
+    bool fin[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        r[j] = NONE; i[j] = n_trav; cnt[j] = 0; slot[j] = SLOT_NONE; fin[j] = true;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { o[j][k] = 0; inv[j][k] = 0; }
+    }
+    unsigned long long cpos = 0;
+    uint32_t cleft = 0;
+    unsigned long long steps = 0, leaf_steps = 0, wsteps = 0;
+    while (true) {
+        bool any_run = false;
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            bool run = i[j] < n_trav;
+            const unsigned long long idle = __ballot(!run);
+            if (idle) {
+                if (!run && r[j] != NONE) { counts[r[j]] = cnt[j]; r[j] = NONE; }
+                const uint32_t nidle = (uint32_t)__popcll(idle);
+                if (next < end && nidle >= refill_min) {
+                    const uint32_t mine = next + (uint32_t)__popcll(idle & lt);
+                    if (!run && mine < end) {
+                        r[j] = mine;
+                        const typename Traits<T>::Ray* rp = rays + mine;
+#pragma unroll
+                        for (int k = 0; k < 3; k++) { o[j][k] = rp->o[k]; inv[j][k] = rp->inv[k]; }
+                        i[j] = 0; cnt[j] = 0; slot[j] = first_slot; run = true;
+                        fin[j] = ray_is_finite<T>(o[j], inv[j]);
+                    }
+                    next = (end - next) < nidle ? end : next + nidle;
+                }
+            }
+            any_run |= run;
+        }
+        if (!__any(any_run)) break;
+        NodeRegs<T> nd[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            if (i[j] < n_trav) {
+                if (slot[j] < K) nd[j] = top.load(slot[j]);
+                else nd[j] = load_node(nodes + i[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            bool rec = false;
+            uint32_t shape = NONE;
+            T t0 = 0, t1 = 0;
+            if (STATS) wsteps++;
+            const bool fast = !WITH_T && !__any(i[j] < n_trav && !fin[j]);   // wave-uniform
+            if (i[j] < n_trav) {
+                const bool hit = fast ? slab_hit_finite<T>(o[j], inv[j], nd[j].mn, nd[j].mx)
+                                      : slab_hit<T>(o[j], inv[j], nd[j].mn, nd[j].mx, t0, t1);
+                shape = nd[j].shape;
+                const bool leaf = trav_is_leaf(shape);
+                rec = hit && leaf;
+                const bool descend = hit && !leaf;
+                i[j] = descend ? i[j] + 1 : nd[j].exit;   // a leaf's exit IS i+1
+                const uint32_t child = slot[j] < 0x8000u ? 2u * slot[j] : SLOT_NONE;
+                slot[j] = descend ? child : (leaf ? SLOT_NONE : (shape & 0xFFFFu));
+                if (STATS) { steps++; leaf_steps += leaf ? 1 : 0; }
+            }
+            const unsigned long long m = __ballot(rec);
+            if (m) {
+                const uint32_t h = (uint32_t)__popcll(m);
+                if (h > cleft) {
+                    if ((uint32_t)lane < cleft && cpos + lane < pool_cap) pool[cpos + lane].ray = NONE;
+                    unsigned int blo = 0, bhi = 0;
+                    if (lane == 0) {
+                        unsigned long long b = atomicAdd(&ctr[0], (unsigned long long)POOL_CHUNK);
+                        blo = (unsigned int)b; bhi = (unsigned int)(b >> 32);
+                    }
+                    blo = __builtin_amdgcn_readfirstlane(blo); bhi = __builtin_amdgcn_readfirstlane(bhi);
+                    cpos = ((unsigned long long)bhi << 32) | blo;
+                    cleft = POOL_CHUNK;
+                }
+                if (rec) {
+                    const unsigned long long pslot = cpos + __popcll(m & lt);
+                    if (pslot < pool_cap) {
+                        HitRec hr; hr.ray = r[j]; hr.k = cnt[j]; hr.shape = shape;
+                        pool[pslot] = hr;
+                        if (WITH_T) { pool_t[2 * pslot] = t0; pool_t[2 * pslot + 1] = t1; }
+                    }
+                    cnt[j]++;
+                }
+                cpos += h; cleft -= h;
+            }
+        }
+    }
+    if ((uint32_t)lane < cleft && cpos + lane < pool_cap) pool[cpos + lane].ray = NONE;
+    if (STATS) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            steps += __shfl_down(steps, d);
+            leaf_steps += __shfl_down(leaf_steps, d);
+        }
+        if (lane == 0) { atomicAdd(&ctr[1], steps); atomicAdd(&ctr[2], leaf_steps); atomicAdd(&ctr[4], wsteps); }
     }
 }
 
@@ -183,6 +470,7 @@ __global__ __launch_bounds__(256) void k_hits_scatter(const HitRec* __restrict__
     for (unsigned long long j = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; j < n;
          j += (unsigned long long)gridDim.x * blockDim.x) {
         const HitRec h = pool[j];
+        if (h.ray == NONE) continue;   // unused tail of a per-wave chunk
         const uint32_t d = offsets[h.ray] + h.k;
         indices[d] = h.shape;
         if (WITH_T) { tslice[2 * (size_t)d] = pool_t[2 * j]; tslice[2 * (size_t)d + 1] = pool_t[2 * j + 1]; }
@@ -198,7 +486,7 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
     const bool with_t = (flags & BVHGPU_TRAVERSE_T_SLICE) != 0;
     const bool stats = (flags & BVHGPU_TRAVERSE_STATS) != 0;
     h->ctx = ctx; h->dtype = Traits<T>::dtype; h->n_rays = n_rays; h->flags = flags; h->total = 0;
-    h->stats = bvhgpu_traverse_stats{0, 0, 0, 0};
+    h->stats = bvhgpu_traverse_stats{0, 0, 0, 0, 0};
     h->counts.reserve((n_rays + 1) * 4);
     h->offsets.reserve((n_rays + 1) * 4);
     h->ctr.reserve(8 * sizeof(unsigned long long));
@@ -229,9 +517,40 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
         T* pool_t = h->pool_t.as<T>();
         const unsigned long long cap = h->pool_cap;
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
-#define LAUNCH_TRAV(WT, STT) \
-    hipLaunchKernelGGL((k_traverse<T, WT, STT>), grid, block, 0, st, nodes, n_trav, rays_dev, (uint32_t)n_rays, counts, \
-                       pool, pool_t, cap, ctr)
+// launch geometry.  variant 0: one ray per lane per launch; 1: persistent waves with ray refill;
+        // 2: persistent + LDS-resident top of the tree (one 1024-thread workgroup per CU)
+        int variant = ctx->tune[BVHGPU_TUNE_TRAVERSE_VARIANT];
+        if (variant == 2 && (t->slot_entry.p == nullptr || n_rays < (size_t)ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS]))
+            variant = 0;
+        const bool persist = variant != 0;
+        const size_t full = (n_rays + WAVE - 1) / WAVE;
+        const uint32_t wpc = variant == 2 ? LDS_THREADS / WAVE : (uint32_t)std::max(1, ctx->tune[BVHGPU_TUNE_TRAVERSE_WAVES_PER_CU]);
+        const uint32_t n_waves = (uint32_t)std::min<size_t>(full, (size_t)ctx->n_cu * wpc);
+        const uint32_t rpw = (uint32_t)((n_rays + n_waves - 1) / n_waves);
+        const uint32_t refill_min = (uint32_t)std::min(64, std::max(1, ctx->tune[BVHGPU_TUNE_TRAVERSE_REFILL_MIN]));
+        const dim3 pgrid((n_waves + 3) / 4);
+        const dim3 lgrid((n_waves + LDS_THREADS / WAVE - 1) / (LDS_THREADS / WAVE));
+        const uint32_t first_slot = t->n >= 2 ? 2u : SLOT_NONE;   // entry 0 is the root's left child (heap number 2)
+        const uint32_t* slot_entry = t->slot_entry.as<uint32_t>();
+        const int rpl = ctx->tune[BVHGPU_TUNE_TRAVERSE_RAYS_PER_LANE];
+#define LAUNCH_TRAV(WT, STT)                                                                                               \
+    do {                                                                                                                   \
+        if (variant == 2 && rpl >= 4)                                                                                      \
+            hipLaunchKernelGGL((k_traverse_lds<T, WT, STT, 4>), lgrid, dim3(LDS_THREADS), 0, st, nodes, n_trav, slot_entry,\
+                               first_slot, rays_dev, (uint32_t)n_rays, rpw, refill_min, counts, pool, pool_t, cap, ctr);   \
+        else if (variant == 2 && rpl >= 2)                                                                                 \
+            hipLaunchKernelGGL((k_traverse_lds<T, WT, STT, 2>), lgrid, dim3(LDS_THREADS), 0, st, nodes, n_trav, slot_entry,\
+                               first_slot, rays_dev, (uint32_t)n_rays, rpw, refill_min, counts, pool, pool_t, cap, ctr);   \
+        else if (variant == 2)                                                                                             \
+            hipLaunchKernelGGL((k_traverse_lds<T, WT, STT, 1>), lgrid, dim3(LDS_THREADS), 0, st, nodes, n_trav, slot_entry,\
+                               first_slot, rays_dev, (uint32_t)n_rays, rpw, refill_min, counts, pool, pool_t, cap, ctr);   \
+        else if (variant == 1)                                                                                             \
+            hipLaunchKernelGGL((k_traverse_persist<T, WT, STT>), pgrid, block, 0, st, nodes, n_trav, rays_dev,             \
+                               (uint32_t)n_rays, rpw, refill_min, counts, pool, pool_t, cap, ctr);                         \
+        else                                                                                                               \
+            hipLaunchKernelGGL((k_traverse<T, WT, STT>), grid, block, 0, st, nodes, n_trav, rays_dev, (uint32_t)n_rays,    \
+                               counts, pool, pool_t, cap, ctr);                                                            \
+    } while (0)
         if (with_t) { if (stats) LAUNCH_TRAV(true, true); else LAUNCH_TRAV(true, false); }
         else { if (stats) LAUNCH_TRAV(false, true); else LAUNCH_TRAV(false, false); }
 #undef LAUNCH_TRAV
@@ -252,17 +571,19 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
         BVH_HIP(hipMemcpyAsync(pin, ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         BVH_HIP(hipStreamSynchronize(st));
         BVH_HIP(hipGetLastError());
-        const unsigned long long total = pin[0];
-        if (total != pin[3]) throw HipFail{hipErrorUnknown, "hit pool / count scan mismatch", __LINE__};
+        const unsigned long long used = pin[0];   // pool slots taken (persistent variant: whole chunks)
+        const unsigned long long total = pin[3];  // sum of the per-ray counts = number of hits
+        if (used < total || (!persist && used != total)) throw HipFail{hipErrorUnknown, "hit pool / count scan mismatch", __LINE__};
         if (total > 0xFFFFFFFFull) throw HipFail{hipErrorInvalidValue, "OVERFLOW", __LINE__};
-        if (total > cap) {  // pool too small: grow to the exact need and replay (deterministic)
-            h->pool_cap = (size_t)total + (size_t)total / 8 + 1024;
+        if (used > cap) {  // pool too small: grow to the need (deterministic: same chunks on replay) and replay
+            h->pool_cap = (size_t)used + (size_t)used / 8 + 1024;
             continue;
         }
         h->total = total;
         h->stats.hits = total;
         if (stats) {
             h->stats.device_steps = pin[1];
+            h->stats.wave_steps = pin[4];
             // reference-equivalent loop iterations (flat_bvh.rs:408): in the folded layout every
             // reported leaf stands for a navigator visit plus a leaf-entry visit
             const bool one_to_one = t->unfolded || t->n == 1;

@@ -83,6 +83,7 @@ typedef struct {
     uint64_t visited;     /* reference loop iterations (flat_bvh.rs:408) = slab tests; STATS flag   */
     uint64_t leaf_visits; /* of which leaf entries (second test of a shape AABB, :411-418); STATS   */
     uint64_t device_steps;/* node visits this engine actually performed (folded layout); STATS      */
+    uint64_t wave_steps;  /* wavefront iterations of the walk loop: device_steps / (64 * wave_steps) = lane utilisation */
 } bvhgpu_traverse_stats;
 
 /* ---- context ---- */
@@ -168,6 +169,19 @@ void bvhgpu_hits_destroy(bvhgpu_hits *hits);
 typedef struct { float build_ms, flatten_ms, traverse_kernel_ms, traverse_total_ms; } bvhgpu_timings;
 int bvhgpu_enable_timing(bvhgpu_ctx *ctx, int on);
 int bvhgpu_last_timings(bvhgpu_ctx *ctx, bvhgpu_timings *out);
+
+/* ---- tuning knobs (performance only; results never change).  Not part of the reference surface. ---- */
+typedef enum {
+    BVHGPU_TUNE_TRAVERSE_VARIANT = 0,      /* 0 one ray per lane per launch; 1 persistent waves with ray refill;
+                                              2 (default) persistent + top of the tree resident in LDS */
+    BVHGPU_TUNE_TRAVERSE_WAVES_PER_CU = 1, /* variant 1: resident waves per CU (default 32) */
+    BVHGPU_TUNE_TRAVERSE_REFILL_MIN = 2,   /* variants 1, 2: refill once this many lanes are idle (default 1) */
+    BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS = 3, /* variant 2 is used for batches of at least this many rays (default 16384) */
+    BVHGPU_TUNE_TRAVERSE_RAYS_PER_LANE = 4,/* variant 2: independent walks per lane (1, 2 or 4; default 4) */
+    BVHGPU_TUNE_COUNT = 8
+} bvhgpu_tune;
+int bvhgpu_set_tuning(bvhgpu_ctx *ctx, int knob, int value);
+int bvhgpu_get_tuning(const bvhgpu_ctx *ctx, int knob, int *value);
 
 #ifdef __cplusplus
 }
