@@ -163,7 +163,7 @@ def main():
     kern_s = phases["traverse_kernel_ms"] * 1e-3
     achieved = algo_bytes / kern_s / 1e9
     roofline = {
-        "kernel": "k_traverse", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "kernel": "k_traverse_lds", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.pmc_traffic,
         "algorithmic_bytes_per_launch": int(algo_bytes), "kernel_ms": round(phases["traverse_kernel_ms"], 4),
         "slab_tests_per_s": round(V / kern_s, 1), "visited": int(V), "leaf_visits": int(VL), "hits": int(H),

@@ -91,6 +91,7 @@ SYMBOLS = [
     ("bvhgpu_get_tuning", _i, [_vp, _i, C.POINTER(_i)]),
 ]
 TUNE_TRAVERSE_VARIANT, TUNE_TRAVERSE_WAVES_PER_CU, TUNE_TRAVERSE_REFILL_MIN = 0, 1, 2
+TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_TRAVERSE_LDS_SLOTS, TUNE_TRAVERSE_LDS_THREADS = 3, 4, 5
 
 _lib = None
 

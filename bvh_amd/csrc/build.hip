@@ -51,6 +51,9 @@ template <typename T> struct BuildArgs {
     uint32_t* node_start;
     uint32_t* node_count;
     uint32_t* shape_node;
+    uint16_t* node_slot;     // heap number of every node (SLOT_NONE beyond the first 15 levels): traversal's LDS slots
+    uint32_t* slot_entry;    // cleared here, filled by flatten
+    uint32_t n_slots;
     uint32_t* idx[2];
     uint8_t* bk;
     Item<T>* big[2];
@@ -126,7 +129,7 @@ template <typename T> __device__ void init_stats(ItemStats<T>* s, int lane) {
 // enqueue one child / root work item (whole wave participates; lane 0 owns the atomics)
 template <typename T>
 __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, uint32_t parent, uint32_t start,
-                          uint32_t count, const T* A, const T* C, int lane) {
+                          uint32_t count, const T* A, const T* C, uint32_t heap, int lane) {
     const int nslot = lvl_slot(next_level);
     const int npar = next_level & 1;
     uint32_t slot = 0, tb = 0;
@@ -146,7 +149,7 @@ __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, ui
     Item<T>* it = is_small ? &a.small[slot] : (is_mid ? &a.mid[slot] : &a.big[npar][slot]);
     if (lane == 0) {
         it->ni = ni; it->parent = parent; it->start = start; it->count = count;
-        it->tile_base = tb; it->parity = (uint32_t)npar; it->_r0 = 0; it->_r1 = 0;
+        it->tile_base = tb; it->parity = (uint32_t)npar; it->heap = heap; it->_r1 = 0;
     }
     if (lane < 6) { it->A[lane] = A[lane]; it->C[lane] = C[lane]; }
     if (!is_small && !is_mid) {
@@ -159,6 +162,7 @@ __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, ui
 template <typename T> __global__ __launch_bounds__(256) void k_init(BuildArgs<T> a) {
     using Tr = Traits<T>;
     for (int i = threadIdx.x; i < (int)(ROOTKEY_OFF / 4); i += 256) a.ctr[i] = 0;
+    for (uint32_t i = threadIdx.x; i < a.n_slots; i += 256) a.slot_entry[i] = NONE;
     if (threadIdx.x < STAT_KEYS) a.rootkeys[threadIdx.x] = key_is_min(threadIdx.x) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
 }
 
@@ -172,7 +176,7 @@ template <typename T> __global__ __launch_bounds__(64) void k_root(BuildArgs<T> 
         A[k] = Tr::unkey(a.rootkeys[k]);
         C[k] = Tr::unkey(a.rootkeys[6 + k]);
     }
-    push_item<T>(a, 0, 0u, 0u, 0u, a.n, A, C, lane);
+    push_item<T>(a, 0, 0u, 0u, 0u, a.n, A, C, 1u, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -398,9 +402,10 @@ template <typename T> __global__ __launch_bounds__(256) void k_select(BuildArgs<
             nd->parent = parent; nd->l = li; nd->r = ri; nd->shape = NONE;
             a.node_start[ni] = start;
             a.node_count[ni] = count;
+            a.node_slot[ni] = (uint16_t)it->heap;
         }
-        push_item<T>(a, level + 1, li, ni, start, nl, AL, CL, lane);
-        push_item<T>(a, level + 1, ri, ni, start + nl, count - nl, AR, CR, lane);
+        push_item<T>(a, level + 1, li, ni, start, nl, AL, CL, heap_child(it->heap, 0u), lane);
+        push_item<T>(a, level + 1, ri, ni, start + nl, count - nl, AR, CR, heap_child(it->heap, 1u), lane);
 
         // per-tile exclusive offsets for the stable scatter: dest = start + tile_cnt[t][b] + rank
         uint32_t base[NUM_BUCKETS];
@@ -497,6 +502,7 @@ template <typename T> struct MidSub {
     uint32_t ax, degen, half, nl;
     uint32_t base[NUM_BUCKETS + 1];     // exclusive bucket offsets inside the sub-node; base[6] = count
     uint32_t child[2];                  // next-level sub-node ids, NONE if the child left the workgroup
+    uint32_t heap, _pad;                // heap number of the sub-node (common.hpp heap_child)
     unsigned long long scan0_lo, scanE_lo;  // packed counters before the first / after the last position
     uint32_t scan0_hi, scanE_hi;
 };
@@ -569,7 +575,7 @@ template <typename T> __global__ __launch_bounds__(MID_THREADS) void k_mid(Build
         }
         if (tid == 0) {
             MidSub<T>* m = &s_sub[0][0];
-            m->start = 0; m->count = count; m->ni = it->ni; m->parent = it->parent;
+            m->start = 0; m->count = count; m->ni = it->ni; m->parent = it->parent; m->heap = it->heap;
             for (int k = 0; k < 6; k++) { m->A[k] = it->A[k]; m->C[k] = it->C[k]; }
             midsub_derive(m);
             s_nsub = 1;
@@ -773,6 +779,7 @@ template <typename T> __global__ __launch_bounds__(MID_THREADS) void k_mid(Build
                     nd->parent = m->parent; nd->l = li; nd->r = ri; nd->shape = NONE;
                     a.node_start[ni] = istart + m->start;
                     a.node_count[ni] = m->count;
+                    a.node_slot[ni] = (uint16_t)m->heap;
                     m->nl = nl;
                 }
                 const bool subL = has && cl > (uint32_t)SMALL_MAX, subR = has && cr > (uint32_t)SMALL_MAX;
@@ -801,13 +808,14 @@ template <typename T> __global__ __launch_bounds__(MID_THREADS) void k_mid(Build
                         if (is_sub) {
                             MidSub<T>* c = &s_sub[cur ^ 1][side ? idR : idL];
                             c->start = cstart; c->count = ccount; c->ni = cni; c->parent = ni;
+                            c->heap = heap_child(m->heap, (uint32_t)side);
 #pragma unroll
                             for (int k = 0; k < 6; k++) { c->A[k] = CA[k]; c->C[k] = CC[k]; }
                             midsub_derive(c);
                         } else {
                             Item<T>* g = &a.small[side ? slR : slL];
                             g->ni = cni; g->parent = ni; g->start = istart + cstart; g->count = ccount;
-                            g->tile_base = 0; g->parity = out_parity; g->_r0 = 0; g->_r1 = 0;
+                            g->tile_base = 0; g->parity = out_parity; g->heap = heap_child(m->heap, (uint32_t)side); g->_r1 = 0;
 #pragma unroll
                             for (int k = 0; k < 6; k++) { g->A[k] = CA[k]; g->C[k] = CC[k]; }
                         }
@@ -877,7 +885,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
     }
     // per-lane copy of the segment (= BvhNodeBuildArgs) the lane currently belongs to
     int lo = done ? lane : 0, hi = done ? lane + 1 : n;
-    uint32_t ni = it->ni, parent = it->parent;
+    uint32_t ni = it->ni, parent = it->parent, heap = it->heap;
     T Cb[6], A0[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) { Cb[k] = it->C[k]; A0[k] = it->A[k]; }
@@ -891,6 +899,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
             for (int k = 0; k < 3; k++) { nd->l_min[k] = 0; nd->l_max[k] = 0; nd->r_min[k] = 0; nd->r_max[k] = 0; }
             nd->parent = parent; nd->l = NONE; nd->r = NONE; nd->shape = shape;
             a.shape_node[shape] = ni;       // set_bh_node_index (:102)
+            a.node_slot[ni] = (uint16_t)heap;
             a.node_start[ni] = istart + lane;
             a.node_count[ni] = 1;
             done = true;
@@ -995,10 +1004,11 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
                 nd->parent = parent; nd->l = li; nd->r = ri; nd->shape = NONE;
                 a.node_start[ni] = istart + lo;
                 a.node_count[ni] = segn;
+                a.node_slot[ni] = (uint16_t)heap;
             }
             parent = ni;
-            if (left) { hi = q; ni = li; saA = surface_area(AL); }
-            else { lo = q; ni = ri; saA = surface_area(AR); }
+            if (left) { hi = q; ni = li; saA = surface_area(AL); heap = heap_child(heap, 0u); }
+            else { lo = q; ni = ri; saA = surface_area(AR); heap = heap_child(heap, 1u); }
 #pragma unroll
             for (int k = 0; k < 6; k++) Cb[k] = Cn[k];
         }
@@ -1030,6 +1040,8 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     t->node_start.reserve(t->n_nodes * 4);
     t->node_count.reserve(t->n_nodes * 4);
     t->shape_node.reserve(n * 4);
+    t->node_slot.reserve(t->n_nodes * 2);
+    t->slot_entry.reserve(TopCfg<T>::SLOTS * 4);
     t->idx[0].reserve(n * 4);
     t->idx[1].reserve(n * 4);
     t->bk.reserve(n);
@@ -1052,6 +1064,9 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     a.node_start = t->node_start.as<uint32_t>();
     a.node_count = t->node_count.as<uint32_t>();
     a.shape_node = t->shape_node.as<uint32_t>();
+    a.node_slot = t->node_slot.as<uint16_t>();
+    a.slot_entry = t->slot_entry.as<uint32_t>();
+    a.n_slots = TopCfg<T>::SLOTS;
     a.idx[0] = t->idx[0].as<uint32_t>(); a.idx[1] = t->idx[1].as<uint32_t>();
     a.bk = t->bk.as<uint8_t>();
     a.big[0] = t->big[0].as<Item<T>>(); a.big[1] = t->big[1].as<Item<T>>();

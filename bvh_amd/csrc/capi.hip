@@ -398,9 +398,10 @@ int bvhgpu_tree_from_flat_f64(bvhgpu_ctx* ctx, const bvhgpu_flat_f64* flat, size
     return tree_from_flat<double>(ctx, flat, n_flat, shape_aabbs, n, out);
 }
 
-// ---- scene blob: header | traversal array | shape AABBs ----
-struct SceneHeader { uint32_t magic, dtype; uint64_t n, n_trav; uint32_t unfolded, _pad; uint64_t trav_bytes, aabb_bytes; };
-static constexpr uint32_t SCENE_MAGIC = 0x42564833u;  // "BVH3"
+// ---- scene blob: header | traversal array | shape AABBs | top-of-tree slot table ----
+struct SceneHeader { uint32_t magic, dtype; uint64_t n, n_trav; uint32_t unfolded, _pad; uint64_t trav_bytes, aabb_bytes, slot_bytes; };
+static constexpr uint32_t SCENE_MAGIC = 0x42564834u;  // "BVH4"
+static size_t slot_table_bytes(int dtype) { return (dtype == BVHGPU_F32 ? TopCfg<float>::SLOTS : TopCfg<double>::SLOTS) * 4; }
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 int bvhgpu_scene_nbytes(const bvhgpu_tree* t, size_t* nbytes) {
@@ -408,7 +409,7 @@ int bvhgpu_scene_nbytes(const bvhgpu_tree* t, size_t* nbytes) {
     if (!t->flattened) return BVHGPU_NOT_FLATTENED;
     size_t tsz = t->dtype == BVHGPU_F32 ? sizeof(TravNode<float>) : sizeof(TravNode<double>);
     size_t ssz = t->dtype == BVHGPU_F32 ? 4 : 8;
-    *nbytes = 256 + align256(t->n_trav * tsz) + align256(t->n * 6 * ssz);
+    *nbytes = 256 + align256(t->n_trav * tsz) + align256(t->n * 6 * ssz) + align256(t->slot_entry.p ? slot_table_bytes(t->dtype) : 0);
     return BVHGPU_OK;
 }
 
@@ -425,11 +426,13 @@ int bvhgpu_scene_export(bvhgpu_tree* t, void* dst, int mem) {
         h->magic = SCENE_MAGIC; h->dtype = (uint32_t)t->dtype; h->n = t->n; h->n_trav = t->n_trav;
         h->unfolded = t->unfolded ? 1u : 0u;
         h->trav_bytes = t->n_trav * tsz; h->aabb_bytes = t->n * 6 * ssz;
+        h->slot_bytes = t->slot_entry.p ? slot_table_bytes(t->dtype) : 0;
         char* d = static_cast<char*>(dst);
         const hipMemcpyKind kd = mem == BVHGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
         BVH_HIP(hipMemcpyAsync(d, h, 256, mem == BVHGPU_DEVICE ? hipMemcpyHostToDevice : hipMemcpyHostToHost, ctx->stream));
         if (h->trav_bytes) BVH_HIP(hipMemcpyAsync(d + 256, t->trav.p, h->trav_bytes, kd, ctx->stream));
         if (h->aabb_bytes) BVH_HIP(hipMemcpyAsync(d + 256 + align256(h->trav_bytes), t->aabbs.p, h->aabb_bytes, kd, ctx->stream));
+        if (h->slot_bytes) BVH_HIP(hipMemcpyAsync(d + 256 + align256(h->trav_bytes) + align256(h->aabb_bytes), t->slot_entry.p, h->slot_bytes, kd, ctx->stream));
         BVH_HIP(hipStreamSynchronize(ctx->stream));  // the pinned header page is reused by the next call
         return (int)BVHGPU_OK;
     });
@@ -450,15 +453,18 @@ int bvhgpu_scene_import(bvhgpu_ctx* ctx, const void* src, size_t nbytes, int mem
         BVH_HIP(hipMemcpyAsync(h, s, 256, mem == BVHGPU_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, ctx->stream));
         BVH_HIP(hipStreamSynchronize(ctx->stream));
         if (h->magic != SCENE_MAGIC || h->dtype > 1) return fail(ctx, BVHGPU_INVALID_ARG, "not a bvhgpu scene blob");
-        if (256 + align256(h->trav_bytes) + align256(h->aabb_bytes) > nbytes) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob truncated");
+        if (256 + align256(h->trav_bytes) + align256(h->aabb_bytes) + align256(h->slot_bytes) > nbytes) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob truncated");
+        if (h->slot_bytes && h->slot_bytes != slot_table_bytes((int)h->dtype)) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob slot table size");
         t->dtype = (int)h->dtype; t->n = h->n; t->n_trav = h->n_trav; t->n_nodes = 0; t->n_flat = 0;
         t->unfolded = h->unfolded != 0;
-        const size_t tb = h->trav_bytes, ab = h->aabb_bytes;
+        const size_t tb = h->trav_bytes, ab = h->aabb_bytes, sb = h->slot_bytes;
         t->trav.reserve(tb + 16);
         t->aabbs.reserve(ab + 16);
         const hipMemcpyKind kd = mem == BVHGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
         if (tb) BVH_HIP(hipMemcpyAsync(t->trav.p, s + 256, tb, kd, ctx->stream));
         if (ab) BVH_HIP(hipMemcpyAsync(t->aabbs.p, s + 256 + align256(tb), ab, kd, ctx->stream));
+        if (sb) { t->slot_entry.reserve(sb); BVH_HIP(hipMemcpyAsync(t->slot_entry.p, s + 256 + align256(tb) + align256(ab), sb, kd, ctx->stream)); }
+        else t->slot_entry.release();
         if (mem != BVHGPU_DEVICE) BVH_HIP(hipStreamSynchronize(ctx->stream));
         t->built = false; t->flattened = true;
         return (int)BVHGPU_OK;

@@ -102,9 +102,16 @@ template <> struct __attribute__((aligned(64))) TravNode<double> {
 constexpr uint32_t TRAV_INNER = 0x80000000u;
 constexpr uint32_t SLOT_NONE = 0xFFFFu;
 __host__ __device__ inline bool trav_is_leaf(uint32_t w) { return (w & TRAV_INNER) == 0u; }
+__host__ __device__ inline uint32_t heap_child(uint32_t h, uint32_t side) {  // saturating 2h + side
+    const uint32_t c = 2u * h + side;
+    return (h >= 0x8000u || c > SLOT_NONE) ? SLOT_NONE : c;
+}
 // top-of-tree slots = heap numbers (root 1, children 2h / 2h+1) below TopCfg<T>::SLOTS; what fits 160 KB of LDS
 template <typename T> struct TopCfg;
-template <> struct TopCfg<float> { static constexpr uint32_t SLOTS = 5056; };   // 2 x 16 B per slot
+#ifndef BVH_TOP_SLOTS_F32
+#define BVH_TOP_SLOTS_F32 5056
+#endif
+template <> struct TopCfg<float> { static constexpr uint32_t SLOTS = BVH_TOP_SLOTS_F32; };   // 2 x 16 B per slot
 template <> struct TopCfg<double> { static constexpr uint32_t SLOTS = 2880; };  // 56 B per slot
 static_assert(sizeof(TravNode<float>) == 32, "trav f32");
 static_assert(sizeof(TravNode<double>) == 64, "trav f64");
@@ -117,7 +124,8 @@ template <typename T> struct Item {
     uint32_t count;    // indices.len()
     uint32_t tile_base;
     uint32_t parity;   // which idx buffer holds its slice
-    uint32_t _r0, _r1;
+    uint32_t heap;     // heap number of the node (root 1, children 2h / 2h+1), saturated at SLOT_NONE
+    uint32_t _r1;
     T A[6];            // aabb_bounds
     T C[6];            // centroid_bounds
 };

@@ -31,38 +31,11 @@ template <> __device__ __forceinline__ void write_trav<double>(TravNode<double>*
     p[3] = make_double2(__longlong_as_double((long long)es), 0.0);
 }
 
-// Top-of-tree slots for the LDS-resident part of traversal: heap numbering (root 1, children 2h and 2h+1)
-// assigned by a breadth-first sweep of ONE workgroup over the first levels of the tree; slot h < SLOTS
-// holds the traversal entry of the node with heap number h.  Only ~SLOTS nodes are touched.
-template <typename T>
-__global__ __launch_bounds__(1024) void k_top_slots(const typename Traits<T>::Node* __restrict__ nodes, uint32_t n_nodes,
-                                                    uint32_t* __restrict__ slot_entry, uint16_t* __restrict__ node_slot) {
-    constexpr uint32_t K = TopCfg<T>::SLOTS;
-    __shared__ uint32_t s_node[K];
-    for (uint32_t h = threadIdx.x; h < K; h += blockDim.x) s_node[h] = NONE;
-    __syncthreads();
-    if (threadIdx.x == 0 && n_nodes > 1) s_node[1] = 0;
-    __syncthreads();
-    for (uint32_t lo = 1; lo < K; lo <<= 1) {   // heap numbers [lo, 2lo) form one level
-        for (uint32_t h = lo + threadIdx.x; h < 2 * lo && h < K; h += blockDim.x) {
-            const uint32_t ni = s_node[h];
-            if (ni == NONE) continue;
-            if (h > 1) { slot_entry[h] = ni - 1; node_slot[ni] = (uint16_t)h; }   // entry of tree node ni is trav[ni-1]
-            const typename Traits<T>::Node* nd = nodes + ni;
-            if (nd->shape == NONE) {
-                if (2 * h < K) s_node[2 * h] = nd->l;
-                if (2 * h + 1 < K) s_node[2 * h + 1] = nd->r;
-            }
-        }
-        __syncthreads();
-    }
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node* __restrict__ nodes,
                                                  const uint32_t* __restrict__ node_start,
                                                  const uint32_t* __restrict__ node_count, const T* __restrict__ aabbs,
-                                                 const uint16_t* __restrict__ node_slot,
+                                                 const uint16_t* __restrict__ node_slot, uint32_t* __restrict__ slot_entry,
                                                  typename Traits<T>::Flat* __restrict__ flat, TravNode<T>* __restrict__ trav,
                                                  uint32_t n_nodes) {
     using Tr = Traits<T>;
@@ -90,6 +63,10 @@ __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node*
         mx[k] = is_left ? pn.l_max[k] : pn.r_max[k];
     }
     const uint32_t L = node_start[i], kcnt = node_count[i];
+    // the builder numbered the nodes heap-style (root 1, children 2h / 2h+1): the first TopCfg<T>::SLOTS of
+    // them are the top of the tree that traversal keeps in LDS; slot h holds traversal entry i-1
+    const uint32_t myslot = node_slot[i];
+    if (myslot < TopCfg<T>::SLOTS) slot_entry[myslot] = i - 1;
     const uint32_t nav = i - 1 + L;
     typename Tr::Flat f = {};
 #pragma unroll
@@ -122,17 +99,12 @@ template <typename T> void flatten_tree(bvhgpu_tree* t) {
     if (t->n == 0) { t->flattened = true; return; }
     t->flat.reserve(t->n_flat * sizeof(typename Tr::Flat));
     t->trav.reserve(t->n_trav * sizeof(TravNode<T>));
-    t->slot_entry.reserve(TopCfg<T>::SLOTS * 4);
-    t->node_slot.reserve(t->n_nodes * 2);
     const uint32_t nn = (uint32_t)t->n_nodes;
     hipStream_t st = t->ctx->stream;
-    BVH_HIP(hipMemsetAsync(t->slot_entry.p, 0xFF, TopCfg<T>::SLOTS * 4, st));
-    BVH_HIP(hipMemsetAsync(t->node_slot.p, 0xFF, t->n_nodes * 2, st));
-    hipLaunchKernelGGL(k_top_slots<T>, dim3(1), dim3(1024), 0, st, t->nodes.as<typename Tr::Node>(), nn,
-                       t->slot_entry.as<uint32_t>(), t->node_slot.as<uint16_t>());
     hipLaunchKernelGGL(k_flatten<T>, dim3((nn + 255) / 256), dim3(256), 0, st,
                        t->nodes.as<typename Tr::Node>(), t->node_start.as<uint32_t>(), t->node_count.as<uint32_t>(),
-                       t->aabbs.as<T>(), t->node_slot.as<uint16_t>(), t->flat.as<typename Tr::Flat>(),
+                       t->aabbs.as<T>(), t->node_slot.as<uint16_t>(), t->slot_entry.as<uint32_t>(),
+                       t->flat.as<typename Tr::Flat>(),
                        t->trav.as<TravNode<T>>(), nn);
     BVH_HIP(hipGetLastError());
     t->flattened = true;

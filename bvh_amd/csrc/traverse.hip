@@ -221,10 +221,14 @@ __global__ __launch_bounds__(256) void k_traverse_persist(const TravNode<T>* __r
 // outside the resident set (deep in the tree, or after a leaf) reads HBM/L2 as before and re-enters
 // the resident set through the same word.  Waves are persistent with ray refill as above.
 // ------------------------------------------------------------------------------------------------
+// LDS image of the resident entries: 16-byte planes of K slots each (K is a launch parameter)
 template <typename T> struct TopLds;
 template <> struct TopLds<float> {
-    static constexpr uint32_t K = TopCfg<float>::SLOTS;
-    float4 lo[K], hi[K];
+    static constexpr uint32_t BYTES_PER_SLOT = 32;
+    float4 *lo, *hi;
+    __device__ __forceinline__ TopLds(unsigned char* base, uint32_t K) {
+        lo = reinterpret_cast<float4*>(base); hi = lo + K;
+    }
     __device__ __forceinline__ void store(uint32_t q, const TravNode<float>* g) {
         const float4* p = reinterpret_cast<const float4*>(g);
         lo[q] = p[0]; hi[q] = p[1];
@@ -238,9 +242,12 @@ template <> struct TopLds<float> {
     }
 };
 template <> struct TopLds<double> {
-    static constexpr uint32_t K = TopCfg<double>::SLOTS;
-    double2 a[K], b[K], c[K];
-    uint2 d[K];
+    static constexpr uint32_t BYTES_PER_SLOT = 56;
+    double2 *a, *b, *c;
+    uint2* d;
+    __device__ __forceinline__ TopLds(unsigned char* base, uint32_t K) {
+        a = reinterpret_cast<double2*>(base); b = a + K; c = b + K; d = reinterpret_cast<uint2*>(c + K);
+    }
     __device__ __forceinline__ void store(uint32_t q, const TravNode<double>* g) {
         const double2* p = reinterpret_cast<const double2*>(g);
         a[q] = p[0]; b[q] = p[1]; c[q] = p[2];
@@ -259,97 +266,87 @@ template <> struct TopLds<double> {
 };
 
 constexpr int LDS_THREADS = 1024;
+constexpr int LDS_INNER = 8;   // walk steps between two refill phases
 
-// R rays per lane: one wave-step issues the node fetches of R independent walks before it waits, so a
-// workgroup of 16 waves keeps 16*R fetches per SIMD-quad in flight (the walk is a dependent chain of
-// ~750 ns steps; with the top of the tree in LDS almost every step still has a few lanes deep in the
-// tree that read L2, and only memory-level parallelism hides that).
-template <typename T, bool WITH_T, bool STATS, int R>
+// The workgroup's 16 waves draw rays from ONE cursor in LDS (a wave-aggregated ds_add per refill phase),
+// so the tail of a launch is the tail of a workgroup's ray range, not of every wave's.  Retiring and
+// refilling lanes is kept OUT of the walk loop: LDS_INNER lean steps (~38 VALU each), then one refill
+// phase; a lane whose ray ends mid-way idles for at most LDS_INNER-1 steps.
+template <typename T, bool WITH_T, bool STATS>
 __global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>* __restrict__ nodes, uint32_t n_trav,
-                                                               const uint32_t* __restrict__ slot_entry, uint32_t first_slot,
+                                                               const uint32_t* __restrict__ slot_entry, uint32_t K,
+                                                               uint32_t first_slot,
                                                                const typename Traits<T>::Ray* __restrict__ rays,
-                                                               uint32_t n_rays, uint32_t rays_per_wave, uint32_t refill_min,
+                                                               uint32_t n_rays, uint32_t rays_per_wg,
                                                                uint32_t* __restrict__ counts, HitRec* __restrict__ pool,
                                                                T* __restrict__ pool_t, unsigned long long pool_cap,
                                                                unsigned long long* __restrict__ ctr) {
-    constexpr uint32_t K = TopLds<T>::K;
-    __shared__ TopLds<T> top;
-    for (uint32_t q = threadIdx.x; q < K; q += LDS_THREADS) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t& s_next = *reinterpret_cast<uint32_t*>(smem);
+    TopLds<T> top(smem + 16, K);
+    const unsigned long long g0 = (unsigned long long)blockIdx.x * rays_per_wg;
+    const unsigned long long g1 = g0 + rays_per_wg;
+    const uint32_t wg_begin = (uint32_t)(g0 < n_rays ? g0 : n_rays);
+    const uint32_t wg_end = (uint32_t)(g1 < n_rays ? g1 : n_rays);
+    if (threadIdx.x == 0) s_next = wg_begin;
+    for (uint32_t q = threadIdx.x; q < K; q += blockDim.x) {
         const uint32_t e = slot_entry[q];
         if (e != NONE) top.store(q, nodes + e);
     }
     __syncthreads();
 
-    const uint32_t wave = (blockIdx.x * LDS_THREADS + threadIdx.x) >> 6;
     const int lane = lane_id();
     const unsigned long long lt = lanemask_lt();
-    const unsigned long long b0 = (unsigned long long)wave * rays_per_wave;
-    const unsigned long long b1 = b0 + rays_per_wave;
-    uint32_t next = (uint32_t)(b0 < n_rays ? b0 : n_rays);
-    const uint32_t end = (uint32_t)(b1 < n_rays ? b1 : n_rays);
-    next = __builtin_amdgcn_readfirstlane(next);
-    T o[R][3], inv[R][3];
-    uint32_t r[R], i[R], cnt[R], slot[R];
-    bool fin[R];
-#pragma unroll
-    for (int j = 0; j < R; j++) {
-        r[j] = NONE; i[j] = n_trav; cnt[j] = 0; slot[j] = SLOT_NONE; fin[j] = true;
-#pragma unroll
-        for (int k = 0; k < 3; k++) { o[j][k] = 0; inv[j][k] = 0; }
-    }
+    T o[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
+    uint32_t r = NONE, i = n_trav, cnt = 0, slot = SLOT_NONE;
+    bool fin = true;
+    bool exhausted = wg_begin >= wg_end;   // wave-uniform: the workgroup's range has been handed out
     unsigned long long cpos = 0;
     uint32_t cleft = 0;
     unsigned long long steps = 0, leaf_steps = 0, wsteps = 0;
     while (true) {
-        bool any_run = false;
-#pragma unroll
-        for (int j = 0; j < R; j++) {
-            bool run = i[j] < n_trav;
-            const unsigned long long idle = __ballot(!run);
-            if (idle) {
-                if (!run && r[j] != NONE) { counts[r[j]] = cnt[j]; r[j] = NONE; }
+        // ---- refill phase
+        bool run = i < n_trav;
+        const unsigned long long idle = __ballot(!run);
+        if (idle) {
+            if (!run && r != NONE) { counts[r] = cnt; r = NONE; }
+            if (!exhausted) {
                 const uint32_t nidle = (uint32_t)__popcll(idle);
-                if (next < end && nidle >= refill_min) {
-                    const uint32_t mine = next + (uint32_t)__popcll(idle & lt);
-                    if (!run && mine < end) {
-                        r[j] = mine;
-                        const typename Traits<T>::Ray* rp = rays + mine;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_next, nidle);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const uint32_t mine = base + (uint32_t)__popcll(idle & lt);
+                if (!run && base < wg_end && mine < wg_end) {
+                    r = mine;
+                    const typename Traits<T>::Ray* rp = rays + mine;
 #pragma unroll
-                        for (int k = 0; k < 3; k++) { o[j][k] = rp->o[k]; inv[j][k] = rp->inv[k]; }
-                        i[j] = 0; cnt[j] = 0; slot[j] = first_slot; run = true;
-                        fin[j] = ray_is_finite<T>(o[j], inv[j]);
-                    }
-                    next = (end - next) < nidle ? end : next + nidle;
+                    for (int k = 0; k < 3; k++) { o[k] = rp->o[k]; inv[k] = rp->inv[k]; }
+                    i = 0; cnt = 0; slot = first_slot; run = true;
+                    fin = ray_is_finite<T>(o, inv);
                 }
+                exhausted = base >= wg_end || (wg_end - base) <= nidle;
             }
-            any_run |= run;
+            if (!__any(run)) break;
         }
-        if (!__any(any_run)) break;
-        NodeRegs<T> nd[R];
-#pragma unroll
-        for (int j = 0; j < R; j++) {
-            if (i[j] < n_trav) {
-                if (slot[j] < K) nd[j] = top.load(slot[j]);
-                else nd[j] = load_node(nodes + i[j]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < R; j++) {
+        const bool fast = !WITH_T && !__any(run && !fin);   // wave-uniform
+        // ---- LDS_INNER walk steps
+        for (int s = 0; s < LDS_INNER; s++) {
             bool rec = false;
             uint32_t shape = NONE;
             T t0 = 0, t1 = 0;
             if (STATS) wsteps++;
-            const bool fast = !WITH_T && !__any(i[j] < n_trav && !fin[j]);   // wave-uniform
-            if (i[j] < n_trav) {
-                const bool hit = fast ? slab_hit_finite<T>(o[j], inv[j], nd[j].mn, nd[j].mx)
-                                      : slab_hit<T>(o[j], inv[j], nd[j].mn, nd[j].mx, t0, t1);
-                shape = nd[j].shape;
+            if (i < n_trav) {
+                NodeRegs<T> nd;
+                if (slot < K) nd = top.load(slot);
+                else nd = load_node(nodes + i);
+                const bool hit = fast ? slab_hit_finite<T>(o, inv, nd.mn, nd.mx) : slab_hit<T>(o, inv, nd.mn, nd.mx, t0, t1);
+                shape = nd.shape;
                 const bool leaf = trav_is_leaf(shape);
                 rec = hit && leaf;
                 const bool descend = hit && !leaf;
-                i[j] = descend ? i[j] + 1 : nd[j].exit;   // a leaf's exit IS i+1
-                const uint32_t child = slot[j] < 0x8000u ? 2u * slot[j] : SLOT_NONE;
-                slot[j] = descend ? child : (leaf ? SLOT_NONE : (shape & 0xFFFFu));
+                i = descend ? i + 1 : nd.exit;   // a leaf's exit IS i+1
+                const uint32_t child = min(slot << 1, SLOT_NONE);
+                slot = descend ? child : (leaf ? SLOT_NONE : (shape & 0xFFFFu));
                 if (STATS) { steps++; leaf_steps += leaf ? 1 : 0; }
             }
             const unsigned long long m = __ballot(rec);
@@ -369,11 +366,11 @@ __global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>*
                 if (rec) {
                     const unsigned long long pslot = cpos + __popcll(m & lt);
                     if (pslot < pool_cap) {
-                        HitRec hr; hr.ray = r[j]; hr.k = cnt[j]; hr.shape = shape;
+                        HitRec hr; hr.ray = r; hr.k = cnt; hr.shape = shape;
                         pool[pslot] = hr;
                         if (WITH_T) { pool_t[2 * pslot] = t0; pool_t[2 * pslot + 1] = t1; }
                     }
-                    cnt[j]++;
+                    cnt++;
                 }
                 cpos += h; cleft -= h;
             }
@@ -524,26 +521,31 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
             variant = 0;
         const bool persist = variant != 0;
         const size_t full = (n_rays + WAVE - 1) / WAVE;
-        const uint32_t wpc = variant == 2 ? LDS_THREADS / WAVE : (uint32_t)std::max(1, ctx->tune[BVHGPU_TUNE_TRAVERSE_WAVES_PER_CU]);
+        // variant 2 geometry: workgroups of lds_threads that each keep K top-of-tree slots in LDS; as many
+        // workgroups per CU as 160 KB of LDS and 32 waves allow
+        const uint32_t lds_threads = (uint32_t)std::min(LDS_THREADS, std::max(64, ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_THREADS] & ~63));
+        const uint32_t K = (uint32_t)std::min<int>((int)TopCfg<T>::SLOTS, std::max(4, ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_SLOTS]));
+        const size_t lds_bytes = 16 + (size_t)K * TopLds<T>::BYTES_PER_SLOT;
+        const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds_bytes, 2048 / lds_threads));
+        const uint32_t wpc = variant == 2 ? wg_per_cu * lds_threads / WAVE
+                                          : (uint32_t)std::max(1, ctx->tune[BVHGPU_TUNE_TRAVERSE_WAVES_PER_CU]);
         const uint32_t n_waves = (uint32_t)std::min<size_t>(full, (size_t)ctx->n_cu * wpc);
         const uint32_t rpw = (uint32_t)((n_rays + n_waves - 1) / n_waves);
         const uint32_t refill_min = (uint32_t)std::min(64, std::max(1, ctx->tune[BVHGPU_TUNE_TRAVERSE_REFILL_MIN]));
         const dim3 pgrid((n_waves + 3) / 4);
-        const dim3 lgrid((n_waves + LDS_THREADS / WAVE - 1) / (LDS_THREADS / WAVE));
+        const dim3 lgrid((n_waves + lds_threads / WAVE - 1) / (lds_threads / WAVE));
         const uint32_t first_slot = t->n >= 2 ? 2u : SLOT_NONE;   // entry 0 is the root's left child (heap number 2)
         const uint32_t* slot_entry = t->slot_entry.as<uint32_t>();
-        const int rpl = ctx->tune[BVHGPU_TUNE_TRAVERSE_RAYS_PER_LANE];
+        const uint32_t rpg = (uint32_t)((n_rays + lgrid.x - 1) / lgrid.x);   // rays per workgroup (variant 2)
 #define LAUNCH_TRAV(WT, STT)                                                                                               \
     do {                                                                                                                   \
-        if (variant == 2 && rpl >= 4)                                                                                      \
-            hipLaunchKernelGGL((k_traverse_lds<T, WT, STT, 4>), lgrid, dim3(LDS_THREADS), 0, st, nodes, n_trav, slot_entry,\
-                               first_slot, rays_dev, (uint32_t)n_rays, rpw, refill_min, counts, pool, pool_t, cap, ctr);   \
-        else if (variant == 2 && rpl >= 2)                                                                                 \
-            hipLaunchKernelGGL((k_traverse_lds<T, WT, STT, 2>), lgrid, dim3(LDS_THREADS), 0, st, nodes, n_trav, slot_entry,\
-                               first_slot, rays_dev, (uint32_t)n_rays, rpw, refill_min, counts, pool, pool_t, cap, ctr);   \
-        else if (variant == 2)                                                                                             \
-            hipLaunchKernelGGL((k_traverse_lds<T, WT, STT, 1>), lgrid, dim3(LDS_THREADS), 0, st, nodes, n_trav, slot_entry,\
-                               first_slot, rays_dev, (uint32_t)n_rays, rpw, refill_min, counts, pool, pool_t, cap, ctr);   \
+        if (variant == 2)                                                                                                  \
+        {                                                                                                                  \
+            BVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse_lds<T, WT, STT>),                        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                      \
+            hipLaunchKernelGGL((k_traverse_lds<T, WT, STT>), lgrid, dim3(lds_threads), lds_bytes, st, nodes, n_trav,       \
+                               slot_entry, K, first_slot, rays_dev, (uint32_t)n_rays, rpg, counts, pool, pool_t, cap, ctr);\
+        }                                                                                                                  \
         else if (variant == 1)                                                                                             \
             hipLaunchKernelGGL((k_traverse_persist<T, WT, STT>), pgrid, block, 0, st, nodes, n_trav, rays_dev,             \
                                (uint32_t)n_rays, rpw, refill_min, counts, pool, pool_t, cap, ctr);                         \

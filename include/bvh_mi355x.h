@@ -177,7 +177,8 @@ typedef enum {
     BVHGPU_TUNE_TRAVERSE_WAVES_PER_CU = 1, /* variant 1: resident waves per CU (default 32) */
     BVHGPU_TUNE_TRAVERSE_REFILL_MIN = 2,   /* variants 1, 2: refill once this many lanes are idle (default 1) */
     BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS = 3, /* variant 2 is used for batches of at least this many rays (default 16384) */
-    BVHGPU_TUNE_TRAVERSE_RAYS_PER_LANE = 4,/* variant 2: independent walks per lane (1, 2 or 4; default 4) */
+    BVHGPU_TUNE_TRAVERSE_LDS_SLOTS = 4,    /* variant 2: top-of-tree entries kept in LDS per workgroup (default 2048 = 11 levels) */
+    BVHGPU_TUNE_TRAVERSE_LDS_THREADS = 5,  /* variant 2: workgroup size (default 1024) */
     BVHGPU_TUNE_COUNT = 8
 } bvhgpu_tune;
 int bvhgpu_set_tuning(bvhgpu_ctx *ctx, int knob, int value);

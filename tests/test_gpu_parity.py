@@ -301,3 +301,72 @@ def test_full_size_properties_1m_rays(eng, orc):
     assert np.array_equal(ro, off[:6001]) and np.array_equal(ri, idx[:off[6000]])
     # slab tests per ray: SURVEY §8d re-derived on the device
     assert 60 < st["visited"] / R < 90
+
+
+# ------------------------------------------------------------------ traversal variants (tuning knobs never change results)
+@pytest.mark.parametrize("variant,slots,threads", [(0, 0, 0), (1, 0, 0), (2, 5056, 1024), (2, 2048, 1024), (2, 300, 256),
+                                                   (2, 4, 64)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_traversal_variants_same_result(eng, orc, variant, slots, threads, dtype):
+    """one ray per lane / persistent waves with refill / LDS-resident top of the tree: identical CSR (order
+    included), t-slices and reference-equivalent visit counters on scenes that stress every path: deep and
+    shallow walks, many hits per ray (per-wave pool chunks + overflow replay), axis-parallel and in-plane
+    rays (non-finite inverse directions → exact NaN-aware slab test), n = 1 and n = 2 trees, an uploaded
+    FlatBvh whose shapes moved."""
+    from bvh_amd import Context
+    from bvh_amd._lib import (TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_TRAVERSE_LDS_SLOTS, TUNE_TRAVERSE_LDS_THREADS,
+                              TUNE_TRAVERSE_VARIANT)
+    ctx = Context(0)
+    ctx.set_tuning(TUNE_TRAVERSE_VARIANT, variant)
+    ctx.set_tuning(TUNE_TRAVERSE_LDS_MIN_RAYS, 0)
+    if variant == 2:
+        ctx.set_tuning(TUNE_TRAVERSE_LDS_SLOTS, slots)
+        ctx.set_tuning(TUNE_TRAVERSE_LDS_THREADS, threads)
+    rtol = 1e-5 if dtype == np.float32 else 1e-12
+    rng = np.random.default_rng(77)
+
+    def check(aabbs, rays, flat_upload=None):
+        aabbs = aabbs.astype(dtype)
+        if flat_upload is None:
+            tree = eng.Bvh.from_aabbs(aabbs, ctx).flatten()
+            oflat = orc.flatten(orc.build(aabbs).nodes)
+            cur = aabbs
+        else:
+            oflat, cur = flat_upload
+            tree = eng.FlatBvh.from_flat_nodes(oflat, cur, ctx)
+        rb = eng.RayBatch(len(rays), dtype, host=np.ascontiguousarray(rays))
+        off, idx, ts, st = tree.traverse_batch(rb, want_t=True, stats=True)
+        ooff, oidx, ots, ost = orc.traverse_flat(oflat, cur, rays, want_t=True, threads=orc.max_threads())
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+        if len(idx):
+            assert np.allclose(ts, ots, rtol=rtol, atol=0)
+        assert (st["hits"], st["visited"], st["leaf_visits"]) == (ost["hits"], ost["visited"], ost["leaf_visits"])
+        off2, idx2, _, _ = tree.traverse_batch(rb)          # the NaN-free fast slab test (no t-slice requested)
+        assert np.array_equal(off2, ooff) and np.array_equal(idx2, oidx)
+
+    # clustered boxes, generic + axis-parallel + in-plane rays
+    n = 20000
+    lo = rng.integers(-60, 60, size=(n, 3)).astype(dtype) + rng.uniform(0, 1, size=(n, 3)).round(1).astype(dtype)
+    ext = rng.integers(0, 4, size=(n, 3)).astype(dtype)
+    aabbs = np.concatenate([lo, lo + ext], axis=1)
+    o = rng.uniform(-70, 70, size=(9000, 3)).astype(dtype)
+    d = rng.normal(size=(9000, 3)).astype(dtype)
+    d[:1500] = rng.integers(-1, 2, size=(1500, 3))
+    d[np.all(d == 0, axis=1)] = [0, 1, 0]
+    o[:700] = np.round(o[:700])                              # origins on box face planes
+    check(aabbs, orc.make_rays(o, d, dtype))
+    # many hits per ray
+    m = 3000
+    x = np.arange(m, dtype=dtype) * dtype(0.25)
+    lo2 = np.stack([x, np.zeros(m, dtype), np.zeros(m, dtype)], axis=1)
+    row = np.concatenate([lo2, lo2 + dtype(1.0)], axis=1)
+    o2 = np.tile(np.array([-5, 0.5, 0.5], dtype), (200, 1)); o2[:, 1] += np.linspace(0, 0.4, 200).astype(dtype)
+    check(row, orc.make_rays(o2, np.tile(np.array([1, 0, 0], dtype), (200, 1)), dtype))
+    # tiny trees
+    for k in (1, 2, 3):
+        check(aabbs[:k], orc.make_rays(o[:500], d[:500], dtype))
+    # uploaded FlatBvh, shapes moved
+    small = aabbs[:3000].astype(dtype)
+    oflat = orc.flatten(orc.build(small).nodes)
+    moved = small.copy(); moved[::3, [0, 3]] += dtype(0.75)
+    check(small, orc.make_rays(o[:4000], d[:4000], dtype), flat_upload=(oflat, moved))

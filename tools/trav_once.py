@@ -17,7 +17,7 @@ reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 R = 1_000_000
 dev = torch.device("cuda", 0)
 ctx = Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
-ctx.set_tuning(0, variant); ctx.set_tuning(1, wpc); ctx.set_tuning(2, refill); ctx.set_tuning(4, 1)
+ctx.set_tuning(0, variant); ctx.set_tuning(1, wpc); ctx.set_tuning(2, refill)
 bounds = tb.default_bounds()
 _, aabbs = tb.create_n_cubes(10000, bounds)
 bvh = Bvh.from_aabbs(torch.from_numpy(aabbs).to(dev), ctx)
