@@ -28,12 +28,22 @@ namespace bvhgpu {
 constexpr int MAXLV = 96;        // counter slots (levels beyond reuse the last two, host-synchronised)
 constexpr int CTR_SMALL = 0;     // u32: number of small items (<= 64 shapes, wave-subtree tier)
 constexpr int CTR_MID = 1;       // u32: number of mid items (65 .. MID_MAX shapes, workgroup tier)
-constexpr int MID_THREADS = 512;  // workgroup tier: one 8-wave workgroup per node (256 VGPRs per lane available)
-template <typename T> struct MidCfg {
-    static constexpr int MAXN = sizeof(T) == 4 ? 4096 : 2048;  // shapes one workgroup can hold (LDS: 24/48 B each)
-    static constexpr int PPT = MAXN / MID_THREADS;             // consecutive positions owned by a thread
-    static constexpr int MAXSUB = MAXN / 64;                   // > MAXN/65 simultaneously active sub-nodes
+constexpr int CTR_MID2 = 2;      // u32: number of second-mid-tier items (65 .. MidB::MAXN shapes)
+// Workgroup tiers.  A: nodes up to MidA::MAXN shapes, one 512-thread workgroup per node (LDS holds all its
+// AABBs, so one workgroup per CU and only n/MAXN of them): it splits until a child fits tier B and hands it
+// over.  B: nodes up to MidB::MAXN shapes, 256 threads and ~40 KB of LDS, so every CU runs several and the
+// whole chip is busy: it splits down to <= 64-shape children for the wave tier.
+template <typename T> struct MidB {
+    static constexpr int MAXN = sizeof(T) == 4 ? 1024 : 512;
+    static constexpr int THREADS = 256;
+    static constexpr int HANDOFF = SMALL_MAX;
 };
+template <typename T> struct MidA {
+    static constexpr int MAXN = sizeof(T) == 4 ? 4096 : 2048;  // shapes one workgroup can hold (LDS: 24/48 B each)
+    static constexpr int THREADS = 512;
+    static constexpr int HANDOFF = MidB<T>::MAXN;
+};
+template <typename T> struct MidCfg { static constexpr int MAXN = MidA<T>::MAXN; };
 constexpr int CTR_LEVEL0 = 16;   // u32 pairs (n_items, n_tiles) per level slot
 constexpr size_t ROOTKEY_OFF = 1024;  // byte offset of the 12 root keys inside the ctr buffer
 
@@ -58,6 +68,7 @@ template <typename T> struct BuildArgs {
     uint8_t* bk;
     Item<T>* big[2];
     Item<T>* mid;
+    Item<T>* mid2;
     Item<T>* small;
     ItemStats<T>* stats[2];
     uint32_t* tile_item[2];
@@ -134,10 +145,12 @@ __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, ui
     const int npar = next_level & 1;
     uint32_t slot = 0, tb = 0;
     const bool is_small = count <= (uint32_t)SMALL_MAX;
-    const bool is_mid = !is_small && count <= (uint32_t)MidCfg<T>::MAXN;
+    const bool is_mid2 = !is_small && count <= (uint32_t)MidB<T>::MAXN;
+    const bool is_mid = !is_small && !is_mid2 && count <= (uint32_t)MidA<T>::MAXN;
     const uint32_t ntile = (count + TILE - 1) / TILE;
     if (lane == 0) {
         if (is_small) slot = atomicAdd(&a.ctr[CTR_SMALL], 1u);
+        else if (is_mid2) slot = atomicAdd(&a.ctr[CTR_MID2], 1u);
         else if (is_mid) slot = atomicAdd(&a.ctr[CTR_MID], 1u);
         else {
             slot = atomicAdd(&a.ctr[CTR_LEVEL0 + 2 * nslot], 1u);
@@ -146,13 +159,13 @@ __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, ui
     }
     slot = __shfl(slot, 0);
     tb = __shfl(tb, 0);
-    Item<T>* it = is_small ? &a.small[slot] : (is_mid ? &a.mid[slot] : &a.big[npar][slot]);
+    Item<T>* it = is_small ? &a.small[slot] : (is_mid2 ? &a.mid2[slot] : (is_mid ? &a.mid[slot] : &a.big[npar][slot]));
     if (lane == 0) {
         it->ni = ni; it->parent = parent; it->start = start; it->count = count;
         it->tile_base = tb; it->parity = (uint32_t)npar; it->heap = heap; it->_r1 = 0;
     }
     if (lane < 6) { it->A[lane] = A[lane]; it->C[lane] = C[lane]; }
-    if (!is_small && !is_mid) {
+    if (!is_small && !is_mid && !is_mid2) {
         for (uint32_t j = lane; j < ntile; j += WAVE) a.tile_item[npar][tb + j] = slot;
         init_stats<T>(&a.stats[npar][slot], lane);
     }
@@ -530,16 +543,20 @@ __device__ __forceinline__ uint32_t packed_field(unsigned long long lo, uint32_t
 #ifdef BVH_PROFILE_MID
 __device__ unsigned long long g_mid_prof[8];
 #define MID_T0() long long _t0 = clock64()
-#define MID_T(i) do { long long _t1 = clock64(); if (tid == 0 && blockIdx.x == 0) { atomicAdd(&g_mid_prof[i], (unsigned long long)(_t1 - _t0)); if (i == 5) atomicAdd(&g_mid_prof[0], 1ull); } _t0 = _t1; } while (0)
+#define MID_T(i) do { long long _t1 = clock64(); if (tid == 0 && blockIdx.x == 0 && TIER_A == (BVH_PROFILE_MID == 1)) { atomicAdd(&g_mid_prof[i], (unsigned long long)(_t1 - _t0)); if (i == 5) atomicAdd(&g_mid_prof[0], 1ull); } _t0 = _t1; } while (0)
 #else
 #define MID_T0()
 #define MID_T(i)
 #endif
 
-template <typename T> __global__ __launch_bounds__(MID_THREADS) void k_mid(BuildArgs<T> a, uint32_t first) {
+template <typename T, typename Cfg, bool TIER_A>
+__global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t first) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
-    constexpr int MAXN = MidCfg<T>::MAXN, PPT = MidCfg<T>::PPT, MAXSUB = MidCfg<T>::MAXSUB;
+    constexpr int MAXN = Cfg::MAXN, MID_THREADS = Cfg::THREADS, PPT = MAXN / MID_THREADS;
+    constexpr int HANDOFF = Cfg::HANDOFF;                 // children with at most this many shapes leave the workgroup
+    constexpr int MAXSUB = MAXN / (HANDOFF + 1) + 1;      // simultaneously active sub-nodes
+    static_assert(MAXSUB <= WAVE, "phase 4 gives one lane of wave 0 to every active sub-node");
     constexpr uint8_t SEG_NONE = 0xFFu;
     __shared__ __attribute__((aligned(16))) T s_box[MAXN * 6];
     __shared__ uint32_t s_idx[MAXN];
@@ -550,12 +567,13 @@ template <typename T> __global__ __launch_bounds__(MID_THREADS) void k_mid(Build
     __shared__ uint32_t s_whi[MID_THREADS / WAVE];
     __shared__ uint32_t s_nsub;
 
-    const uint32_t n_mid = a.ctr[CTR_MID];
+    const uint32_t n_mid = a.ctr[TIER_A ? CTR_MID : CTR_MID2];
+    const Item<T>* queue = TIER_A ? a.mid : a.mid2;
     const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     const unsigned long long lt = lanemask_lt();
 
     for (uint32_t item_id = first + blockIdx.x; item_id < n_mid; item_id += gridDim.x) {
-        const Item<T>* it = &a.mid[item_id];
+        const Item<T>* it = &queue[item_id];
         const uint32_t istart = it->start, count = it->count;
         const uint32_t* gsrc = a.idx[it->parity];
         uint32_t* gdst = a.idx[it->parity ^ 1];   // where the <= 64-shape children's slices are left
@@ -782,18 +800,26 @@ template <typename T> __global__ __launch_bounds__(MID_THREADS) void k_mid(Build
                     a.node_slot[ni] = (uint16_t)m->heap;
                     m->nl = nl;
                 }
-                const bool subL = has && cl > (uint32_t)SMALL_MAX, subR = has && cr > (uint32_t)SMALL_MAX;
-                const bool smL = has && !subL, smR = has && !subR;
+                const bool subL = has && cl > (uint32_t)HANDOFF, subR = has && cr > (uint32_t)HANDOFF;
+                // a child that leaves goes to the wave tier (<= 64 shapes) or, from tier A, to tier B
+                const bool smL = has && !subL && cl <= (uint32_t)SMALL_MAX, smR = has && !subR && cr <= (uint32_t)SMALL_MAX;
+                const bool m2L = has && !subL && !smL, m2R = has && !subR && !smR;
                 const unsigned long long mL = __ballot(subL), mR = __ballot(subR);
                 const unsigned long long qL = __ballot(smL), qR = __ballot(smR);
+                const unsigned long long wL = __ballot(m2L), wR = __ballot(m2R);
                 const uint32_t idL = (uint32_t)(__popcll(mL & lt) + __popcll(mR & lt));
                 const uint32_t idR = idL + (subL ? 1u : 0u);
                 const uint32_t nsmall = (uint32_t)(__popcll(qL) + __popcll(qR));
-                uint32_t sbase = 0;
+                const uint32_t nmid2 = (uint32_t)(__popcll(wL) + __popcll(wR));
+                uint32_t sbase = 0, wbase = 0;
                 if (lane == 0 && nsmall) sbase = atomicAdd(&a.ctr[CTR_SMALL], nsmall);
+                if (lane == 0 && nmid2) wbase = atomicAdd(&a.ctr[CTR_MID2], nmid2);
                 sbase = __shfl(sbase, 0);
+                wbase = __shfl(wbase, 0);
                 const uint32_t slL = sbase + (uint32_t)(__popcll(qL & lt) + __popcll(qR & lt));
                 const uint32_t slR = slL + (smL ? 1u : 0u);
+                const uint32_t w2L = wbase + (uint32_t)(__popcll(wL & lt) + __popcll(wR & lt));
+                const uint32_t w2R = w2L + (m2L ? 1u : 0u);
                 if (has) {
                     const uint32_t ni = m->ni, li = ni + 1, ri = li + (2 * nl - 1);
                     m->child[0] = subL ? idL : NONE;
@@ -813,7 +839,8 @@ template <typename T> __global__ __launch_bounds__(MID_THREADS) void k_mid(Build
                             for (int k = 0; k < 6; k++) { c->A[k] = CA[k]; c->C[k] = CC[k]; }
                             midsub_derive(c);
                         } else {
-                            Item<T>* g = &a.small[side ? slR : slL];
+                            const bool to_small = side ? smR : smL;
+                            Item<T>* g = to_small ? &a.small[side ? slR : slL] : &a.mid2[side ? w2R : w2L];
                             g->ni = cni; g->parent = ni; g->start = istart + cstart; g->count = ccount;
                             g->tile_base = 0; g->parity = out_parity; g->heap = heap_child(m->heap, (uint32_t)side); g->_r1 = 0;
 #pragma unroll
@@ -938,7 +965,11 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
 #pragma unroll
         for (int k = 0; k < 3; k++) c[k] = center1(box[k], box[3 + k]);
 
-        // ---- segmented inclusive prefix (P) and suffix (S) joins of AABB and centroid bounds
+        // ---- segmented inclusive prefix (P) and suffix (S) joins of AABB and centroid bounds.  One
+        //      v_min/v_max per join (common.hpp join_min/join_max: -0 < +0 like the oracle).  A lane at the
+        //      edge of its segment fetches from ITSELF (join(x, x) = x), so no select is needed, and all 24
+        //      cross-lane moves of a step are issued before any is consumed (a ds_bpermute round trip is
+        //      ~100 cycles).  Steps whose distance is not below the longest live segment are skipped.
         T P[12], S[12];
 #pragma unroll
         for (int k = 0; k < 6; k++) { P[k] = box[k]; S[k] = box[k]; }
@@ -946,49 +977,60 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
         for (int k = 0; k < 3; k++) { P[6 + k] = c[k]; P[9 + k] = c[k]; S[6 + k] = c[k]; S[9 + k] = c[k]; }
 #pragma unroll
         for (int d = 1; d < WAVE; d <<= 1) {
-            const bool up_ok = (lane - d) >= lo;
-            const bool dn_ok = (lane + d) < hi;
+            if (!__any(!done && segn > d)) break;
+            const int up4 = ((lane - d) >= lo ? lane - d : lane) << 2;
+            const int dn4 = ((lane + d) < hi ? lane + d : lane) << 2;
+            T u[12], v[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) u[k] = lane_fetch(P[k], up4);
+#pragma unroll
+            for (int k = 0; k < 12; k++) v[k] = lane_fetch(S[k], dn4);
 #pragma unroll
             for (int k = 0; k < 12; k++) {
-                const bool is_min = key_is_min(k);
-                T u = __shfl_up(P[k], d);
-                T v = __shfl_down(S[k], d);
-                if (up_ok) P[k] = is_min ? tmin(P[k], u) : tmax(P[k], u);
-                if (dn_ok) S[k] = is_min ? tmin(S[k], v) : tmax(S[k], v);
+                P[k] = key_is_min(k) ? join_min(P[k], u[k]) : join_max(P[k], u[k]);
+                S[k] = key_is_min(k) ? join_min(S[k], v[k]) : join_max(S[k], v[k]);
             }
         }
         // ---- SAH cost of the 5 candidates (:231-247): L = prefix at the last lane of bucket <= s,
         //      R = suffix at the first lane of bucket > s
         const T saP = surface_area(P), saS = surface_area(S);
+        int cumv[NUM_BUCKETS - 1];
+        T salv[NUM_BUCKETS - 1], sarv[NUM_BUCKETS - 1];
+        {
+            int cum = 0;
+#pragma unroll
+            for (int s2 = 0; s2 < NUM_BUCKETS - 1; s2++) { cum += cnt[s2]; cumv[s2] = cum; }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < NUM_BUCKETS - 1; s2++) {   // the 10 fetches first, the costs afterwards
+            const int q2 = lo + cumv[s2];
+            salv[s2] = lane_fetch(saP, min(max(q2 - 1, 0), 63) << 2);
+            sarv[s2] = lane_fetch(saS, min(max(q2, 0), 63) << 2);
+        }
         int nl = cnt[0];
         bool taken = false;  // no winner (NaN/inf costs) → min_bucket 0 with EMPTY child bounds (:225-230)
         T min_cost = Tr::inf();
-        int cum = 0;
 #pragma unroll
-        for (int s = 0; s < NUM_BUCKETS - 1; s++) {
-            cum += cnt[s];
-            int q = lo + cum;
-            int ql = min(max(q - 1, 0), 63), qr = min(max(q, 0), 63);
-            T sal = __shfl(saP, ql);
-            T sar = __shfl(saS, qr);
-            T cl = (T)cum * sal;
-            T cr = (T)(segn - cum) * sar;
+        for (int s2 = 0; s2 < NUM_BUCKETS - 1; s2++) {
+            T cl = (T)cumv[s2] * salv[s2];
+            T cr = (T)(segn - cumv[s2]) * sarv[s2];
             T num = cl + cr;
             T cost = num / saA;
-            bool take = degen ? (s == 0) : (cost < min_cost);
-            if (take) { min_cost = cost; nl = cum; taken = true; }
+            bool take = degen ? (s2 == 0) : (cost < min_cost);
+            if (take) { min_cost = cost; nl = cumv[s2]; taken = true; }
         }
         const int q = lo + nl;
-        const int ql = min(max(q - 1, 0), 63), qr = min(max(q, 0), 63);
+        const int ql4 = min(max(q - 1, 0), 63) << 2, qr4 = min(max(q, 0), 63) << 2;
         T AL[6], AR[6], Cn[6];
         const bool left = lane < q;
+        {
+            T kl[12], kr[12];
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            AL[k] = __shfl(P[k], ql);
-            AR[k] = __shfl(S[k], qr);
-            T cl = __shfl(P[6 + k], ql);
-            T cr = __shfl(S[6 + k], qr);
-            Cn[k] = left ? cl : cr;
+            for (int k = 0; k < 12; k++) kl[k] = lane_fetch(P[k], ql4);
+#pragma unroll
+            for (int k = 0; k < 12; k++) kr[k] = lane_fetch(S[k], qr4);
+#pragma unroll
+            for (int k = 0; k < 6; k++) { AL[k] = kl[k]; AR[k] = kr[k]; Cn[k] = left ? kl[6 + k] : kr[6 + k]; }
         }
         if (!taken) { box_empty(AL); box_empty(AR); box_empty(Cn); }
         if (!done) {
@@ -1033,7 +1075,8 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
 
     constexpr size_t MID_MAX = (size_t)MidCfg<T>::MAXN;
     const size_t max_big = n / (MID_MAX + 1) + 2;       // simultaneously active nodes with > MID_MAX shapes
-    const size_t max_mid = n / (SMALL_MAX + 1) + 2;     // nodes with 65..MID_MAX shapes whose parent was larger
+    const size_t max_mid = n / (MidB<T>::MAXN + 1) + 2;  // tier A: nodes with more than MidB::MAXN shapes
+    const size_t max_mid2 = n / (SMALL_MAX + 1) + 2;     // tier B: nodes with 65..MidB::MAXN shapes
     const size_t max_tiles = n / TILE + max_big + 2;
     t->aabbs.reserve(n * 6 * sizeof(T));
     t->nodes.reserve(t->n_nodes * sizeof(typename Tr::Node));
@@ -1051,6 +1094,7 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
         t->tile_item[i].reserve(max_tiles * 4);
     }
     t->mid.reserve(max_mid * sizeof(Item<T>));
+    t->mid2.reserve(max_mid2 * sizeof(Item<T>));
     t->small.reserve((n + 1) * sizeof(Item<T>));
     t->tile_cnt.reserve(max_tiles * NUM_BUCKETS * 4);
     t->ctr.reserve(ROOTKEY_OFF + STAT_KEYS * sizeof(Key));
@@ -1071,6 +1115,7 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     a.bk = t->bk.as<uint8_t>();
     a.big[0] = t->big[0].as<Item<T>>(); a.big[1] = t->big[1].as<Item<T>>();
     a.mid = t->mid.as<Item<T>>();
+    a.mid2 = t->mid2.as<Item<T>>();
     a.small = t->small.as<Item<T>>();
     a.stats[0] = t->stats[0].as<ItemStats<T>>(); a.stats[1] = t->stats[1].as<ItemStats<T>>();
     a.tile_item[0] = t->tile_item[0].as<uint32_t>(); a.tile_item[1] = t->tile_item[1].as<uint32_t>();
@@ -1087,6 +1132,7 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     const int tile_grid = (int)std::min<size_t>(max_tiles, 2048);
     const int sel_grid = (int)std::min<size_t>((max_big + 3) / 4, 1024);
     const int mid_grid = (int)std::min<size_t>(max_mid, (size_t)ctx->n_cu);
+    const int mid2_grid = (int)std::min<size_t>(max_mid2, (size_t)ctx->n_cu * 4);
     const int small_grid = (int)std::min<size_t>((n + 3) / 4, (size_t)ctx->n_cu * 8);
     uint32_t* pin = reinterpret_cast<uint32_t*>(ctx->pinned);
     auto run_level = [&](int L) {
@@ -1104,14 +1150,18 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
         if (fixed > MAXLV - 4) fixed = MAXLV - 4;
         for (; level < fixed; level++) run_level(level);
     }
-    uint32_t mid_done = 0, small_done = 0;
+    uint32_t mid_done = 0, mid2_done = 0, small_done = 0;
     while (true) {
-        if (n > (size_t)SMALL_MAX) hipLaunchKernelGGL(k_mid<T>, dim3(mid_grid), dim3(MID_THREADS), 0, st, a, mid_done);
+        if (n > (size_t)MidB<T>::MAXN)
+            hipLaunchKernelGGL((k_mid<T, MidA<T>, true>), dim3(mid_grid), dim3(MidA<T>::THREADS), 0, st, a, mid_done);
+        if (n > (size_t)SMALL_MAX)
+            hipLaunchKernelGGL((k_mid<T, MidB<T>, false>), dim3(mid2_grid), dim3(MidB<T>::THREADS), 0, st, a, mid2_done);
         hipLaunchKernelGGL(k_small<T>, dim3(small_grid), dim3(256), 0, st, a, small_done);
         BVH_HIP(hipMemcpyAsync(pin, a.ctr, ROOTKEY_OFF, hipMemcpyDeviceToHost, st));
         BVH_HIP(hipStreamSynchronize(st));
         BVH_HIP(hipGetLastError());
         mid_done = pin[CTR_MID];
+        mid2_done = pin[CTR_MID2];
         small_done = pin[CTR_SMALL];
         if (n <= (size_t)MID_MAX || pin[CTR_LEVEL0 + 2 * lvl_slot(level)] == 0) break;
         // slow path: the level queue is not empty yet — one more level per host round trip

@@ -239,6 +239,23 @@ template <typename T> __device__ __forceinline__ bool ray_is_finite(const T o[3]
 // ------------------------------------------------------------------------------------------------
 // wave64 helpers
 // ------------------------------------------------------------------------------------------------
+// Aabb join on NaN-free floats in ONE instruction: V_MIN_F32 / V_MAX_F32 (and the F64 forms) order
+// -0 < +0 (ISA: "if S0 == +0 and S1 == -0 return S1"), i.e. exactly tmin / tmax above and the integer-key
+// order.  Written as asm so that no canonicalising v_max x,x is added for values that come out of shuffles.
+__device__ __forceinline__ float join_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float join_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double join_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double join_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// value of lane (byte address `addr4` = 4 * lane) — one ds_bpermute_b32 per dword
+__device__ __forceinline__ float lane_fetch(float v, int addr4) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(addr4, __float_as_int(v)));
+}
+__device__ __forceinline__ double lane_fetch(double v, int addr4) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(addr4, (int)(b & 0xFFFFFFFFll));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr4, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     int l = lane_id();
