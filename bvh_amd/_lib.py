@@ -19,6 +19,8 @@ HOST, DEVICE = 0, 1
 NONE = 0xFFFFFFFF
 TRAVERSE_T_SLICE = 1
 TRAVERSE_STATS = 2
+TRAVERSE_TRIANGLES = 4
+TRAVERSE_CLOSEST = 8
 
 NODE_F32 = np.dtype([("l_min", "<f4", 3), ("l_max", "<f4", 3), ("r_min", "<f4", 3), ("r_max", "<f4", 3),
                      ("parent", "<u4"), ("l", "<u4"), ("r", "<u4"), ("shape", "<u4")])
@@ -79,8 +81,14 @@ SYMBOLS = [
     ("bvhgpu_rays_new_f64", _i, [_vp, _vp, _vp, _sz, _i, _vp, _i]),
     ("bvhgpu_gen_rays_f32", _i, [_vp, C.c_uint64, _sz, _vp, _vp]),
     ("bvhgpu_gen_rays_f64", _i, [_vp, C.c_uint64, _sz, _vp, _vp]),
+    ("bvhgpu_ray_triangle_pairs_f32", _i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    ("bvhgpu_ray_triangle_pairs_f64", _i, [_vp, _vp, _vp, _sz, _i, _vp]),
     ("bvhgpu_traverse_f32", _i, [_vp, _vp, _sz, _i, _u, _pp]),
     ("bvhgpu_traverse_f64", _i, [_vp, _vp, _sz, _i, _u, _pp]),
+    ("bvhgpu_tree_set_triangles_f32", _i, [_vp, _vp, _sz, _i]),
+    ("bvhgpu_tree_set_triangles_f64", _i, [_vp, _vp, _sz, _i]),
+    ("bvhgpu_hits_fetch_triangles", _i, [_vp, _vp, _i]),
+    ("bvhgpu_hits_fetch_closest", _i, [_vp, _vp, _vp, _i]),
     ("bvhgpu_hits_info", _i, [_vp, C.POINTER(_sz), C.POINTER(C.c_uint64), C.POINTER(TraverseStats)]),
     ("bvhgpu_hits_fetch", _i, [_vp, _vp, _vp, _vp, _i]),
     ("bvhgpu_hits_device", _i, [_vp, _pp, _pp, _pp]),
@@ -90,7 +98,7 @@ SYMBOLS = [
     ("bvhgpu_set_tuning", _i, [_vp, _i, _i]),
     ("bvhgpu_get_tuning", _i, [_vp, _i, C.POINTER(_i)]),
 ]
-TUNE_TRAVERSE_VARIANT, TUNE_TRAVERSE_WAVES_PER_CU, TUNE_TRAVERSE_REFILL_MIN = 0, 1, 2
+TUNE_TRAVERSE_VARIANT = 0
 TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_TRAVERSE_LDS_SLOTS, TUNE_TRAVERSE_LDS_THREADS = 3, 4, 5
 
 _lib = None

@@ -21,7 +21,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (DEVICE, F32, F64, FLAT_F32, FLAT_F64, HOST, NODE_F32, NODE_F64, NONE, RAY_F32, RAY_F64,
-                   TRAVERSE_STATS, TRAVERSE_T_SLICE, BvhGpuError, check, ptr)
+                   TRAVERSE_CLOSEST, TRAVERSE_STATS, TRAVERSE_T_SLICE, TRAVERSE_TRIANGLES, BvhGpuError, check, ptr)
 
 
 def _sfx(dtype) -> str:
@@ -214,6 +214,20 @@ class RayBatch:
         return RayBatch(n, dtype, host=None, device=device_obj, device_ptr=device_obj.data_ptr())
 
 
+def intersect_triangle_pairs(rays: "RayBatch", tris, ctx: Optional["Context"] = None) -> np.ndarray:
+    """Ray::intersects_triangle (ray_impl.rs:154-213) for ray i against triangle i, on the GPU.
+    tris: (n,3,3) or (n,9).  returns (n,3) = Intersection{distance,u,v}."""
+    ctx = ctx or default_context()
+    ft = np.float32 if rays.sfx == "f32" else np.float64
+    t = np.ascontiguousarray(tris, dtype=ft).reshape(-1, 9)
+    if len(t) != rays.n or rays.host is None:
+        raise ValueError("one host triangle per host ray is required")
+    out = np.zeros((rays.n, 3), dtype=ft)
+    fn = getattr(_lib.load(), f"bvhgpu_ray_triangle_pairs_{rays.sfx}")
+    check(fn(ctx._h, rays._ptr(), ptr(t), rays.n, HOST, ptr(out)), ctx._h)
+    return out
+
+
 class Ray:
     """struct Ray (ray_impl.rs:17-29).  Ray(origin, direction) == Ray::new."""
 
@@ -233,6 +247,11 @@ class Ray:
         bvh = Bvh.from_aabbs(aabb.as6().reshape(1, 6).astype(self.dtype))
         off, idx, ts, _ = bvh.flatten().traverse_batch(self._batch, want_t=want_t)
         return (len(idx) == 1), (ts[0] if want_t and len(idx) else None)
+
+    def intersects_triangle(self, a, b, c):  # ray_impl.rs:154-213 → Intersection(distance, u, v)
+        t = np.concatenate([np.asarray(v, dtype=self.dtype).reshape(3) for v in (a, b, c)]).reshape(1, 9)
+        r = intersect_triangle_pairs(self._batch, t)[0]
+        return r[0], r[1], r[2]
 
     def intersects_aabb(self, aabb: Aabb) -> bool:  # ray_impl.rs:105-110, intersect_default.rs:16-37
         return self._probe(aabb, False)[0]
@@ -312,6 +331,57 @@ class _TreeBase:
         ts = np.zeros((total.value, 2), dtype=ft) if want_t else None
         check(lib.bvhgpu_hits_fetch(self._hits.h, ptr(offsets), ptr(indices), ptr(ts), HOST), self.ctx._h)
         return offsets, indices, ts, sd
+
+    # ---- triangle stage -------------------------------------------------------------------
+    def set_triangles(self, tris) -> None:
+        """vertices of the shapes, (n,3,3) or (n,9) [a, b, c] (testbase.rs Triangle :316-323); numpy or torch GPU tensor."""
+        lib = _lib.load()
+        fn = getattr(lib, f"bvhgpu_tree_set_triangles_{self.sfx}")
+        if _is_device_tensor(tris):
+            check(fn(self._t, ptr(tris.data_ptr()), tris.numel() // 9, DEVICE), self.ctx._h)
+        else:
+            ft = np.float32 if self.sfx == "f32" else np.float64
+            a = np.ascontiguousarray(tris, dtype=ft).reshape(-1, 9)
+            check(fn(self._t, ptr(a), len(a), HOST), self.ctx._h)
+
+    def intersect_triangles(self, rays: RayBatch, stats: bool = False):
+        """traverse + Ray::intersects_triangle on every returned shape (testbase.rs:826-836).
+        returns (offsets, indices, isect[total,3] = Intersection{distance,u,v}, stats)"""
+        lib = _lib.load()
+        flags = TRAVERSE_TRIANGLES | (TRAVERSE_STATS if stats else 0)
+        check(getattr(lib, f"bvhgpu_traverse_{self.sfx}")(self._t, rays._ptr(), rays.n, rays.mem, flags,
+                                                           C.byref(self._hits.h)), self.ctx._h)
+        total = C.c_uint64()
+        st = _lib.TraverseStats()
+        check(lib.bvhgpu_hits_info(self._hits.h, None, C.byref(total), C.byref(st)), self.ctx._h)
+        ft = np.float32 if self.sfx == "f32" else np.float64
+        offsets = np.zeros(rays.n + 1, dtype=np.uint32)
+        indices = np.zeros(total.value, dtype=np.uint32)
+        isect = np.zeros((total.value, 3), dtype=ft)
+        check(lib.bvhgpu_hits_fetch(self._hits.h, ptr(offsets), ptr(indices), None, HOST), self.ctx._h)
+        check(lib.bvhgpu_hits_fetch_triangles(self._hits.h, ptr(isect), HOST), self.ctx._h)
+        sd = dict(hits=int(st.hits), visited=int(st.visited), leaf_visits=int(st.leaf_visits),
+                  device_steps=int(st.device_steps), wave_steps=int(st.wave_steps))
+        return offsets, indices, isect, sd
+
+    def closest_hits(self, rays: RayBatch, stats: bool = False, fetch: bool = True):
+        """triangle stage fused into the walk: per ray the nearest Intersection and its shape
+        (distance +inf / shape NONE when nothing is hit).  returns (isect[n,3], shape[n], stats)"""
+        lib = _lib.load()
+        flags = TRAVERSE_CLOSEST | (TRAVERSE_STATS if stats else 0)
+        check(getattr(lib, f"bvhgpu_traverse_{self.sfx}")(self._t, rays._ptr(), rays.n, rays.mem, flags,
+                                                           C.byref(self._hits.h)), self.ctx._h)
+        st = _lib.TraverseStats()
+        check(lib.bvhgpu_hits_info(self._hits.h, None, None, C.byref(st)), self.ctx._h)
+        sd = dict(hits=int(st.hits), visited=int(st.visited), leaf_visits=int(st.leaf_visits),
+                  device_steps=int(st.device_steps), wave_steps=int(st.wave_steps))
+        if not fetch:
+            return None, None, sd
+        ft = np.float32 if self.sfx == "f32" else np.float64
+        isect = np.zeros((rays.n, 3), dtype=ft)
+        shape = np.zeros(rays.n, dtype=np.uint32)
+        check(lib.bvhgpu_hits_fetch_closest(self._hits.h, ptr(isect), ptr(shape), HOST), self.ctx._h)
+        return isect, shape, sd
 
     def hits_device(self) -> Tuple[int, int]:
         """device addresses of the last result's (offsets, indices) — valid until the next traverse."""

@@ -52,7 +52,7 @@ void copy_out(bvhgpu_ctx* ctx, void* dst, const void* src_dev, size_t bytes, int
 
 void free_tree_buffers(bvhgpu_tree* t) {
     t->aabbs.release(); t->nodes.release(); t->node_start.release(); t->node_count.release();
-    t->shape_node.release(); t->flat.release(); t->trav.release(); t->slot_entry.release(); t->node_slot.release();
+    t->shape_node.release(); t->flat.release(); t->trav.release(); t->slot_entry.release(); t->node_slot.release(); t->tris.release();
     t->idx[0].release(); t->idx[1].release(); t->bk.release();
     t->big[0].release(); t->big[1].release(); t->mid.release(); t->mid2.release(); t->small.release();
     t->stats[0].release(); t->stats[1].release();
@@ -101,6 +101,12 @@ int do_traverse(bvhgpu_tree* tree, const typename Traits<T>::Ray* rays, size_t n
     if (!tree->flattened) return fail(ctx, BVHGPU_NOT_FLATTENED, "call bvhgpu_flatten first");
     if (n_rays && !rays) return fail(ctx, BVHGPU_INVALID_ARG, "rays is NULL");
     if (n_rays >= 0xFFFFFFFFull) return fail(ctx, BVHGPU_OVERFLOW, "more than 2^32-2 rays in one batch");
+    if ((flags & (BVHGPU_TRAVERSE_TRIANGLES | BVHGPU_TRAVERSE_CLOSEST)) && !tree->has_tris)
+        return fail(ctx, BVHGPU_INVALID_ARG, "TRIANGLES / CLOSEST need bvhgpu_tree_set_triangles first");
+    if ((flags & BVHGPU_TRAVERSE_T_SLICE) && (flags & (BVHGPU_TRAVERSE_TRIANGLES | BVHGPU_TRAVERSE_CLOSEST)))
+        return fail(ctx, BVHGPU_INVALID_ARG, "T_SLICE cannot be combined with TRIANGLES / CLOSEST");
+    if ((flags & BVHGPU_TRAVERSE_TRIANGLES) && (flags & BVHGPU_TRAVERSE_CLOSEST))
+        return fail(ctx, BVHGPU_INVALID_ARG, "TRIANGLES and CLOSEST are alternatives");
     return guarded(ctx, [&] {
         use_device(ctx);
         bvhgpu_hits* h = *hits;
@@ -222,6 +228,29 @@ int tree_from_flat(bvhgpu_ctx* ctx, const typename Traits<T>::Flat* flat, size_t
     t->built = false; t->flattened = true; t->unfolded = true;
     *out = t;
     return BVHGPU_OK;
+}
+
+template <typename T>
+int do_pairs(bvhgpu_ctx* ctx, const typename Traits<T>::Ray* rays, const T* tris, size_t n, int mem, T* out) {
+    if (!ctx) return BVHGPU_INVALID_ARG;
+    if (n && (!rays || !tris || !out)) return fail(ctx, BVHGPU_INVALID_ARG, "NULL argument");
+    if (n >= 0xFFFFFFFFull) return fail(ctx, BVHGPU_OVERFLOW, "too many pairs in one call");
+    return guarded(ctx, [&] {
+        use_device(ctx);
+        using Ray = typename Traits<T>::Ray;
+        const Ray* rd = rays; const T* td = tris; T* od = out;
+        if (mem == BVHGPU_HOST) {
+            const size_t rb = n * sizeof(Ray), tb = n * 9 * sizeof(T), ob = n * 3 * sizeof(T);
+            ctx->upload.reserve(rb + tb + ob + 64);
+            char* base = ctx->upload.as<char>();
+            BVH_HIP(hipMemcpyAsync(base, rays, rb, hipMemcpyHostToDevice, ctx->stream));
+            BVH_HIP(hipMemcpyAsync(base + rb, tris, tb, hipMemcpyHostToDevice, ctx->stream));
+            rd = reinterpret_cast<const Ray*>(base); td = reinterpret_cast<const T*>(base + rb); od = reinterpret_cast<T*>(base + rb + tb);
+        }
+        ray_triangle_pairs<T>(ctx, rd, td, n, od);
+        if (mem == BVHGPU_HOST) copy_out(ctx, out, od, n * 3 * sizeof(T), BVHGPU_HOST);
+        return (int)BVHGPU_OK;
+    });
 }
 
 }  // namespace
@@ -492,12 +521,62 @@ int bvhgpu_gen_rays_f64(bvhgpu_ctx* ctx, uint64_t first, size_t n, const float b
     return guarded(ctx, [&] { use_device(ctx); gen_rays_f64(ctx, first, n, bounds, out_dev); return (int)BVHGPU_OK; });
 }
 
+int bvhgpu_ray_triangle_pairs_f32(bvhgpu_ctx* ctx, const bvhgpu_ray_f32* rays, const float* tris, size_t n, int mem, float* out) {
+    return do_pairs<float>(ctx, rays, tris, n, mem, out);
+}
+int bvhgpu_ray_triangle_pairs_f64(bvhgpu_ctx* ctx, const bvhgpu_ray_f64* rays, const double* tris, size_t n, int mem, double* out) {
+    return do_pairs<double>(ctx, rays, tris, n, mem, out);
+}
+
 // ---- traverse ----
 int bvhgpu_traverse_f32(bvhgpu_tree* tree, const bvhgpu_ray_f32* rays, size_t n_rays, int mem, unsigned flags, bvhgpu_hits** hits) {
     return do_traverse<float>(tree, rays, n_rays, mem, flags, hits);
 }
 int bvhgpu_traverse_f64(bvhgpu_tree* tree, const bvhgpu_ray_f64* rays, size_t n_rays, int mem, unsigned flags, bvhgpu_hits** hits) {
     return do_traverse<double>(tree, rays, n_rays, mem, flags, hits);
+}
+
+static int set_triangles(bvhgpu_tree* t, const void* verts, size_t n, int mem, int dtype) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    bvhgpu_ctx* ctx = t->ctx;
+    if (t->dtype != dtype) return fail(ctx, BVHGPU_DTYPE_MISMATCH, "triangle dtype differs from tree dtype");
+    if (n != t->n) return fail(ctx, BVHGPU_INVALID_ARG, "one triangle per shape is required");
+    if (n && !verts) return fail(ctx, BVHGPU_INVALID_ARG, "verts is NULL");
+    return guarded(ctx, [&] {
+        use_device(ctx);
+        const size_t bytes = n * 9 * (dtype == BVHGPU_F32 ? 4 : 8);
+        t->tris.reserve(bytes + 16);
+        if (bytes) {
+            BVH_HIP(hipMemcpyAsync(t->tris.p, verts, bytes, mem == BVHGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+            if (mem != BVHGPU_DEVICE) BVH_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        t->has_tris = true;
+        return (int)BVHGPU_OK;
+    });
+}
+int bvhgpu_tree_set_triangles_f32(bvhgpu_tree* t, const float* verts, size_t n, int mem) { return set_triangles(t, verts, n, mem, BVHGPU_F32); }
+int bvhgpu_tree_set_triangles_f64(bvhgpu_tree* t, const double* verts, size_t n, int mem) { return set_triangles(t, verts, n, mem, BVHGPU_F64); }
+
+int bvhgpu_hits_fetch_triangles(bvhgpu_hits* h, void* isect, int mem) {
+    if (!h || !h->ctx) return BVHGPU_INVALID_ARG;
+    bvhgpu_ctx* ctx = h->ctx;
+    if (!(h->flags & BVHGPU_TRAVERSE_TRIANGLES)) return fail(ctx, BVHGPU_INVALID_ARG, "traverse was run without BVHGPU_TRAVERSE_TRIANGLES");
+    return guarded(ctx, [&] {
+        use_device(ctx);
+        if (isect && h->total) copy_out(ctx, isect, h->isect.p, h->total * 3 * (h->dtype == BVHGPU_F32 ? 4 : 8), mem);
+        return (int)BVHGPU_OK;
+    });
+}
+int bvhgpu_hits_fetch_closest(bvhgpu_hits* h, void* isect, uint32_t* shape, int mem) {
+    if (!h || !h->ctx) return BVHGPU_INVALID_ARG;
+    bvhgpu_ctx* ctx = h->ctx;
+    if (!(h->flags & BVHGPU_TRAVERSE_CLOSEST)) return fail(ctx, BVHGPU_INVALID_ARG, "traverse was run without BVHGPU_TRAVERSE_CLOSEST");
+    return guarded(ctx, [&] {
+        use_device(ctx);
+        if (isect && h->n_rays) copy_out(ctx, isect, h->closest.p, h->n_rays * 3 * (h->dtype == BVHGPU_F32 ? 4 : 8), mem);
+        if (shape && h->n_rays) copy_out(ctx, shape, h->closest_prim.p, h->n_rays * 4, mem);
+        return (int)BVHGPU_OK;
+    });
 }
 
 int bvhgpu_hits_info(const bvhgpu_hits* h, size_t* n_rays, uint64_t* total, bvhgpu_traverse_stats* stats) {
@@ -512,6 +591,7 @@ int bvhgpu_hits_fetch(bvhgpu_hits* h, uint32_t* offsets, uint32_t* indices, void
     if (!h || !h->ctx) return BVHGPU_INVALID_ARG;
     bvhgpu_ctx* ctx = h->ctx;
     if (tslice && !(h->flags & BVHGPU_TRAVERSE_T_SLICE)) return fail(ctx, BVHGPU_INVALID_ARG, "traverse was run without BVHGPU_TRAVERSE_T_SLICE");
+    if (h->flags & BVHGPU_TRAVERSE_CLOSEST) return fail(ctx, BVHGPU_INVALID_ARG, "CLOSEST produces no CSR: use bvhgpu_hits_fetch_closest");
     return guarded(ctx, [&] {
         use_device(ctx);
         if (offsets) copy_out(ctx, offsets, h->offsets.p, (h->n_rays + 1) * 4, mem);
@@ -523,6 +603,7 @@ int bvhgpu_hits_fetch(bvhgpu_hits* h, uint32_t* offsets, uint32_t* indices, void
 
 int bvhgpu_hits_device(const bvhgpu_hits* h, const uint32_t** offsets, const uint32_t** indices, const void** tslice) {
     if (!h) return BVHGPU_INVALID_ARG;
+    if (h->flags & BVHGPU_TRAVERSE_CLOSEST) return fail(h->ctx, BVHGPU_INVALID_ARG, "CLOSEST produces no CSR");
     if (offsets) *offsets = h->offsets.as<uint32_t>();
     if (indices) *indices = h->indices.as<uint32_t>();
     if (tslice) *tslice = (h->flags & BVHGPU_TRAVERSE_T_SLICE) ? h->tslice.p : nullptr;
@@ -534,6 +615,7 @@ void bvhgpu_hits_destroy(bvhgpu_hits* h) {
     if (h->ctx) { (void)hipSetDevice(h->ctx->device); (void)hipStreamSynchronize(h->ctx->stream); }
     h->counts.release(); h->offsets.release(); h->pool.release(); h->pool_t.release();
     h->indices.release(); h->tslice.release(); h->blocksums.release(); h->ctr.release();
+    h->isect.release(); h->closest.release(); h->closest_prim.release();
     delete h;
 }
 

@@ -73,6 +73,8 @@ struct bvhgpu_tree {
     bvhgpu::DevBuf shape_node;  // n * u32
     bvhgpu::DevBuf flat;        // n_flat * Flat     (reference layout, for export/parity)
     bvhgpu::DevBuf trav;        // n_trav * TravNode (engine layout, what traversal reads)
+    bvhgpu::DevBuf tris;        // n * 9 T triangle vertices (optional: triangle stage)
+    bool has_tris = false;
     bvhgpu::DevBuf slot_entry;  // TopCfg::SLOTS * u32: traversal entry held in LDS slot s (NONE = unused slot)
     bvhgpu::DevBuf node_slot;   // n_nodes * u16: LDS slot of the node's traversal entry (SLOT_NONE = not resident)
     // build scratch (kept for rebuild)
@@ -101,6 +103,9 @@ struct bvhgpu_hits {
     bvhgpu::DevBuf pool_t;   // 2 T per record
     bvhgpu::DevBuf indices;  // total u32
     bvhgpu::DevBuf tslice;   // total * 2 T
+    bvhgpu::DevBuf isect;    // total * 3 T: Intersection{distance,u,v} per candidate (TRIANGLES)
+    bvhgpu::DevBuf closest;  // n_rays * 3 T (CLOSEST)
+    bvhgpu::DevBuf closest_prim;  // n_rays u32
     bvhgpu::DevBuf blocksums;
     bvhgpu::DevBuf ctr;      // [0] pool count (u64) [1] visited [2] leaf_visits [3] device_steps [4] ray ticket
     size_t pool_cap = 0;
@@ -116,6 +121,8 @@ template <typename T> void flatten_tree(bvhgpu_tree* t);
 template <typename T>
 void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, unsigned flags,
                     bvhgpu_hits* h);
+template <typename T>
+void ray_triangle_pairs(bvhgpu_ctx* ctx, const typename Traits<T>::Ray* rays_dev, const T* tris_dev, size_t n, T* out_dev);
 template <typename T>
 void rays_new(bvhgpu_ctx* ctx, const T* origins_dev, const T* dirs_dev, size_t n, typename Traits<T>::Ray* out_dev);
 void gen_rays_f32(bvhgpu_ctx* ctx, uint64_t first, size_t n, const float bounds[6], bvhgpu_ray_f32* out_dev);

@@ -1,18 +1,31 @@
 // traverse.hip — <FlatBvh as BoundingHierarchy>::traverse (src/flat_bvh.rs:396-431) for a BATCH of
-// rays, plus Ray::new (src/ray/ray_impl.rs:70-80) and the bench ray stream (src/testbase.rs:687-691).
+// rays, the triangle stage that follows it in the reference's harness (Ray::intersects_triangle,
+// src/ray/ray_impl.rs:154-213; loop src/testbase.rs:826-836), Ray::new (src/ray/ray_impl.rs:70-80) and
+// the bench ray stream (src/testbase.rs:687-691).
 //
-// One ray per lane walks the engine's folded pre-order array (common.hpp TravNode): slab test
+// A lane walks the engine's folded pre-order array (common.hpp TravNode): slab test
 // (src/ray/intersect_default.rs:16-37) → hit: i+1, miss: exit.  The walk visits boxes in exactly the
 // reference's order, so each ray's shapes come out in the reference's (DFS, left-first) order.
 // Variable-length output (Vec<&Shape> per ray) becomes CSR in three steps:
 //   1. walk: every reported shape is appended to a pool as (ray, k, shape) with k = the ray's running
-//      hit count; one wave-aggregated atomic per wave-iteration that has hits; counts[ray] = k_end;
+//      hit count (per-wave chunks of the pool: one global atomic per 64 records); counts[ray] = k_end;
 //   2. exclusive scan of counts → offsets (reduce / scan-of-sums / rescan, 3 small kernels);
-//   3. indices[offsets[ray] + k] = shape.
-// If the pool was too small the total is still exact; the host grows it and replays.
+//   3. indices[offsets[ray] + k] = shape  (+ per-hit values: t-slice or triangle Intersection).
+// If the pool was too small the totals are still exact; the host grows it and replays.
+// Two walk kernels: k_traverse (one ray per lane per launch; small batches) and k_traverse_lds (persistent
+// workgroups, top of the tree resident in LDS, ray refill; large batches).
 #include "engine.hpp"
 
 namespace bvhgpu {
+
+// what a walk produces besides the CSR of shape indices
+enum : int {
+    MODE_INDICES = 0,   // Vec<&Shape> only
+    MODE_T_SLICE = 1,   // + Ray::intersection_slice_for_aabb per hit (2 scalars)
+    MODE_TRIANGLES = 2, // + Ray::intersects_triangle per hit: Intersection{distance,u,v} (3 scalars)
+    MODE_CLOSEST = 3    // no CSR: per ray the candidate triangle with the smallest distance
+};
+template <int MODE> struct ModeVals { static constexpr int N = MODE == MODE_T_SLICE ? 2 : (MODE == MODE_TRIANGLES ? 3 : 0); };
 
 // ---- node fetch: two (f32) / four (f64) 16-byte loads per lane -------------------------------
 template <typename T> struct NodeRegs { T mn[3], mx[3]; uint32_t exit, shape; };
@@ -39,28 +52,176 @@ __device__ __forceinline__ NodeRegs<double> load_node(const TravNode<double>* p)
 
 struct HitRec { uint32_t ray, k, shape; };
 
-// ctr layout (u64): [0] pool appends  [1] device steps  [2] leaf-entry steps
-template <typename T, bool WITH_T, bool STATS>
+// everything a walk kernel writes
+template <typename T> struct WalkOut {
+    uint32_t* counts;            // per ray: number of shapes returned
+    HitRec* pool;                // hit records in arrival order
+    T* pool_v;                   // ModeVals::N scalars per record
+    unsigned long long pool_cap;
+    unsigned long long* ctr;     // [0] pool slots taken [1] device steps [2] leaf-entry steps [4] wave steps [5] candidates (closest mode)
+    const T* tris;               // n x 9 vertices (triangle modes)
+    T* closest;                  // per ray {distance,u,v} (closest mode)
+    uint32_t* closest_prim;      // per ray shape index or NONE
+};
+
+// ---- Ray::intersects_triangle (ray_impl.rs:154-213), Möller–Trumbore with back-face culling.  Same
+//      sequence of IEEE operations as the reference: nalgebra cross = (ay*bz - az*by, az*bx - ax*bz,
+//      ax*by - ay*bx), dot = (a0*b0 + a1*b1) + a2*b2, no contraction.  Returns the Intersection fields.
+template <typename T> __device__ __forceinline__ void cross3(const T a[3], const T b[3], T out[3]) {
+    T p0 = a[1] * b[2], q0 = a[2] * b[1];
+    T p1 = a[2] * b[0], q1 = a[0] * b[2];
+    T p2 = a[0] * b[1], q2 = a[1] * b[0];
+    out[0] = p0 - q0; out[1] = p1 - q1; out[2] = p2 - q2;
+}
+template <typename T> __device__ __forceinline__ T dot3(const T a[3], const T b[3]) {
+    T x = a[0] * b[0], y = a[1] * b[1], z = a[2] * b[2];
+    T s = x + y;
+    return s + z;
+}
+template <typename T>
+__device__ __forceinline__ void ray_triangle(const T o[3], const T d[3], const T* __restrict__ tri, T out[3]) {
+    const T a[3] = {tri[0], tri[1], tri[2]};
+    T ab[3], ac[3], uvec[3], ao[3], vvec[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ab[k] = tri[3 + k] - a[k]; ac[k] = tri[6 + k] - a[k]; }   // :170-171
+    cross3<T>(d, ac, uvec);                                                                  // :176
+    const T det = dot3<T>(ab, uvec);                                                         // :181
+    out[0] = Traits<T>::inf(); out[1] = 0; out[2] = 0;
+    if (det < Traits<T>::eps()) return;                                                      // :186-188
+    const T inv_det = (T)1 / det;                                                            // :190
+#pragma unroll
+    for (int k = 0; k < 3; k++) ao[k] = o[k] - a[k];                                         // :193
+    const T u = dot3<T>(ao, uvec) * inv_det;                                                 // :196
+    out[1] = u;
+    if (!(u >= (T)0 && u <= (T)1)) return;                                                   // :199-201
+    cross3<T>(ao, ab, vvec);                                                                 // :204
+    const T v = dot3<T>(d, vvec) * inv_det;                                                  // :207
+    out[2] = v;
+    if (v < (T)0 || u + v > (T)1) return;                                                    // :209-211
+    const T dist = dot3<T>(ac, vvec) * inv_det;                                              // :213
+    if (dist > Traits<T>::eps()) out[0] = dist;                                              // :215-219
+}
+
+// ---- per-lane ray state
+template <typename T, int MODE> struct LaneRay {
+    T o[3], inv[3];
+    T d[MODE >= MODE_TRIANGLES ? 3 : 1];   // direction: only the triangle stage needs it
+    T best[MODE == MODE_CLOSEST ? 3 : 1];  // closest Intersection so far
+    uint32_t best_prim;
+    uint32_t r, cnt;
+    bool fin;                              // all components finite → NaN-free slab test is exact
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { o[k] = 0; inv[k] = 0; }
+        d[0] = 0; best[0] = 0; best_prim = NONE; r = NONE; cnt = 0; fin = true;
+    }
+    __device__ __forceinline__ void load(const typename Traits<T>::Ray* __restrict__ rays, uint32_t ray) {
+        const typename Traits<T>::Ray* rp = rays + ray;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { o[k] = rp->o[k]; inv[k] = rp->inv[k]; }
+        if (MODE >= MODE_TRIANGLES) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) d[k] = rp->d[k];
+        }
+        if (MODE == MODE_CLOSEST) { best[0] = Traits<T>::inf(); best[1] = 0; best[2] = 0; }
+        best_prim = NONE; r = ray; cnt = 0;
+        fin = ray_is_finite<T>(o, inv);
+    }
+    // the ray has left the tree: its Vec / closest hit is complete
+    __device__ __forceinline__ void retire(const WalkOut<T>& w) {
+        if (MODE == MODE_CLOSEST) {
+            w.closest[3 * (size_t)r] = best[0]; w.closest[3 * (size_t)r + 1] = best[1]; w.closest[3 * (size_t)r + 2] = best[2];
+            w.closest_prim[r] = best_prim;
+        } else {
+            w.counts[r] = cnt;
+        }
+        r = NONE;
+    }
+};
+
+constexpr uint32_t POOL_CHUNK = 64;  // >= 64: one wave-step reports at most 64 hits
+// wave-uniform cursor into this wave's current chunk of the hit pool
+struct PoolCursor { unsigned long long pos = 0; uint32_t left = 0; };
+
+// A leaf box was hit (rec) in some lanes of the wave: do what the MODE asks for with the shape.
+template <typename T, int MODE>
+__device__ __forceinline__ void report(bool rec, uint32_t shape, T t0, T t1, LaneRay<T, MODE>& ray, const WalkOut<T>& w,
+                                       PoolCursor& pc, int lane, unsigned long long lt) {
+    const unsigned long long m = __ballot(rec);
+    if (!m) return;
+    T vals[3] = {t0, t1, 0};
+    if (MODE >= MODE_TRIANGLES && rec) ray_triangle<T>(ray.o, ray.d, w.tris + 9 * (size_t)shape, vals);
+    if (MODE == MODE_CLOSEST) {
+        if (rec) {
+            if (vals[0] < ray.best[0]) { ray.best[0] = vals[0]; ray.best[1] = vals[1]; ray.best[2] = vals[2]; ray.best_prim = shape; }
+            ray.cnt++;
+        }
+        return;
+    }
+    constexpr int NV = ModeVals<MODE>::N;
+    const uint32_t h = (uint32_t)__popcll(m);
+    if (h > pc.left) {   // wave-uniform: start a new chunk, invalidate what is left of the old one
+        if ((uint32_t)lane < pc.left && pc.pos + lane < w.pool_cap) w.pool[pc.pos + lane].ray = NONE;
+        unsigned int blo = 0, bhi = 0;
+        if (lane == 0) {
+            unsigned long long b = atomicAdd(&w.ctr[0], (unsigned long long)POOL_CHUNK);
+            blo = (unsigned int)b; bhi = (unsigned int)(b >> 32);
+        }
+        blo = __builtin_amdgcn_readfirstlane(blo); bhi = __builtin_amdgcn_readfirstlane(bhi);
+        pc.pos = ((unsigned long long)bhi << 32) | blo;
+        pc.left = POOL_CHUNK;
+    }
+    if (rec) {
+        const unsigned long long slot = pc.pos + __popcll(m & lt);
+        if (slot < w.pool_cap) {
+            HitRec hr; hr.ray = ray.r; hr.k = ray.cnt; hr.shape = shape;
+            w.pool[slot] = hr;
+#pragma unroll
+            for (int k = 0; k < NV; k++) w.pool_v[NV * slot + k] = vals[k];
+        }
+        ray.cnt++;
+    }
+    pc.pos += h; pc.left -= h;
+}
+
+template <typename T, int MODE>
+__device__ __forceinline__ void walk_epilogue(const WalkOut<T>& w, PoolCursor& pc, int lane, bool stats,
+                                              unsigned long long steps, unsigned long long leaf_steps,
+                                              unsigned long long wsteps, unsigned long long cands) {
+    if (MODE != MODE_CLOSEST && (uint32_t)lane < pc.left && pc.pos + lane < w.pool_cap) w.pool[pc.pos + lane].ray = NONE;
+    if (stats) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            steps += __shfl_down(steps, d);
+            leaf_steps += __shfl_down(leaf_steps, d);
+            cands += __shfl_down(cands, d);
+        }
+        if (lane == 0) {
+            atomicAdd(&w.ctr[1], steps); atomicAdd(&w.ctr[2], leaf_steps); atomicAdd(&w.ctr[4], wsteps);
+            if (MODE == MODE_CLOSEST) atomicAdd(&w.ctr[5], cands);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one ray per lane per launch
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MODE, bool STATS>
 __global__ __launch_bounds__(256) void k_traverse(const TravNode<T>* __restrict__ nodes, uint32_t n_trav,
                                                   const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_rays,
-                                                  uint32_t* __restrict__ counts, HitRec* __restrict__ pool,
-                                                  T* __restrict__ pool_t, unsigned long long pool_cap,
-                                                  unsigned long long* __restrict__ ctr) {
+                                                  WalkOut<T> w) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = lane_id();
     const unsigned long long lt = lanemask_lt();
     const bool active = r < n_rays;
-    T o[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
-    if (active) {
-        const typename Traits<T>::Ray* rp = rays + r;
-#pragma unroll
-        for (int k = 0; k < 3; k++) { o[k] = rp->o[k]; inv[k] = rp->inv[k]; }
-    }
+    LaneRay<T, MODE> ray;
+    ray.clear();
+    if (active) ray.load(rays, r);
     uint32_t i = active ? 0u : n_trav;
-    uint32_t cnt = 0;
+    PoolCursor pc;
     unsigned long long steps = 0, leaf_steps = 0, wsteps = 0;
     // wave-uniform: every ray of this wave is finite → the NaN-free slab test (common.hpp) is exact
-    const bool fast = !WITH_T && !__any(active && !ray_is_finite<T>(o, inv));
+    const bool fast = MODE != MODE_T_SLICE && !__any(active && !ray.fin);
     while (true) {
         const bool run = i < n_trav;
         if (!__any(run)) break;
@@ -70,158 +231,35 @@ __global__ __launch_bounds__(256) void k_traverse(const TravNode<T>* __restrict_
         if (STATS) wsteps++;
         if (run) {
             const NodeRegs<T> nd = load_node(nodes + i);
-            const bool hit = fast ? slab_hit_finite<T>(o, inv, nd.mn, nd.mx) : slab_hit<T>(o, inv, nd.mn, nd.mx, t0, t1);
+            const bool hit = fast ? slab_hit_finite<T>(ray.o, ray.inv, nd.mn, nd.mx)
+                                  : slab_hit<T>(ray.o, ray.inv, nd.mn, nd.mx, t0, t1);
             shape = nd.shape;
             const bool leaf = trav_is_leaf(shape);
             rec = hit && leaf;
             i = hit ? i + 1 : nd.exit;   // a leaf's exit IS i+1
             if (STATS) { steps++; leaf_steps += leaf ? 1 : 0; }
         }
-        const unsigned long long m = __ballot(rec);
-        if (m) {
-            unsigned int blo = 0, bhi = 0;
-            if (lane == 0) {
-                unsigned long long b = atomicAdd(&ctr[0], (unsigned long long)__popcll(m));
-                blo = (unsigned int)b; bhi = (unsigned int)(b >> 32);
-            }
-            blo = __shfl(blo, 0); bhi = __shfl(bhi, 0);
-            if (rec) {
-                const unsigned long long slot = (((unsigned long long)bhi << 32) | blo) + __popcll(m & lt);
-                if (slot < pool_cap) {
-                    HitRec h; h.ray = r; h.k = cnt; h.shape = shape;
-                    pool[slot] = h;
-                    if (WITH_T) { pool_t[2 * slot] = t0; pool_t[2 * slot + 1] = t1; }
-                }
-                cnt++;
-            }
-        }
+        report<T, MODE>(rec, shape, t0, t1, ray, w, pc, lane, lt);
     }
-    if (active) counts[r] = cnt;
-    if (STATS) {
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            steps += __shfl_down(steps, d);
-            leaf_steps += __shfl_down(leaf_steps, d);
-        }
-        if (lane == 0) { atomicAdd(&ctr[1], steps); atomicAdd(&ctr[2], leaf_steps); atomicAdd(&ctr[4], wsteps); }
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// persistent variant: a wave owns a contiguous range of rays and keeps its 64 lanes busy — a lane whose
-// ray has left the tree takes the next ray of the range (wave-uniform cursor, no atomics, no LDS).
-// With one ray per lane for the whole launch a wave runs until its LONGEST ray ends (E[max of 64] is
-// ~2.7x the mean walk length on the 120k-triangle scene); with refill a wave-step does useful work in
-// almost every lane.  Hit records go to the pool in per-wave CHUNKs: one global atomic per 64 records
-// instead of one per wave-step with a hit (hit-heavy scenes would serialise on that one address);
-// the unused tail of a chunk is marked invalid (ray == NONE) for k_hits_scatter.
-// ------------------------------------------------------------------------------------------------
-constexpr uint32_t POOL_CHUNK = 64;  // >= 64: one wave-step reports at most 64 hits
-
-template <typename T, bool WITH_T, bool STATS>
-__global__ __launch_bounds__(256) void k_traverse_persist(const TravNode<T>* __restrict__ nodes, uint32_t n_trav,
-                                                          const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_rays,
-                                                          uint32_t rays_per_wave, uint32_t refill_min,
-                                                          uint32_t* __restrict__ counts, HitRec* __restrict__ pool,
-                                                          T* __restrict__ pool_t, unsigned long long pool_cap,
-                                                          unsigned long long* __restrict__ ctr) {
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = lane_id();
-    const unsigned long long lt = lanemask_lt();
-    const unsigned long long b0 = (unsigned long long)wave * rays_per_wave;
-    const unsigned long long b1 = b0 + rays_per_wave;
-    uint32_t next = (uint32_t)(b0 < n_rays ? b0 : n_rays);      // wave-uniform cursor into the range
-    const uint32_t end = (uint32_t)(b1 < n_rays ? b1 : n_rays);
-    next = __builtin_amdgcn_readfirstlane(next);
-    T o[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
-    uint32_t r = NONE, i = n_trav, cnt = 0;
-    bool fin = true;               // this lane's ray has only finite components (NaN-free slab test is exact)
-    unsigned long long cpos = 0;   // wave-uniform: next free slot of this wave's pool chunk
-    uint32_t cleft = 0;            // wave-uniform: free slots left in it
-    unsigned long long steps = 0, leaf_steps = 0, wsteps = 0;
-    while (true) {
-        bool run = i < n_trav;
-        const unsigned long long idle = __ballot(!run);
-        if (idle) {
-            if (!run && r != NONE) { counts[r] = cnt; r = NONE; }   // the ray's Vec is complete
-            const uint32_t nidle = (uint32_t)__popcll(idle);
-            if (next < end && nidle >= refill_min) {
-                const uint32_t mine = next + (uint32_t)__popcll(idle & lt);
-                if (!run && mine < end) {
-                    r = mine;
-                    const typename Traits<T>::Ray* rp = rays + r;
-#pragma unroll
-                    for (int k = 0; k < 3; k++) { o[k] = rp->o[k]; inv[k] = rp->inv[k]; }
-                    i = 0; cnt = 0; run = true;
-                    fin = ray_is_finite<T>(o, inv);
-                }
-                next = (end - next) < nidle ? end : next + nidle;
-            }
-            if (!__any(run)) break;   // nothing in flight and the range is exhausted
-        }
-        bool rec = false;
-        uint32_t shape = NONE;
-        T t0 = 0, t1 = 0;
-        if (STATS) wsteps++;
-        const bool fast = !WITH_T && !__any(run && !fin);   // wave-uniform
-        if (run) {
-            const NodeRegs<T> nd = load_node(nodes + i);
-            const bool hit = fast ? slab_hit_finite<T>(o, inv, nd.mn, nd.mx) : slab_hit<T>(o, inv, nd.mn, nd.mx, t0, t1);
-            shape = nd.shape;
-            const bool leaf = trav_is_leaf(shape);
-            rec = hit && leaf;
-            i = hit ? i + 1 : nd.exit;   // a leaf's exit IS i+1
-            if (STATS) { steps++; leaf_steps += leaf ? 1 : 0; }
-        }
-        const unsigned long long m = __ballot(rec);
-        if (m) {
-            const uint32_t h = (uint32_t)__popcll(m);
-            if (h > cleft) {   // wave-uniform: start a new chunk, invalidate what is left of the old one
-                if ((uint32_t)lane < cleft && cpos + lane < pool_cap) pool[cpos + lane].ray = NONE;
-                unsigned int blo = 0, bhi = 0;
-                if (lane == 0) {
-                    unsigned long long b = atomicAdd(&ctr[0], (unsigned long long)POOL_CHUNK);
-                    blo = (unsigned int)b; bhi = (unsigned int)(b >> 32);
-                }
-                blo = __builtin_amdgcn_readfirstlane(blo); bhi = __builtin_amdgcn_readfirstlane(bhi);
-                cpos = ((unsigned long long)bhi << 32) | blo;
-                cleft = POOL_CHUNK;
-            }
-            if (rec) {
-                const unsigned long long slot = cpos + __popcll(m & lt);
-                if (slot < pool_cap) {
-                    HitRec hr; hr.ray = r; hr.k = cnt; hr.shape = shape;
-                    pool[slot] = hr;
-                    if (WITH_T) { pool_t[2 * slot] = t0; pool_t[2 * slot + 1] = t1; }
-                }
-                cnt++;
-            }
-            cpos += h; cleft -= h;
-        }
-    }
-    if ((uint32_t)lane < cleft && cpos + lane < pool_cap) pool[cpos + lane].ray = NONE;
-    if (STATS) {
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            steps += __shfl_down(steps, d);
-            leaf_steps += __shfl_down(leaf_steps, d);
-        }
-        if (lane == 0) { atomicAdd(&ctr[1], steps); atomicAdd(&ctr[2], leaf_steps); atomicAdd(&ctr[4], wsteps); }
-    }
+    const unsigned long long cands = active ? ray.cnt : 0;
+    if (active) ray.retire(w);
+    walk_epilogue<T, MODE>(w, pc, lane, STATS, steps, leaf_steps, wsteps, cands);
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS-resident top of the tree.  On the 120k-triangle scene 85 % of all box tests touch the first 12
-// levels of the tree (4095 entries) and the vector L1 — one tag lookup per lane per 16-byte load for
-// these scattered reads — is the unit that saturates.  One 1024-thread workgroup per CU copies the
-// entries whose heap number is below TopCfg<T>::SLOTS into LDS (split into 16-byte planes so that a
-// ds_read_b128 of 16 lanes spreads over all 16 bank quads) and every lane tracks the slot of its
-// current entry: descend → 2*slot, miss → the exit's slot carried in the entry's spare word.  A lane
-// outside the resident set (deep in the tree, or after a leaf) reads HBM/L2 as before and re-enters
-// the resident set through the same word.  Waves are persistent with ray refill as above.
+// LDS-resident top of the tree.  On the 120k-triangle scene 72 % of all box tests touch the first 11
+// levels of the tree (2047 entries) and the vector L1 — one tag lookup per lane per 16-byte load for
+// these scattered reads — is the unit that saturates (measured: ~1 lane-access per clock per CU).  A
+// 1024-thread workgroup copies the entries whose heap number is below K into LDS (split into 16-byte
+// planes so that a ds_read_b128 of 16 lanes spreads over all 16 bank quads; 2 workgroups of 64 KB per
+// CU) and every lane tracks the slot of its current entry: descend → 2*slot, miss → the exit's slot
+// carried in the entry's spare word.  A lane outside the resident set (deep in the tree, or after a
+// leaf) reads L2 as before and re-enters the resident set through the same word.
+// The workgroup's waves draw rays from ONE cursor in LDS (a wave-aggregated ds_add per refill phase), so
+// the tail of a launch is the tail of a workgroup's ray range, not of every wave's.  Retiring and
+// refilling lanes is kept OUT of the walk loop: LDS_INNER lean steps (~38 VALU each), then one refill
+// phase; a lane whose ray ends mid-way idles for at most LDS_INNER-1 steps.
 // ------------------------------------------------------------------------------------------------
-// LDS image of the resident entries: 16-byte planes of K slots each (K is a launch parameter)
 template <typename T> struct TopLds;
 template <> struct TopLds<float> {
     static constexpr uint32_t BYTES_PER_SLOT = 32;
@@ -268,19 +306,12 @@ template <> struct TopLds<double> {
 constexpr int LDS_THREADS = 1024;
 constexpr int LDS_INNER = 8;   // walk steps between two refill phases
 
-// The workgroup's 16 waves draw rays from ONE cursor in LDS (a wave-aggregated ds_add per refill phase),
-// so the tail of a launch is the tail of a workgroup's ray range, not of every wave's.  Retiring and
-// refilling lanes is kept OUT of the walk loop: LDS_INNER lean steps (~38 VALU each), then one refill
-// phase; a lane whose ray ends mid-way idles for at most LDS_INNER-1 steps.
-template <typename T, bool WITH_T, bool STATS>
+template <typename T, int MODE, bool STATS>
 __global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>* __restrict__ nodes, uint32_t n_trav,
                                                                const uint32_t* __restrict__ slot_entry, uint32_t K,
                                                                uint32_t first_slot,
                                                                const typename Traits<T>::Ray* __restrict__ rays,
-                                                               uint32_t n_rays, uint32_t rays_per_wg,
-                                                               uint32_t* __restrict__ counts, HitRec* __restrict__ pool,
-                                                               T* __restrict__ pool_t, unsigned long long pool_cap,
-                                                               unsigned long long* __restrict__ ctr) {
+                                                               uint32_t n_rays, uint32_t rays_per_wg, WalkOut<T> w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t& s_next = *reinterpret_cast<uint32_t*>(smem);
     TopLds<T> top(smem + 16, K);
@@ -297,19 +328,18 @@ __global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>*
 
     const int lane = lane_id();
     const unsigned long long lt = lanemask_lt();
-    T o[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
-    uint32_t r = NONE, i = n_trav, cnt = 0, slot = SLOT_NONE;
-    bool fin = true;
+    LaneRay<T, MODE> ray;
+    ray.clear();
+    uint32_t i = n_trav, slot = SLOT_NONE;
     bool exhausted = wg_begin >= wg_end;   // wave-uniform: the workgroup's range has been handed out
-    unsigned long long cpos = 0;
-    uint32_t cleft = 0;
-    unsigned long long steps = 0, leaf_steps = 0, wsteps = 0;
+    PoolCursor pc;
+    unsigned long long steps = 0, leaf_steps = 0, wsteps = 0, cands = 0;
     while (true) {
         // ---- refill phase
         bool run = i < n_trav;
         const unsigned long long idle = __ballot(!run);
         if (idle) {
-            if (!run && r != NONE) { counts[r] = cnt; r = NONE; }
+            if (!run && ray.r != NONE) { cands += ray.cnt; ray.retire(w); }
             if (!exhausted) {
                 const uint32_t nidle = (uint32_t)__popcll(idle);
                 uint32_t base = 0;
@@ -317,18 +347,14 @@ __global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>*
                 base = __builtin_amdgcn_readfirstlane(base);
                 const uint32_t mine = base + (uint32_t)__popcll(idle & lt);
                 if (!run && base < wg_end && mine < wg_end) {
-                    r = mine;
-                    const typename Traits<T>::Ray* rp = rays + mine;
-#pragma unroll
-                    for (int k = 0; k < 3; k++) { o[k] = rp->o[k]; inv[k] = rp->inv[k]; }
-                    i = 0; cnt = 0; slot = first_slot; run = true;
-                    fin = ray_is_finite<T>(o, inv);
+                    ray.load(rays, mine);
+                    i = 0; slot = first_slot; run = true;
                 }
                 exhausted = base >= wg_end || (wg_end - base) <= nidle;
             }
             if (!__any(run)) break;
         }
-        const bool fast = !WITH_T && !__any(run && !fin);   // wave-uniform
+        const bool fast = MODE != MODE_T_SLICE && !__any(run && !ray.fin);   // wave-uniform
         // ---- LDS_INNER walk steps
         for (int s = 0; s < LDS_INNER; s++) {
             bool rec = false;
@@ -339,7 +365,8 @@ __global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>*
                 NodeRegs<T> nd;
                 if (slot < K) nd = top.load(slot);
                 else nd = load_node(nodes + i);
-                const bool hit = fast ? slab_hit_finite<T>(o, inv, nd.mn, nd.mx) : slab_hit<T>(o, inv, nd.mn, nd.mx, t0, t1);
+                const bool hit = fast ? slab_hit_finite<T>(ray.o, ray.inv, nd.mn, nd.mx)
+                                      : slab_hit<T>(ray.o, ray.inv, nd.mn, nd.mx, t0, t1);
                 shape = nd.shape;
                 const bool leaf = trav_is_leaf(shape);
                 rec = hit && leaf;
@@ -349,42 +376,10 @@ __global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>*
                 slot = descend ? child : (leaf ? SLOT_NONE : (shape & 0xFFFFu));
                 if (STATS) { steps++; leaf_steps += leaf ? 1 : 0; }
             }
-            const unsigned long long m = __ballot(rec);
-            if (m) {
-                const uint32_t h = (uint32_t)__popcll(m);
-                if (h > cleft) {
-                    if ((uint32_t)lane < cleft && cpos + lane < pool_cap) pool[cpos + lane].ray = NONE;
-                    unsigned int blo = 0, bhi = 0;
-                    if (lane == 0) {
-                        unsigned long long b = atomicAdd(&ctr[0], (unsigned long long)POOL_CHUNK);
-                        blo = (unsigned int)b; bhi = (unsigned int)(b >> 32);
-                    }
-                    blo = __builtin_amdgcn_readfirstlane(blo); bhi = __builtin_amdgcn_readfirstlane(bhi);
-                    cpos = ((unsigned long long)bhi << 32) | blo;
-                    cleft = POOL_CHUNK;
-                }
-                if (rec) {
-                    const unsigned long long pslot = cpos + __popcll(m & lt);
-                    if (pslot < pool_cap) {
-                        HitRec hr; hr.ray = r; hr.k = cnt; hr.shape = shape;
-                        pool[pslot] = hr;
-                        if (WITH_T) { pool_t[2 * pslot] = t0; pool_t[2 * pslot + 1] = t1; }
-                    }
-                    cnt++;
-                }
-                cpos += h; cleft -= h;
-            }
+            report<T, MODE>(rec, shape, t0, t1, ray, w, pc, lane, lt);
         }
     }
-    if ((uint32_t)lane < cleft && cpos + lane < pool_cap) pool[cpos + lane].ray = NONE;
-    if (STATS) {
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
-            steps += __shfl_down(steps, d);
-            leaf_steps += __shfl_down(leaf_steps, d);
-        }
-        if (lane == 0) { atomicAdd(&ctr[1], steps); atomicAdd(&ctr[2], leaf_steps); atomicAdd(&ctr[4], wsteps); }
-    }
+    walk_epilogue<T, MODE>(w, pc, lane, STATS, steps, leaf_steps, wsteps, cands);
 }
 
 // ---- exclusive scan of per-ray counts ----------------------------------------------------------
@@ -457,11 +452,11 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__
     if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = (uint32_t)(*total);
 }
 
-template <typename T, bool WITH_T>
-__global__ __launch_bounds__(256) void k_hits_scatter(const HitRec* __restrict__ pool, const T* __restrict__ pool_t,
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void k_hits_scatter(const HitRec* __restrict__ pool, const T* __restrict__ pool_v,
                                                       const unsigned long long* __restrict__ ctr,
                                                       unsigned long long pool_cap, const uint32_t* __restrict__ offsets,
-                                                      uint32_t* __restrict__ indices, T* __restrict__ tslice) {
+                                                      uint32_t* __restrict__ indices, T* __restrict__ vals) {
     const unsigned long long n = ctr[0];
     if (n > pool_cap) return;  // pool overflowed: indices[] is too small as well; the host grows both and replays
     for (unsigned long long j = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; j < n;
@@ -470,28 +465,107 @@ __global__ __launch_bounds__(256) void k_hits_scatter(const HitRec* __restrict__
         if (h.ray == NONE) continue;   // unused tail of a per-wave chunk
         const uint32_t d = offsets[h.ray] + h.k;
         indices[d] = h.shape;
-        if (WITH_T) { tslice[2 * (size_t)d] = pool_t[2 * j]; tslice[2 * (size_t)d + 1] = pool_t[2 * j + 1]; }
+#pragma unroll
+        for (int k = 0; k < NV; k++) vals[NV * (size_t)d + k] = pool_v[NV * j + k];
     }
 }
 
 // ------------------------------------------------------------------------------------------------
+template <typename T, int MODE, bool STATS>
+static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, const WalkOut<T>& w) {
+    bvhgpu_ctx* ctx = t->ctx;
+    hipStream_t st = ctx->stream;
+    const uint32_t n_trav = (uint32_t)t->n_trav;
+    const TravNode<T>* nodes = t->trav.as<TravNode<T>>();
+    // variant 0: one ray per lane per launch; 2: persistent workgroups + LDS-resident top of the tree
+    int variant = ctx->tune[BVHGPU_TUNE_TRAVERSE_VARIANT];
+    if (variant != 0 && (t->slot_entry.p == nullptr || n_rays < (size_t)ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS]))
+        variant = 0;
+    if (variant == 0) {
+        hipLaunchKernelGGL((k_traverse<T, MODE, STATS>), dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, nodes,
+                           n_trav, rays_dev, (uint32_t)n_rays, w);
+        return;
+    }
+    // workgroups of lds_threads that each keep K top-of-tree slots in LDS; as many per CU as 160 KB of LDS
+    // and 32 waves allow
+    const uint32_t lds_threads = (uint32_t)std::min(LDS_THREADS, std::max(64, ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_THREADS] & ~63));
+    const uint32_t K = (uint32_t)std::min<int>((int)TopCfg<T>::SLOTS, std::max(4, ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_SLOTS]));
+    const size_t lds_bytes = 16 + (size_t)K * TopLds<T>::BYTES_PER_SLOT;
+    const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds_bytes, 2048 / lds_threads));
+    const size_t full = (n_rays + WAVE - 1) / WAVE;
+    const uint32_t n_waves = (uint32_t)std::min<size_t>(full, (size_t)ctx->n_cu * wg_per_cu * (lds_threads / WAVE));
+    const dim3 lgrid((n_waves + lds_threads / WAVE - 1) / (lds_threads / WAVE));
+    const uint32_t rpg = (uint32_t)((n_rays + lgrid.x - 1) / lgrid.x);   // rays per workgroup
+    const uint32_t first_slot = t->n >= 2 ? 2u : SLOT_NONE;               // entry 0 is the root's left child (heap number 2)
+    BVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse_lds<T, MODE, STATS>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL((k_traverse_lds<T, MODE, STATS>), lgrid, dim3(lds_threads), lds_bytes, st, nodes, n_trav,
+                       t->slot_entry.as<uint32_t>(), K, first_slot, rays_dev, (uint32_t)n_rays, rpg, w);
+}
+
 template <typename T>
 void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, unsigned flags,
                     bvhgpu_hits* h) {
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
-    const bool with_t = (flags & BVHGPU_TRAVERSE_T_SLICE) != 0;
     const bool stats = (flags & BVHGPU_TRAVERSE_STATS) != 0;
+    const int mode = (flags & BVHGPU_TRAVERSE_CLOSEST) ? MODE_CLOSEST
+                   : (flags & BVHGPU_TRAVERSE_TRIANGLES) ? MODE_TRIANGLES
+                   : (flags & BVHGPU_TRAVERSE_T_SLICE) ? MODE_T_SLICE : MODE_INDICES;
+    const int nv = mode == MODE_T_SLICE ? 2 : (mode == MODE_TRIANGLES ? 3 : 0);
     h->ctx = ctx; h->dtype = Traits<T>::dtype; h->n_rays = n_rays; h->flags = flags; h->total = 0;
     h->stats = bvhgpu_traverse_stats{0, 0, 0, 0, 0};
+    h->ctr.reserve(8 * sizeof(unsigned long long));
+    unsigned long long* pin = reinterpret_cast<unsigned long long*>(ctx->pinned);
+    unsigned long long* ctr = h->ctr.as<unsigned long long>();
+
+    WalkOut<T> w;
+    w.counts = nullptr; w.pool = nullptr; w.pool_v = nullptr; w.pool_cap = 0; w.ctr = ctr;
+    w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr;
+
+#define DISPATCH_WALK()                                                                              \
+    do {                                                                                             \
+        switch (mode) {                                                                              \
+            case MODE_INDICES: if (stats) launch_walk<T, MODE_INDICES, true>(t, rays_dev, n_rays, w);  \
+                               else launch_walk<T, MODE_INDICES, false>(t, rays_dev, n_rays, w); break; \
+            case MODE_T_SLICE: if (stats) launch_walk<T, MODE_T_SLICE, true>(t, rays_dev, n_rays, w);  \
+                               else launch_walk<T, MODE_T_SLICE, false>(t, rays_dev, n_rays, w); break; \
+            case MODE_TRIANGLES: if (stats) launch_walk<T, MODE_TRIANGLES, true>(t, rays_dev, n_rays, w); \
+                                 else launch_walk<T, MODE_TRIANGLES, false>(t, rays_dev, n_rays, w); break; \
+            default: if (stats) launch_walk<T, MODE_CLOSEST, true>(t, rays_dev, n_rays, w);           \
+                     else launch_walk<T, MODE_CLOSEST, false>(t, rays_dev, n_rays, w); break;         \
+        }                                                                                            \
+    } while (0)
+
+    if (mode == MODE_CLOSEST) {   // no CSR: one Intersection + shape per ray
+        h->closest.reserve(std::max<size_t>(n_rays, 1) * 3 * sizeof(T));
+        h->closest_prim.reserve(std::max<size_t>(n_rays, 1) * 4);
+        if (n_rays == 0) return;
+        w.closest = h->closest.as<T>(); w.closest_prim = h->closest_prim.as<uint32_t>();
+        BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));
+        if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
+        DISPATCH_WALK();
+        if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
+        BVH_HIP(hipMemcpyAsync(pin, ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        BVH_HIP(hipStreamSynchronize(st));
+        BVH_HIP(hipGetLastError());
+        if (stats) {
+            const bool one_to_one = t->unfolded || t->n == 1;
+            h->stats.hits = pin[5];
+            h->stats.device_steps = pin[1];
+            h->stats.wave_steps = pin[4];
+            h->stats.visited = one_to_one ? pin[1] : pin[1] + pin[5];
+            h->stats.leaf_visits = one_to_one ? pin[2] : pin[5];
+        }
+        if (ctx->timing) ctx->ev_set |= 4u;
+        return;
+    }
+
     h->counts.reserve((n_rays + 1) * 4);
     h->offsets.reserve((n_rays + 1) * 4);
-    h->ctr.reserve(8 * sizeof(unsigned long long));
     const uint32_t nb = (uint32_t)((n_rays + SCAN_BLOCK - 1) / SCAN_BLOCK);
     h->blocksums.reserve((nb + 1) * sizeof(unsigned long long));
     if (h->pool_cap == 0) h->pool_cap = std::max<size_t>(n_rays, (size_t)1 << 16);
-    unsigned long long* pin = reinterpret_cast<unsigned long long*>(ctx->pinned);
-
     if (n_rays == 0) {
         BVH_HIP(hipMemsetAsync(h->offsets.p, 0, 4, st));
         BVH_HIP(hipStreamSynchronize(st));
@@ -500,62 +574,16 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
     for (int attempt = 0; attempt < 2; attempt++) {
         h->pool.reserve(h->pool_cap * sizeof(HitRec));
         h->indices.reserve(h->pool_cap * 4);
-        if (with_t) {
-            h->pool_t.reserve(h->pool_cap * 2 * sizeof(T));
-            h->tslice.reserve(h->pool_cap * 2 * sizeof(T));
+        if (nv) {
+            h->pool_t.reserve(h->pool_cap * nv * sizeof(T));
+            (mode == MODE_T_SLICE ? h->tslice : h->isect).reserve(h->pool_cap * nv * sizeof(T));
         }
-        unsigned long long* ctr = h->ctr.as<unsigned long long>();
         BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));
-        const uint32_t n_trav = (uint32_t)t->n_trav;
-        const dim3 grid((unsigned)((n_rays + 255) / 256)), block(256);
-        const TravNode<T>* nodes = t->trav.as<TravNode<T>>();
-        uint32_t* counts = h->counts.as<uint32_t>();
-        HitRec* pool = h->pool.as<HitRec>();
-        T* pool_t = h->pool_t.as<T>();
         const unsigned long long cap = h->pool_cap;
+        w.counts = h->counts.as<uint32_t>(); w.pool = h->pool.as<HitRec>(); w.pool_v = h->pool_t.as<T>(); w.pool_cap = cap;
+        uint32_t* counts = w.counts;
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
-// launch geometry.  variant 0: one ray per lane per launch; 1: persistent waves with ray refill;
-        // 2: persistent + LDS-resident top of the tree (one 1024-thread workgroup per CU)
-        int variant = ctx->tune[BVHGPU_TUNE_TRAVERSE_VARIANT];
-        if (variant == 2 && (t->slot_entry.p == nullptr || n_rays < (size_t)ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS]))
-            variant = 0;
-        const bool persist = variant != 0;
-        const size_t full = (n_rays + WAVE - 1) / WAVE;
-        // variant 2 geometry: workgroups of lds_threads that each keep K top-of-tree slots in LDS; as many
-        // workgroups per CU as 160 KB of LDS and 32 waves allow
-        const uint32_t lds_threads = (uint32_t)std::min(LDS_THREADS, std::max(64, ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_THREADS] & ~63));
-        const uint32_t K = (uint32_t)std::min<int>((int)TopCfg<T>::SLOTS, std::max(4, ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_SLOTS]));
-        const size_t lds_bytes = 16 + (size_t)K * TopLds<T>::BYTES_PER_SLOT;
-        const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds_bytes, 2048 / lds_threads));
-        const uint32_t wpc = variant == 2 ? wg_per_cu * lds_threads / WAVE
-                                          : (uint32_t)std::max(1, ctx->tune[BVHGPU_TUNE_TRAVERSE_WAVES_PER_CU]);
-        const uint32_t n_waves = (uint32_t)std::min<size_t>(full, (size_t)ctx->n_cu * wpc);
-        const uint32_t rpw = (uint32_t)((n_rays + n_waves - 1) / n_waves);
-        const uint32_t refill_min = (uint32_t)std::min(64, std::max(1, ctx->tune[BVHGPU_TUNE_TRAVERSE_REFILL_MIN]));
-        const dim3 pgrid((n_waves + 3) / 4);
-        const dim3 lgrid((n_waves + lds_threads / WAVE - 1) / (lds_threads / WAVE));
-        const uint32_t first_slot = t->n >= 2 ? 2u : SLOT_NONE;   // entry 0 is the root's left child (heap number 2)
-        const uint32_t* slot_entry = t->slot_entry.as<uint32_t>();
-        const uint32_t rpg = (uint32_t)((n_rays + lgrid.x - 1) / lgrid.x);   // rays per workgroup (variant 2)
-#define LAUNCH_TRAV(WT, STT)                                                                                               \
-    do {                                                                                                                   \
-        if (variant == 2)                                                                                                  \
-        {                                                                                                                  \
-            BVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse_lds<T, WT, STT>),                        \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                      \
-            hipLaunchKernelGGL((k_traverse_lds<T, WT, STT>), lgrid, dim3(lds_threads), lds_bytes, st, nodes, n_trav,       \
-                               slot_entry, K, first_slot, rays_dev, (uint32_t)n_rays, rpg, counts, pool, pool_t, cap, ctr);\
-        }                                                                                                                  \
-        else if (variant == 1)                                                                                             \
-            hipLaunchKernelGGL((k_traverse_persist<T, WT, STT>), pgrid, block, 0, st, nodes, n_trav, rays_dev,             \
-                               (uint32_t)n_rays, rpw, refill_min, counts, pool, pool_t, cap, ctr);                         \
-        else                                                                                                               \
-            hipLaunchKernelGGL((k_traverse<T, WT, STT>), grid, block, 0, st, nodes, n_trav, rays_dev, (uint32_t)n_rays,    \
-                               counts, pool, pool_t, cap, ctr);                                                            \
-    } while (0)
-        if (with_t) { if (stats) LAUNCH_TRAV(true, true); else LAUNCH_TRAV(true, false); }
-        else { if (stats) LAUNCH_TRAV(false, true); else LAUNCH_TRAV(false, false); }
-#undef LAUNCH_TRAV
+        DISPATCH_WALK();
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); }
         unsigned long long* bs = h->blocksums.as<unsigned long long>();
         hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs);
@@ -563,19 +591,23 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
         hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs, ctr + 3,
                            h->offsets.as<uint32_t>());
         const int sgrid = (int)std::min<size_t>((cap + 255) / 256, (size_t)ctx->n_cu * 8);
-        if (with_t)
-            hipLaunchKernelGGL((k_hits_scatter<T, true>), dim3(sgrid), dim3(256), 0, st, pool, pool_t, ctr, cap,
-                               h->offsets.as<uint32_t>(), h->indices.as<uint32_t>(), h->tslice.as<T>());
+        T* vals = mode == MODE_T_SLICE ? h->tslice.as<T>() : h->isect.as<T>();
+        if (nv == 2)
+            hipLaunchKernelGGL((k_hits_scatter<T, 2>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap,
+                               h->offsets.as<uint32_t>(), h->indices.as<uint32_t>(), vals);
+        else if (nv == 3)
+            hipLaunchKernelGGL((k_hits_scatter<T, 3>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap,
+                               h->offsets.as<uint32_t>(), h->indices.as<uint32_t>(), vals);
         else
-            hipLaunchKernelGGL((k_hits_scatter<T, false>), dim3(sgrid), dim3(256), 0, st, pool, pool_t, ctr, cap,
-                               h->offsets.as<uint32_t>(), h->indices.as<uint32_t>(), h->tslice.as<T>());
+            hipLaunchKernelGGL((k_hits_scatter<T, 0>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap,
+                               h->offsets.as<uint32_t>(), h->indices.as<uint32_t>(), vals);
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
         BVH_HIP(hipMemcpyAsync(pin, ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         BVH_HIP(hipStreamSynchronize(st));
         BVH_HIP(hipGetLastError());
-        const unsigned long long used = pin[0];   // pool slots taken (persistent variant: whole chunks)
+        const unsigned long long used = pin[0];   // pool slots taken (whole chunks)
         const unsigned long long total = pin[3];  // sum of the per-ray counts = number of hits
-        if (used < total || (!persist && used != total)) throw HipFail{hipErrorUnknown, "hit pool / count scan mismatch", __LINE__};
+        if (used < total) throw HipFail{hipErrorUnknown, "hit pool / count scan mismatch", __LINE__};
         if (total > 0xFFFFFFFFull) throw HipFail{hipErrorInvalidValue, "OVERFLOW", __LINE__};
         if (used > cap) {  // pool too small: grow to the need (deterministic: same chunks on replay) and replay
             h->pool_cap = (size_t)used + (size_t)used / 8 + 1024;
@@ -596,10 +628,36 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
         return;
     }
     throw HipFail{hipErrorUnknown, "hit pool did not converge", __LINE__};
+#undef DISPATCH_WALK
 }
 
 template void traverse_batch<float>(bvhgpu_tree*, const bvhgpu_ray_f32*, size_t, unsigned, bvhgpu_hits*);
 template void traverse_batch<double>(bvhgpu_tree*, const bvhgpu_ray_f64*, size_t, unsigned, bvhgpu_hits*);
+
+// ------------------------------------------------------------------------------------------------
+// Ray::intersects_triangle for n independent (ray, triangle) pairs — ray_impl.rs:154-213
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_ray_triangle_pairs(const typename Traits<T>::Ray* __restrict__ rays,
+                                                            const T* __restrict__ tris, uint32_t n, T* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const typename Traits<T>::Ray* rp = rays + i;
+    const T o[3] = {rp->o[0], rp->o[1], rp->o[2]};
+    const T d[3] = {rp->d[0], rp->d[1], rp->d[2]};
+    T r[3];
+    ray_triangle<T>(o, d, tris + 9 * (size_t)i, r);
+    out[3 * (size_t)i] = r[0]; out[3 * (size_t)i + 1] = r[1]; out[3 * (size_t)i + 2] = r[2];
+}
+template <typename T>
+void ray_triangle_pairs(bvhgpu_ctx* ctx, const typename Traits<T>::Ray* rays_dev, const T* tris_dev, size_t n, T* out_dev) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_ray_triangle_pairs<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, rays_dev,
+                       tris_dev, (uint32_t)n, out_dev);
+    BVH_HIP(hipGetLastError());
+}
+template void ray_triangle_pairs<float>(bvhgpu_ctx*, const bvhgpu_ray_f32*, const float*, size_t, float*);
+template void ray_triangle_pairs<double>(bvhgpu_ctx*, const bvhgpu_ray_f64*, const double*, size_t, double*);
 
 // ------------------------------------------------------------------------------------------------
 // Ray::new — ray_impl.rs:70-80

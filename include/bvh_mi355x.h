@@ -54,6 +54,10 @@ typedef enum { BVHGPU_HOST = 0, BVHGPU_DEVICE = 1 } bvhgpu_mem;
 /* traversal flags */
 #define BVHGPU_TRAVERSE_T_SLICE 1u /* also return (tmin,tmax) per hit: Ray::intersection_slice_for_aabb (ray_impl.rs:118-145) */
 #define BVHGPU_TRAVERSE_STATS 2u   /* also count reference-equivalent loop iterations (flat_bvh.rs:408) */
+#define BVHGPU_TRAVERSE_TRIANGLES 4u /* also run Ray::intersects_triangle (ray_impl.rs:154-213) on every returned shape, as the
+                                        reference's harness does after traverse (testbase.rs:826-836): Intersection{distance,u,v} per hit */
+#define BVHGPU_TRAVERSE_CLOSEST 8u   /* triangle stage fused into the walk, no CSR: per ray the candidate with the smallest
+                                        Intersection.distance (first one on ties) and its shape index */
 
 /* ---- POD layouts (little-endian, natural alignment, no packing pragmas) ---- */
 
@@ -148,6 +152,11 @@ int bvhgpu_gen_rays_f32(bvhgpu_ctx *ctx, uint64_t first, size_t n, const float b
 /* same stream widened to f64 AFTER generation (f32 origin/target → f64 Ray::new), for the f64 config. */
 int bvhgpu_gen_rays_f64(bvhgpu_ctx *ctx, uint64_t first, size_t n, const float bounds[6], bvhgpu_ray_f64 *out_dev);
 
+/* Ray::intersects_triangle (ray_impl.rs:154-213) for n independent pairs: ray i against triangle i
+ * (tris: n x [a xyz, b xyz, c xyz]); out: n x {distance,u,v}.  `mem` applies to all three buffers. */
+int bvhgpu_ray_triangle_pairs_f32(bvhgpu_ctx *ctx, const bvhgpu_ray_f32 *rays, const float *tris, size_t n, int mem, float *out);
+int bvhgpu_ray_triangle_pairs_f64(bvhgpu_ctx *ctx, const bvhgpu_ray_f64 *rays, const double *tris, size_t n, int mem, double *out);
+
 /* ---- traverse: replaces <FlatBvh as BoundingHierarchy>::traverse (flat_bvh.rs:396-431) and, by the
  * equivalence of bvh_node.rs:288-319, Bvh::traverse (bvh_impl.rs:104-119), for a BATCH of rays.
  * Result = CSR: offsets[n_rays+1], indices[total]; ray i's shapes are indices[offsets[i]..offsets[i+1])
@@ -157,9 +166,17 @@ int bvhgpu_traverse_f32(bvhgpu_tree *tree, const bvhgpu_ray_f32 *rays, size_t n_
                         bvhgpu_hits **hits);
 int bvhgpu_traverse_f64(bvhgpu_tree *tree, const bvhgpu_ray_f64 *rays, size_t n_rays, int mem, unsigned flags,
                         bvhgpu_hits **hits);
+/* Triangle vertices of the shapes (n x [a xyz, b xyz, c xyz], the fields of testbase.rs Triangle :316-323) for the
+ * TRIANGLES / CLOSEST flags; n must equal the tree's shape count.  The tree keeps its own HBM copy. */
+int bvhgpu_tree_set_triangles_f32(bvhgpu_tree *tree, const float *verts, size_t n, int mem);
+int bvhgpu_tree_set_triangles_f64(bvhgpu_tree *tree, const double *verts, size_t n, int mem);
 int bvhgpu_hits_info(const bvhgpu_hits *hits, size_t *n_rays, uint64_t *total, bvhgpu_traverse_stats *stats);
 /* copy out; indices / tslice may be NULL.  tslice: 2 scalars of the tree's dtype per hit (flag T_SLICE). */
 int bvhgpu_hits_fetch(bvhgpu_hits *hits, uint32_t *offsets, uint32_t *indices, void *tslice, int mem);
+/* TRIANGLES: 3 scalars {distance,u,v} per hit, CSR order (distance = +inf: no intersection, ray_impl.rs:150-151). */
+int bvhgpu_hits_fetch_triangles(bvhgpu_hits *hits, void *isect, int mem);
+/* CLOSEST: per ray {distance,u,v} (+inf,0,0 when nothing is hit) and the shape index (BVHGPU_NONE when nothing is hit). */
+int bvhgpu_hits_fetch_closest(bvhgpu_hits *hits, void *isect, uint32_t *shape, int mem);
 /* borrow the device arrays (valid until the next traverse into / destroy of this result). */
 int bvhgpu_hits_device(const bvhgpu_hits *hits, const uint32_t **offsets, const uint32_t **indices, const void **tslice);
 void bvhgpu_hits_destroy(bvhgpu_hits *hits);
@@ -172,10 +189,10 @@ int bvhgpu_last_timings(bvhgpu_ctx *ctx, bvhgpu_timings *out);
 
 /* ---- tuning knobs (performance only; results never change).  Not part of the reference surface. ---- */
 typedef enum {
-    BVHGPU_TUNE_TRAVERSE_VARIANT = 0,      /* 0 one ray per lane per launch; 1 persistent waves with ray refill;
-                                              2 (default) persistent + top of the tree resident in LDS */
-    BVHGPU_TUNE_TRAVERSE_WAVES_PER_CU = 1, /* variant 1: resident waves per CU (default 32) */
-    BVHGPU_TUNE_TRAVERSE_REFILL_MIN = 2,   /* variants 1, 2: refill once this many lanes are idle (default 1) */
+    BVHGPU_TUNE_TRAVERSE_VARIANT = 0,      /* 0 one ray per lane per launch; 2 (default) persistent workgroups with ray
+                                              refill and the top of the tree resident in LDS */
+    BVHGPU_TUNE_RESERVED_1 = 1,
+    BVHGPU_TUNE_RESERVED_2 = 2,
     BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS = 3, /* variant 2 is used for batches of at least this many rays (default 16384) */
     BVHGPU_TUNE_TRAVERSE_LDS_SLOTS = 4,    /* variant 2: top-of-tree entries kept in LDS per workgroup (default 2048 = 11 levels) */
     BVHGPU_TUNE_TRAVERSE_LDS_THREADS = 5,  /* variant 2: workgroup size (default 1024) */

@@ -97,6 +97,8 @@ void orc_aligned_boxes(float *aabbs /* 21*6 */);
     int orc_ray_intersects_aabb_##S(const RAY *r, const T box[6]);     /* intersect_default.rs:16-37 */ \
     int orc_ray_slice_##S(const RAY *r, const T box[6], T out[2]);     /* ray_impl.rs:118-145 */ \
     T orc_ray_triangle_##S(const RAY *r, const T a[3], const T b[3], const T c[3], T uv[2]); /* :154-213 */ \
+    void orc_triangle_stage_##S(const T *tris, const RAY *rays, size_t n_rays, const uint32_t *offsets,  \
+                                const uint32_t *indices, T *isect, T *closest, uint32_t *closest_prim);  \
     T orc_surface_area_##S(const T box[6]);                            /* aabb_impl.rs:551-554 */\
     void orc_center_##S(const T box[6], T out[3]);                     /* aabb_impl.rs:501-504 */\
     int orc_largest_axis_##S(const T box[6]);                          /* aabb_impl.rs:594-596 */\

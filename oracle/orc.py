@@ -234,6 +234,24 @@ def traverse_tree(nodes, shape_aabbs, rays):
     return offsets, indices
 
 
+def triangle_stage(tris, rays, offsets, indices):
+    """testbase.rs:826-836 after traversal: Intersection{distance,u,v} of every candidate (CSR order) and
+    the closest candidate per ray.  tris: (n,3,3) or (n,9).  returns (isect[total,3], closest[r,3], prim[r])"""
+    s = "f32" if rays.dtype == RAY_F32 else "f64"
+    ft = _types(s)[0]
+    t = np.ascontiguousarray(tris, dtype=ft).reshape(-1, 9)
+    rays = np.ascontiguousarray(rays)
+    off = np.ascontiguousarray(offsets, dtype=np.uint32)
+    idx = np.ascontiguousarray(indices, dtype=np.uint32)
+    isect = np.zeros((len(idx), 3), dtype=ft)
+    closest = np.zeros((len(rays), 3), dtype=ft)
+    prim = np.zeros(len(rays), dtype=np.uint32)
+    fn = getattr(lib(), f"orc_triangle_stage_{s}")
+    fn.restype = None
+    fn(_p(t), _p(rays), C.c_size_t(len(rays)), _p(off), _p(idx), _p(isect), _p(closest), _p(prim))
+    return isect, closest, prim
+
+
 def check_tree(nodes, aabbs) -> int:
     s = "f32" if nodes.dtype == NODE_F32 else "f64"
     ft = _types(s)[0]

@@ -370,3 +370,120 @@ def test_traversal_variants_same_result(eng, orc, variant, slots, threads, dtype
     oflat = orc.flatten(orc.build(small).nodes)
     moved = small.copy(); moved[::3, [0, 3]] += dtype(0.75)
     check(small, orc.make_rays(o[:4000], d[:4000], dtype), flat_upload=(oflat, moved))
+
+
+# ------------------------------------------------------------------ triangle stage
+def _pairs_oracle(orc, rays, tris):
+    n = len(rays)
+    isect, _, _ = orc.triangle_stage(tris, rays, np.arange(n + 1, dtype=np.uint32), np.arange(n, dtype=np.uint32))
+    return isect
+
+
+def _triangle_cases(rng, n, dtype, spread):
+    a = rng.uniform(-spread, spread, size=(n, 3)).astype(dtype)
+    b = a + rng.normal(scale=spread * 0.1, size=(n, 3)).astype(dtype)
+    c = a + rng.normal(scale=spread * 0.1, size=(n, 3)).astype(dtype)
+    tris = np.stack([a, b, c], axis=1)
+    u = rng.integers(0, 101, size=n)
+    v = np.minimum(100 - u, rng.integers(0, 101, size=n))
+    p = a + (u[:, None] / 100.0).astype(dtype) * (b - a) + (v[:, None] / 100.0).astype(dtype) * (c - a)
+    o = rng.uniform(-spread, spread, size=(n, 3)).astype(dtype)
+    d = (p - o).astype(dtype)
+    k = n // 8
+    d[:k] = rng.normal(size=(k, 3))                         # random directions: mostly misses
+    tris[k:2 * k, 2] = tris[k:2 * k, 1]                     # degenerate (zero-area) triangles: det == 0
+    o[2 * k:3 * k] = a[2 * k:3 * k]                         # origin on a vertex
+    d[2 * k:3 * k] = (b - a)[2 * k:3 * k]                   # ray inside the triangle's plane
+    return tris, o, d, (u, v)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ray_triangle_pairs_bit_exact(eng, orc, dtype):
+    """Ray::intersects_triangle (ray_impl.rs:154-213) on the device == the oracle's restatement, bit for bit,
+    for every field of Intersection including the u / v left behind by the early returns."""
+    from bvh_amd.api import intersect_triangle_pairs
+    rng = np.random.default_rng(2024)
+    for spread in (1.0, 1e3, 1e10):
+        tris, o, d, _ = _triangle_cases(rng, 20000, dtype, spread)
+        rays = orc.make_rays(o, d, dtype)
+        got = intersect_triangle_pairs(_rb(eng, rays), tris)
+        want = _pairs_oracle(orc, rays, tris)
+        assert got.tobytes() == want.tobytes()
+        assert np.isfinite(want[:, 0]).sum() > 1000        # the sample does exercise real hits
+
+
+def test_reference_ray_hits_triangle_property(eng, orc):
+    """the reference's proptest test_ray_hits_triangle (ray_impl.rs:361-420) on the device implementation."""
+    from bvh_amd.api import intersect_triangle_pairs
+    rng = np.random.default_rng(7)
+    n = 50000
+    f = np.float32
+    a, b, c, origin = (rng.uniform(-10e10, 10e10, size=(n, 3)).astype(f) for _ in range(4))
+    u16 = rng.integers(0, 65536, size=n); v16 = rng.integers(0, 65536, size=n)
+    u = u16 % 101
+    v = np.minimum(100 - u, v16 % 101)
+    uf = (u.astype(f) / f(100.0)); vf = (v.astype(f) / f(100.0))
+    u_vec = b - a; v_vec = c - a
+    with np.errstate(all="ignore"):
+        normal = np.cross(u_vec, v_vec).astype(f)
+        p = a + uf[:, None] * u_vec + vf[:, None] * v_vec
+        d = (p - origin).astype(f)
+        on_back = (normal * (origin - a)).astype(f).sum(axis=1) <= 0
+    rays = orc.make_rays(origin, d, f)
+    tris = np.stack([a, b, c], axis=1)
+    r = intersect_triangle_pairs(_rb(eng, rays), tris)
+    assert r.tobytes() == _pairs_oracle(orc, rays, tris).tobytes()
+    dist, ru, rv = r[:, 0], r[:, 1], r[:, 2]
+    eps = np.finfo(f).eps
+    with np.errstate(all="ignore"):
+        uv = ru + rv
+        inside = (uv >= 0) & (uv <= 1) & (dist < np.inf)
+    border = (np.abs(uf) < eps) | (np.abs(uf - 1) < eps) | (np.abs(vf) < eps) | (np.abs(vf - 1) < eps) | (np.abs(uf + vf - 1) < eps)
+    # numpy's sum order differs from nalgebra's dot only in rounding: skip the few cases at the plane itself
+    clear = np.abs((normal * (origin - a)).sum(axis=1)) > 1e-3 * np.abs(normal * (origin - a)).sum(axis=1)
+    assert np.all(dist[on_back & clear] == np.inf)
+    ok = inside | border
+    # the reference's own property is only approximately true at |coords| ~ 1e11 in f32 (it is a proptest with
+    # regression seeds); require it on the overwhelming majority and identically on the oracle
+    assert ok[~on_back & clear].mean() > 0.95
+
+
+@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_triangle_stage_matches_reference_loop(eng, orc, variant, dtype):
+    """traverse + intersects_triangle on every candidate (testbase.rs:826-836): per-candidate Intersection in
+    CSR order and the closest hit per ray, against the oracle's restatement of that loop."""
+    from bvh_amd import Context, testbase as tb
+    from bvh_amd._lib import TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_TRAVERSE_VARIANT
+    ctx = Context(0)
+    ctx.set_tuning(TUNE_TRAVERSE_VARIANT, variant)
+    ctx.set_tuning(TUNE_TRAVERSE_LDS_MIN_RAYS, 0)
+    tris32, aabbs32 = tb.create_n_cubes(3000)
+    tris, aabbs = tris32.astype(dtype), aabbs32.astype(dtype)
+    rng = np.random.default_rng(3)
+    n = 40000
+    centres = tris.reshape(3000, 36, 3)[:, :, :].mean(axis=1)          # cube centres
+    target = centres[rng.integers(0, 3000, size=n)] + rng.uniform(-0.6, 0.6, size=(n, 3))
+    o = rng.uniform(-1e5, 1e5, size=(n, 3)).astype(dtype)
+    d = (target - o).astype(dtype)
+    d[: n // 10] = rng.normal(size=(n // 10, 3))                        # some rays that hit nothing
+    rays = orc.make_rays(o, d, dtype)
+    bvh = eng.Bvh.from_aabbs(aabbs, ctx)
+    flat = bvh.flatten()
+    flat.set_triangles(tris)
+    off, idx, isect, st = flat.intersect_triangles(_rb(eng, rays), stats=True)
+    oflat = orc.flatten(orc.build(aabbs).nodes)
+    ooff, oidx, _, ost = orc.traverse_flat(oflat, aabbs, rays, threads=orc.max_threads())
+    oisect, oclosest, oprim = orc.triangle_stage(tris, rays, ooff, oidx)
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+    assert isect.tobytes() == oisect.tobytes()
+    assert st["visited"] == ost["visited"]
+    cl, prim, st2 = flat.closest_hits(_rb(eng, rays), stats=True)
+    assert cl.tobytes() == oclosest.tobytes() and np.array_equal(prim, oprim)
+    assert st2["hits"] == ost["hits"] and st2["visited"] == ost["visited"]
+    hit = np.isfinite(oclosest[:, 0])
+    assert hit.sum() > n // 2 and (~hit).sum() > n // 20               # both outcomes are exercised
+    # flags that cannot be combined / missing triangles fail loudly
+    bare = eng.Bvh.from_aabbs(aabbs, ctx).flatten()
+    with pytest.raises(eng.BvhGpuError):
+        bare.closest_hits(_rb(eng, rays[:10]))
