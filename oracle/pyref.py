@@ -262,3 +262,35 @@ def next_point3(state, bounds):  # testbase.rs:567-595
         size = f(bounds[3 + k]) - f(bounds[k])
         out.append(f(bounds[k]) + fv * size)
     return state, out
+
+
+def ray_triangle(ray, a, b, c):  # ray_impl.rs:154-213, written independently of oracle_impl.inc
+    """Möller–Trumbore with back-face culling on numpy scalars of the ray's dtype.
+    ray = (origin, direction, inv_direction); returns (distance, u, v) as Intersection::new receives them."""
+    o, d = np.asarray(ray[0]), np.asarray(ray[1])
+    ft = o.dtype.type
+    a, b, c = (np.asarray(p, dtype=ft) for p in (a, b, c))
+
+    def cross(x, y):  # nalgebra cross
+        return np.array([ft(x[1] * y[2]) - ft(x[2] * y[1]), ft(x[2] * y[0]) - ft(x[0] * y[2]),
+                         ft(x[0] * y[1]) - ft(x[1] * y[0])], dtype=ft)
+
+    def dot(x, y):  # (x0*y0 + x1*y1) + x2*y2
+        return ft(ft(ft(x[0] * y[0]) + ft(x[1] * y[1])) + ft(x[2] * y[2]))
+    with np.errstate(all="ignore"):
+        ab, ac = b - a, c - a
+        uvec = cross(d, ac)
+        det = dot(ab, uvec)
+        if det < np.finfo(ft).eps:
+            return ft(np.inf), ft(0), ft(0)
+        inv_det = ft(ft(1) / det)
+        ao = o - a
+        u = ft(dot(ao, uvec) * inv_det)
+        if not (ft(0) <= u <= ft(1)):
+            return ft(np.inf), u, ft(0)
+        vvec = cross(ao, ab)
+        v = ft(dot(d, vvec) * inv_det)
+        if v < 0 or ft(u + v) > ft(1):
+            return ft(np.inf), u, v
+        dist = ft(dot(ac, vvec) * inv_det)
+        return (dist if dist > np.finfo(ft).eps else ft(np.inf)), u, v

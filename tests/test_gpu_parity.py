@@ -487,3 +487,21 @@ def test_triangle_stage_matches_reference_loop(eng, orc, variant, dtype):
     bare = eng.Bvh.from_aabbs(aabbs, ctx).flatten()
     with pytest.raises(eng.BvhGpuError):
         bare.closest_hits(_rb(eng, rays[:10]))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [48, 700, 6000])
+def test_parity_signed_zero_bounds(eng, orc, n, dtype):
+    """-0.0 and +0.0 coordinates: every join of the builder (integer keys in the level tier, v_min/v_max in
+    the wave tier, LDS atomics in the workgroup tiers) must order -0 < +0 like the oracle, byte for byte."""
+    rng = np.random.default_rng(n)
+    vals = np.array([-0.0, 0.0, -1.0, 1.0, -0.5, 0.5, 2.0], dtype=dtype)
+    lo = vals[rng.integers(0, len(vals), size=(n, 3))]
+    hi = vals[rng.integers(0, len(vals), size=(n, 3))]
+    mn = np.where(lo <= hi, lo, hi); mx = np.where(lo <= hi, hi, lo)
+    # keep the signed zeros that np.where picked: (-0.0 <= 0.0) is True, so min may be -0.0 or +0.0 by position
+    aabbs = np.concatenate([mn, mx], axis=1).astype(dtype)
+    assert np.signbit(aabbs[aabbs == 0]).any() and (~np.signbit(aabbs[aabbs == 0])).any()
+    o = rng.uniform(-3, 3, size=(400, 3)).astype(dtype)
+    d = rng.normal(size=(400, 3)).astype(dtype)
+    _full_parity(eng, orc, aabbs, orc.make_rays(o, d, dtype), 1e-5 if dtype == np.float32 else 1e-12)

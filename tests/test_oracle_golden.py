@@ -127,6 +127,80 @@ def test_triangle_intersection_basic():
         np.isfinite(d2) and abs(d2 - 1.0) < 1e-6 and np.isinf(d))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_triangle_intersection_two_restatements_agree(dtype):
+    """oracle_impl.inc orc_ray_triangle vs the independently written oracle/pyref.py ray_triangle: every field
+    of Intersection bit-identical, including u / v of the early returns (ray_impl.rs:186-211)."""
+    from oracle import pyref
+    rng = np.random.default_rng(5)
+    n = 3000
+    a = rng.uniform(-50, 50, size=(n, 3)).astype(dtype)
+    b = a + rng.normal(scale=3, size=(n, 3)).astype(dtype)
+    c = a + rng.normal(scale=3, size=(n, 3)).astype(dtype)
+    w = rng.uniform(0, 1, size=(n, 2)); w[w.sum(1) > 1] = 1 - w[w.sum(1) > 1]
+    p = a + w[:, :1].astype(dtype) * (b - a) + w[:, 1:].astype(dtype) * (c - a)
+    o = rng.uniform(-60, 60, size=(n, 3)).astype(dtype)
+    d = (p - o).astype(dtype)
+    d[:400] = rng.normal(size=(400, 3))
+    c[400:500] = b[400:500]                                   # zero-area triangles
+    rays = orc.make_rays(o, d, dtype)
+    tris = np.stack([a, b, c], axis=1)
+    isect, closest, prim = orc.triangle_stage(tris, rays, np.arange(n + 1, dtype=np.uint32), np.arange(n, dtype=np.uint32))
+    hits = 0
+    for i in range(n):
+        pr = pyref.ray_triangle((rays[i]["o"], rays[i]["d"], rays[i]["inv"]), a[i], b[i], c[i])
+        got = orc.ray_triangle(rays[i], a[i], b[i], c[i])
+        assert np.array([*pr], dtype=dtype).tobytes() == np.array([*got], dtype=dtype).tobytes() == isect[i].tobytes()
+        hits += np.isfinite(got[0])
+        # one candidate per ray: the closest hit is that candidate iff it is finite
+        assert (prim[i] == i) == bool(np.isfinite(got[0]))
+    assert hits > n // 3
+
+
+def test_triangle_stage_closest_is_first_minimum():
+    """orc_triangle_stage: closest = the candidate with the smallest distance, the first one on ties."""
+    tri = np.array([[0, 0, 0], [0, 1, 0], [1, 0, 0]], dtype=np.float32)
+    tris = np.stack([tri + [0, 0, 5], tri + [0, 0, 2], tri + [0, 0, 2], tri + [0, 0, 9]]).astype(np.float32)
+    rays = orc.make_rays([[0.25, 0.25, -1.0]], [[0, 0, 1]])
+    off = np.array([0, 4], dtype=np.uint32); idx = np.array([0, 1, 2, 3], dtype=np.uint32)
+    isect, closest, prim = orc.triangle_stage(tris, rays, off, idx)
+    assert isect[:, 0].tolist() == [6.0, 3.0, 3.0, 10.0]
+    assert prim[0] == 1 and closest[0, 0] == 3.0
+    _, c2, p2 = orc.triangle_stage(tris, rays, np.array([0, 0], dtype=np.uint32), np.zeros(0, dtype=np.uint32))
+    assert np.isinf(c2[0, 0]) and c2[0, 1] == 0 and c2[0, 2] == 0 and p2[0] == 0xFFFFFFFF
+
+
+def test_reference_ray_hits_triangle_property_on_oracle():
+    """the reference's proptest test_ray_hits_triangle (ray_impl.rs:361-420) restated for the oracle: a ray
+    aimed at a point inside a triangle hits it unless it looks at the back face (culled)."""
+    rng = np.random.default_rng(17)
+    n = 20000
+    f = np.float32
+    a, b, c, origin = (rng.uniform(-1e3, 1e3, size=(n, 3)).astype(f) for _ in range(4))
+    u = rng.integers(0, 65536, size=n) % 101
+    v = np.minimum(100 - u, rng.integers(0, 65536, size=n) % 101)
+    uf, vf = u.astype(f) / f(100), v.astype(f) / f(100)
+    u_vec, v_vec = b - a, c - a
+    normal = np.cross(u_vec, v_vec).astype(f)
+    p = a + uf[:, None] * u_vec + vf[:, None] * v_vec
+    rays = orc.make_rays(origin, (p - origin).astype(f), f)
+    side = (normal.astype(np.float64) * (origin - a).astype(np.float64)).sum(axis=1)
+    clear = np.abs(side) > 1e-4 * np.abs(normal.astype(np.float64) * (origin - a)).sum(axis=1)
+    r, _, _ = orc.triangle_stage(np.stack([a, b, c], axis=1), rays, np.arange(n + 1, dtype=np.uint32),
+                                 np.arange(n, dtype=np.uint32))
+    back = side <= 0
+    assert np.all(np.isinf(r[back & clear, 0]))
+    eps = np.finfo(f).eps
+    with np.errstate(all="ignore"):
+        uv = r[:, 1] + r[:, 2]
+    inside = (uv >= 0) & (uv <= 1) & np.isfinite(r[:, 0])
+    border = (np.abs(uf) < eps) | (np.abs(uf - 1) < eps) | (np.abs(vf) < eps) | (np.abs(vf - 1) < eps) | (np.abs(uf + vf - 1) < eps)
+    front = ~back & clear
+    # points generated on an edge (u, v or u+v within rounding of the border) may fall outside by one ulp
+    near_edge = (u == 0) | (v == 0) | (u + v == 100)
+    assert np.all((inside | border)[front & ~near_edge])
+
+
 # ---------------------------------------------------------------- scene generators
 def test_scene_shape_and_invariants_1200():
     tris, aabbs = orc.create_n_cubes(100)
