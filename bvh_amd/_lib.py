@@ -81,6 +81,8 @@ SYMBOLS = [
     ("bvhgpu_rays_new_f64", _i, [_vp, _vp, _vp, _sz, _i, _vp, _i]),
     ("bvhgpu_gen_rays_f32", _i, [_vp, C.c_uint64, _sz, _vp, _vp]),
     ("bvhgpu_gen_rays_f64", _i, [_vp, C.c_uint64, _sz, _vp, _vp]),
+    ("bvhgpu_gen_primary_rays_f32", _i, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint64, _sz, _vp]),
+    ("bvhgpu_gen_primary_rays_f64", _i, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint64, _sz, _vp]),
     ("bvhgpu_ray_triangle_pairs_f32", _i, [_vp, _vp, _vp, _sz, _i, _vp]),
     ("bvhgpu_ray_triangle_pairs_f64", _i, [_vp, _vp, _vp, _sz, _i, _vp]),
     ("bvhgpu_traverse_f32", _i, [_vp, _vp, _sz, _i, _u, _pp]),
@@ -95,6 +97,10 @@ SYMBOLS = [
     ("bvhgpu_hits_destroy", None, [_vp]),
     ("bvhgpu_enable_timing", _i, [_vp, _i]),
     ("bvhgpu_last_timings", _i, [_vp, C.POINTER(Timings)]),
+    ("bvhgpu_obj_parse", _i, [C.c_char_p, _sz, C.POINTER(C.POINTER(C.c_float)), C.POINTER(_sz), _vp]),
+    ("bvhgpu_obj_free", None, [C.POINTER(C.c_float)]),
+    ("bvhgpu_obj_last_error", C.c_char_p, []),
+    ("bvhgpu_triangles_aabbs_f32", _i, [_vp, _sz, _vp]),
     ("bvhgpu_set_tuning", _i, [_vp, _i, _i]),
     ("bvhgpu_get_tuning", _i, [_vp, _i, C.POINTER(_i)]),
 ]

@@ -228,6 +228,28 @@ def intersect_triangle_pairs(rays: "RayBatch", tris, ctx: Optional["Context"] = 
     return out
 
 
+def camera(eye, look_at, up=(0.0, 1.0, 0.0), fov_y_deg: float = 60.0, aspect: float = 1.6) -> np.ndarray:
+    """cam[14] for RayBatch.primary: eye, right, up, forward (orthonormal, f32), tan_x, tan_y."""
+    e = np.asarray(eye, dtype=np.float64); f = np.asarray(look_at, dtype=np.float64) - e
+    f /= np.linalg.norm(f)
+    r = np.cross(f, np.asarray(up, dtype=np.float64)); r /= np.linalg.norm(r)
+    u = np.cross(r, f)
+    ty = np.tan(np.radians(fov_y_deg) / 2)
+    return np.concatenate([e, r, u, f, [ty * aspect, ty]]).astype(np.float32)
+
+
+def _primary(cam, width, height, first, n, device_obj, dtype, ctx):
+    s = _sfx(dtype)
+    c = np.ascontiguousarray(cam, dtype=np.float32).reshape(14)
+    fn = getattr(_lib.load(), f"bvhgpu_gen_primary_rays_{s}")
+    check(fn(ctx._h, ptr(c), width, height, C.c_uint64(first), n, ptr(device_obj.data_ptr())), ctx._h)
+    return RayBatch(n, dtype, host=None, device=device_obj, device_ptr=device_obj.data_ptr())
+
+
+RayBatch.primary = staticmethod(lambda cam, width, height, first, n, device_obj, dtype=np.float32, ctx=None:
+                               _primary(cam, width, height, first, n, device_obj, dtype, ctx or default_context()))
+
+
 class Ray:
     """struct Ray (ray_impl.rs:17-29).  Ray(origin, direction) == Ray::new."""
 

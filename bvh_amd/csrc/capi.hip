@@ -428,8 +428,8 @@ int bvhgpu_tree_from_flat_f64(bvhgpu_ctx* ctx, const bvhgpu_flat_f64* flat, size
 }
 
 // ---- scene blob: header | traversal array | shape AABBs | top-of-tree slot table ----
-struct SceneHeader { uint32_t magic, dtype; uint64_t n, n_trav; uint32_t unfolded, _pad; uint64_t trav_bytes, aabb_bytes, slot_bytes; };
-static constexpr uint32_t SCENE_MAGIC = 0x42564834u;  // "BVH4"
+struct SceneHeader { uint32_t magic, dtype; uint64_t n, n_trav; uint32_t unfolded, _pad; uint64_t trav_bytes, aabb_bytes, slot_bytes, tri_bytes; };
+static constexpr uint32_t SCENE_MAGIC = 0x42564835u;  // "BVH5"
 static size_t slot_table_bytes(int dtype) { return (dtype == BVHGPU_F32 ? TopCfg<float>::SLOTS : TopCfg<double>::SLOTS) * 4; }
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -438,7 +438,8 @@ int bvhgpu_scene_nbytes(const bvhgpu_tree* t, size_t* nbytes) {
     if (!t->flattened) return BVHGPU_NOT_FLATTENED;
     size_t tsz = t->dtype == BVHGPU_F32 ? sizeof(TravNode<float>) : sizeof(TravNode<double>);
     size_t ssz = t->dtype == BVHGPU_F32 ? 4 : 8;
-    *nbytes = 256 + align256(t->n_trav * tsz) + align256(t->n * 6 * ssz) + align256(t->slot_entry.p ? slot_table_bytes(t->dtype) : 0);
+    *nbytes = 256 + align256(t->n_trav * tsz) + align256(t->n * 6 * ssz) + align256(t->slot_entry.p ? slot_table_bytes(t->dtype) : 0) +
+              align256(t->has_tris ? t->n * 9 * ssz : 0);
     return BVHGPU_OK;
 }
 
@@ -456,12 +457,14 @@ int bvhgpu_scene_export(bvhgpu_tree* t, void* dst, int mem) {
         h->unfolded = t->unfolded ? 1u : 0u;
         h->trav_bytes = t->n_trav * tsz; h->aabb_bytes = t->n * 6 * ssz;
         h->slot_bytes = t->slot_entry.p ? slot_table_bytes(t->dtype) : 0;
+        h->tri_bytes = t->has_tris ? t->n * 9 * ssz : 0;
         char* d = static_cast<char*>(dst);
         const hipMemcpyKind kd = mem == BVHGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
         BVH_HIP(hipMemcpyAsync(d, h, 256, mem == BVHGPU_DEVICE ? hipMemcpyHostToDevice : hipMemcpyHostToHost, ctx->stream));
         if (h->trav_bytes) BVH_HIP(hipMemcpyAsync(d + 256, t->trav.p, h->trav_bytes, kd, ctx->stream));
         if (h->aabb_bytes) BVH_HIP(hipMemcpyAsync(d + 256 + align256(h->trav_bytes), t->aabbs.p, h->aabb_bytes, kd, ctx->stream));
         if (h->slot_bytes) BVH_HIP(hipMemcpyAsync(d + 256 + align256(h->trav_bytes) + align256(h->aabb_bytes), t->slot_entry.p, h->slot_bytes, kd, ctx->stream));
+        if (h->tri_bytes) BVH_HIP(hipMemcpyAsync(d + 256 + align256(h->trav_bytes) + align256(h->aabb_bytes) + align256(h->slot_bytes), t->tris.p, h->tri_bytes, kd, ctx->stream));
         BVH_HIP(hipStreamSynchronize(ctx->stream));  // the pinned header page is reused by the next call
         return (int)BVHGPU_OK;
     });
@@ -482,11 +485,11 @@ int bvhgpu_scene_import(bvhgpu_ctx* ctx, const void* src, size_t nbytes, int mem
         BVH_HIP(hipMemcpyAsync(h, s, 256, mem == BVHGPU_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, ctx->stream));
         BVH_HIP(hipStreamSynchronize(ctx->stream));
         if (h->magic != SCENE_MAGIC || h->dtype > 1) return fail(ctx, BVHGPU_INVALID_ARG, "not a bvhgpu scene blob");
-        if (256 + align256(h->trav_bytes) + align256(h->aabb_bytes) + align256(h->slot_bytes) > nbytes) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob truncated");
+        if (256 + align256(h->trav_bytes) + align256(h->aabb_bytes) + align256(h->slot_bytes) + align256(h->tri_bytes) > nbytes) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob truncated");
         if (h->slot_bytes && h->slot_bytes != slot_table_bytes((int)h->dtype)) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob slot table size");
         t->dtype = (int)h->dtype; t->n = h->n; t->n_trav = h->n_trav; t->n_nodes = 0; t->n_flat = 0;
         t->unfolded = h->unfolded != 0;
-        const size_t tb = h->trav_bytes, ab = h->aabb_bytes, sb = h->slot_bytes;
+        const size_t tb = h->trav_bytes, ab = h->aabb_bytes, sb = h->slot_bytes, gb = h->tri_bytes;
         t->trav.reserve(tb + 16);
         t->aabbs.reserve(ab + 16);
         const hipMemcpyKind kd = mem == BVHGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -494,6 +497,8 @@ int bvhgpu_scene_import(bvhgpu_ctx* ctx, const void* src, size_t nbytes, int mem
         if (ab) BVH_HIP(hipMemcpyAsync(t->aabbs.p, s + 256 + align256(tb), ab, kd, ctx->stream));
         if (sb) { t->slot_entry.reserve(sb); BVH_HIP(hipMemcpyAsync(t->slot_entry.p, s + 256 + align256(tb) + align256(ab), sb, kd, ctx->stream)); }
         else t->slot_entry.release();
+        if (gb) { t->tris.reserve(gb); BVH_HIP(hipMemcpyAsync(t->tris.p, s + 256 + align256(tb) + align256(ab) + align256(sb), gb, kd, ctx->stream)); }
+        t->has_tris = gb != 0;
         if (mem != BVHGPU_DEVICE) BVH_HIP(hipStreamSynchronize(ctx->stream));
         t->built = false; t->flattened = true;
         return (int)BVHGPU_OK;
@@ -521,6 +526,18 @@ int bvhgpu_gen_rays_f64(bvhgpu_ctx* ctx, uint64_t first, size_t n, const float b
     return guarded(ctx, [&] { use_device(ctx); gen_rays_f64(ctx, first, n, bounds, out_dev); return (int)BVHGPU_OK; });
 }
 
+int bvhgpu_gen_primary_rays_f32(bvhgpu_ctx* ctx, const float cam[14], uint32_t width, uint32_t height, uint64_t first, size_t n,
+                                bvhgpu_ray_f32* out_dev) {
+    if (!ctx || !cam || (n && !out_dev) || !width || !height) return fail(ctx, BVHGPU_INVALID_ARG, "bad argument");
+    if (n >= 0xFFFFFFFFull) return fail(ctx, BVHGPU_OVERFLOW, "too many rays in one call");
+    return guarded(ctx, [&] { use_device(ctx); gen_primary<float>(ctx, cam, width, height, first, n, out_dev); return (int)BVHGPU_OK; });
+}
+int bvhgpu_gen_primary_rays_f64(bvhgpu_ctx* ctx, const float cam[14], uint32_t width, uint32_t height, uint64_t first, size_t n,
+                                bvhgpu_ray_f64* out_dev) {
+    if (!ctx || !cam || (n && !out_dev) || !width || !height) return fail(ctx, BVHGPU_INVALID_ARG, "bad argument");
+    if (n >= 0xFFFFFFFFull) return fail(ctx, BVHGPU_OVERFLOW, "too many rays in one call");
+    return guarded(ctx, [&] { use_device(ctx); gen_primary<double>(ctx, cam, width, height, first, n, out_dev); return (int)BVHGPU_OK; });
+}
 int bvhgpu_ray_triangle_pairs_f32(bvhgpu_ctx* ctx, const bvhgpu_ray_f32* rays, const float* tris, size_t n, int mem, float* out) {
     return do_pairs<float>(ctx, rays, tris, n, mem, out);
 }

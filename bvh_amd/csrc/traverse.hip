@@ -740,6 +740,43 @@ __global__ __launch_bounds__(256) void k_gen_rays(unsigned long long first, uint
     ray_new<T>(oo, dd, out + i);
 }
 
+// coherent primary rays (BASELINE.json configs[2]): pinhole camera, row-major W x H image.  Definition in
+// include/bvh_mi355x.h (bvhgpu_gen_primary_rays_*); every operation is a separately rounded f32 op.
+struct Camera14 { float c[14]; };
+template <typename T>
+__global__ __launch_bounds__(256) void k_gen_primary(Camera14 cam, uint32_t width, uint32_t height, unsigned long long first,
+                                                     uint32_t n, typename Traits<T>::Ray* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long id = first + i;
+    const uint32_t x = (uint32_t)(id % width), y = (uint32_t)(id / width);
+    float fx = (float)x + 0.5f; fx = fx / (float)width; fx = fx * 2.0f; const float sx = fx - 1.0f;
+    float fy = (float)y + 0.5f; fy = fy / (float)height; fy = fy * 2.0f; const float sy = 1.0f - fy;
+    const float ax = sx * cam.c[12], ay = sy * cam.c[13];
+    T oo[3], dd[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float r = ax * cam.c[3 + k], u = ay * cam.c[6 + k];
+        const float t = cam.c[9 + k] + r;
+        const float d = t + u;
+        oo[k] = (T)cam.c[k];
+        dd[k] = (T)d;
+    }
+    ray_new<T>(oo, dd, out + i);
+}
+template <typename T>
+void gen_primary(bvhgpu_ctx* ctx, const float cam[14], uint32_t width, uint32_t height, uint64_t first, size_t n,
+                 typename Traits<T>::Ray* out_dev) {
+    if (!n) return;
+    Camera14 c;
+    for (int k = 0; k < 14; k++) c.c[k] = cam[k];
+    hipLaunchKernelGGL(k_gen_primary<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, c, width, height,
+                       (unsigned long long)first, (uint32_t)n, out_dev);
+    BVH_HIP(hipGetLastError());
+}
+template void gen_primary<float>(bvhgpu_ctx*, const float*, uint32_t, uint32_t, uint64_t, size_t, bvhgpu_ray_f32*);
+template void gen_primary<double>(bvhgpu_ctx*, const float*, uint32_t, uint32_t, uint64_t, size_t, bvhgpu_ray_f64*);
+
 void gen_rays_f32(bvhgpu_ctx* ctx, uint64_t first, size_t n, const float bounds[6], bvhgpu_ray_f32* out_dev) {
     if (!n) return;
     Bounds6 b;

@@ -132,7 +132,8 @@ int bvhgpu_tree_from_flat_f32(bvhgpu_ctx *ctx, const bvhgpu_flat_f32 *flat, size
 int bvhgpu_tree_from_flat_f64(bvhgpu_ctx *ctx, const bvhgpu_flat_f64 *flat, size_t n_flat, const double *shape_aabbs,
                               size_t n, bvhgpu_tree **out);
 
-/* ---- scene transport for multi-GPU: one contiguous blob (traversal array + shape AABBs) that the
+/* ---- scene transport for multi-GPU: one contiguous blob (traversal array + shape AABBs + LDS slot
+ * table + triangle vertices when set) that the
  * caller broadcasts (RCCL via torch.distributed / ncclBroadcast) and imports on the peers.  A tree
  * imported this way supports traversal only.  For bvhgpu_scene_import *out may point to NULL (a
  * tree is allocated) or to a tree a previous bvhgpu_scene_import returned (its HBM is reused). ---- */
@@ -156,6 +157,16 @@ int bvhgpu_gen_rays_f64(bvhgpu_ctx *ctx, uint64_t first, size_t n, const float b
  * (tris: n x [a xyz, b xyz, c xyz]); out: n x {distance,u,v}.  `mem` applies to all three buffers. */
 int bvhgpu_ray_triangle_pairs_f32(bvhgpu_ctx *ctx, const bvhgpu_ray_f32 *rays, const float *tris, size_t n, int mem, float *out);
 int bvhgpu_ray_triangle_pairs_f64(bvhgpu_ctx *ctx, const bvhgpu_ray_f64 *rays, const double *tris, size_t n, int mem, double *out);
+
+/* Coherent primary rays (BASELINE.json configs[2]; the reference has no camera, this is the engine's definition,
+ * which the tests' CPU checker restates operation by operation).  cam = eye[3], right[3], up[3], forward[3], tan_x, tan_y.
+ * Ray `first + i` belongs to pixel x = id % width, y = id / width:  sx = (((x + 0.5) / W) * 2) - 1,
+ * sy = 1 - (((y + 0.5) / H) * 2),  dir = (forward + (sx * tan_x) * right) + (sy * tan_y) * up  (separately
+ * rounded f32 operations), ray = Ray::new(eye, dir) (ray_impl.rs:70-80).  `out_dev` is device memory. */
+int bvhgpu_gen_primary_rays_f32(bvhgpu_ctx *ctx, const float cam[14], uint32_t width, uint32_t height, uint64_t first,
+                                size_t n, bvhgpu_ray_f32 *out_dev);
+int bvhgpu_gen_primary_rays_f64(bvhgpu_ctx *ctx, const float cam[14], uint32_t width, uint32_t height, uint64_t first,
+                                size_t n, bvhgpu_ray_f64 *out_dev);
 
 /* ---- traverse: replaces <FlatBvh as BoundingHierarchy>::traverse (flat_bvh.rs:396-431) and, by the
  * equivalence of bvh_node.rs:288-319, Bvh::traverse (bvh_impl.rs:104-119), for a BATCH of rays.
@@ -186,6 +197,16 @@ void bvhgpu_hits_destroy(bvhgpu_hits *hits);
 typedef struct { float build_ms, flatten_ms, traverse_kernel_ms, traverse_total_ms; } bvhgpu_timings;
 int bvhgpu_enable_timing(bvhgpu_ctx *ctx, int on);
 int bvhgpu_last_timings(bvhgpu_ctx *ctx, bvhgpu_timings *out);
+
+/* ---- scene ingest (host code): Wavefront OBJ → triangles, as `obj::load_obj::<Triangle>` + `FromRawVertex::process`
+ * do for the reference's Sponza benches (testbase.rs:445-487, 619-634): every polygon (P / PT / PN / PTN) becomes a
+ * triangle fan over its positions.  *tris_out: malloc'ed n x 9 floats [a xyz, b xyz, c xyz] (release with
+ * bvhgpu_obj_free); bounds_out (nullable): join of the triangle AABBs.  Errors: BVHGPU_INVALID_ARG + bvhgpu_obj_last_error(). */
+int bvhgpu_obj_parse(const char *text, size_t len, float **tris_out, size_t *n_tris_out, float bounds_out[6]);
+void bvhgpu_obj_free(float *tris);
+const char *bvhgpu_obj_last_error(void);
+/* Triangle::new's cached aabb = empty.grow(a).grow(b).grow(c) (testbase.rs:325-333): n x [min xyz, max xyz] */
+int bvhgpu_triangles_aabbs_f32(const float *tris, size_t n, float *aabbs_out);
 
 /* ---- tuning knobs (performance only; results never change).  Not part of the reference surface. ---- */
 typedef enum {

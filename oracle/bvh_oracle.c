@@ -143,6 +143,29 @@ void orc_create_rays(uint64_t first, size_t n, const float bounds[6], orc_ray_f3
     }
 }
 
+/* Coherent primary rays for BASELINE.json configs[2].  The reference has no camera; this is the
+ * engine's definition, restated here operation by operation (all f32, no FMA):
+ *   sx = (((x + 0.5) / W) * 2) - 1,  sy = 1 - (((y + 0.5) / H) * 2)
+ *   dir_k = (forward_k + (sx * tan_x) * right_k) + (sy * tan_y) * up_k,  ray = Ray::new(eye, dir)  (ray_impl.rs:70-80)
+ * cam = eye[3], right[3], up[3], forward[3], tan_x, tan_y; ray index = y * W + x (row-major). */
+void orc_primary_rays(const float cam[14], uint32_t width, uint32_t height, uint64_t first, size_t n, orc_ray_f32 *rays) {
+    (void)height;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t id = first + i;
+        const uint32_t x = (uint32_t)(id % width), y = (uint32_t)(id / width);
+        float fx = (float)x + 0.5f; fx = fx / (float)width; fx = fx * 2.0f; const float sx = fx - 1.0f;
+        float fy = (float)y + 0.5f; fy = fy / (float)height; fy = fy * 2.0f; const float sy = 1.0f - fy;
+        const float ax = sx * cam[12], ay = sy * cam[13];
+        float d[3];
+        for (int k = 0; k < 3; k++) {
+            const float r = ax * cam[3 + k], u = ay * cam[6 + k];
+            float t = cam[9 + k] + r;
+            d[k] = t + u;
+        }
+        orc_ray_new_f32(cam, d, &rays[i]);
+    }
+}
+
 /* generate_aligned_boxes + UnitBox::aabb — testbase.rs:109-116, 84-89 */
 void orc_aligned_boxes(float *aabbs) {
     int i = 0;

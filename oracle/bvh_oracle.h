@@ -88,6 +88,7 @@ void orc_next_point3(uint64_t *seed, const float bounds[6], float out[3]);/* :57
 void orc_create_n_cubes(size_t n_cubes, const float bounds[6], float *tris, float *aabbs);
 /* create_ray stream (testbase.rs:687-691), rays [first, first+n) of the seed-0 stream. */
 void orc_create_rays(uint64_t first, size_t n, const float bounds[6], orc_ray_f32 *rays);
+void orc_primary_rays(const float cam[14], uint32_t width, uint32_t height, uint64_t first, size_t n, orc_ray_f32 *rays);
 /* generate_aligned_boxes (testbase.rs:109-116) → 21 AABBs (UnitBox::aabb :84-89). */
 void orc_aligned_boxes(float *aabbs /* 21*6 */);
 

@@ -99,6 +99,14 @@ def create_rays(first: int, n: int, bounds=DEFAULT_BOUNDS):
     return rays
 
 
+def primary_rays(cam, width: int, height: int, first: int, n: int):
+    """coherent primary rays (bvh_oracle.c orc_primary_rays): cam = eye3, right3, up3, forward3, tan_x, tan_y"""
+    c = np.ascontiguousarray(cam, dtype=np.float32).reshape(14)
+    rays = np.zeros(n, dtype=RAY_F32)
+    lib().orc_primary_rays(_p(c), C.c_uint32(width), C.c_uint32(height), C.c_uint64(first), C.c_size_t(n), _p(rays))
+    return rays
+
+
 def aligned_boxes():
     a = np.empty((21, 6), dtype=np.float32)
     lib().orc_aligned_boxes(_p(a))
