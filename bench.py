@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rays", type=int, default=1_000_000)
     ap.add_argument("--pmc-traffic", type=float, default=None,
-                    help="HBM bytes per k_traverse launch from a separate rocprofv3 --pmc pass (profiles/)")
+                    help="HBM bytes per launch of the traversal kernel from a separate rocprofv3 --pmc pass; default: "
+                         "the newest profiles/*_traffic.json (written by tools/profile_round.sh on this command)")
     return ap.parse_args()
 
 
@@ -162,9 +163,18 @@ def main():
     algo_bytes = R * ray_size + (V - VL) * flat_sz + VL * flat_sz + VL * 6 * elem + 4 * (H + R)
     kern_s = phases["traverse_kernel_ms"] * 1e-3
     achieved = algo_bytes / kern_s / 1e9
+    traffic, traffic_src = args.pmc_traffic, "--pmc-traffic"
+    if traffic is None and args.cubes == 10_000 and R == 1_000_000 and args.dtype == "f32":
+        import glob
+        found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=os.path.getmtime)
+        if found:
+            tj = json.load(open(found[-1]))
+            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), os.path.relpath(found[-1], ROOT)
     roofline = {
         "kernel": "k_traverse_lds", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.pmc_traffic,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "traffic_source": None if traffic is None else f"{traffic_src}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                          "of this command, bytes per launch, FETCH_SIZE doubled per MI355X_MICROARCH.md",
         "algorithmic_bytes_per_launch": int(algo_bytes), "kernel_ms": round(phases["traverse_kernel_ms"], 4),
         "slab_tests_per_s": round(V / kern_s, 1), "visited": int(V), "leaf_visits": int(VL), "hits": int(H),
         "device_steps": int(stats["device_steps"]),
