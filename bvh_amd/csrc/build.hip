@@ -685,13 +685,23 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
             }
             __syncthreads();
             MID_T(2);
-            // ---- phase 3: per-(sub-node, bucket) statistics over the sorted order (utils.rs:81-85)
+            // ---- phase 3: per-(sub-node, bucket) statistics over the sorted order (utils.rs:81-85).
+            //      Joins run on floats (one v_min/v_max each, common.hpp join_min/join_max); only a finished run
+            //      is converted to integer keys, for the LDS atomics that merge runs across threads and waves.
             {
-                Key curv[STAT_KEYS], firstv[STAT_KEYS];
+                T curv[STAT_KEYS], firstv[STAT_KEYS];
                 int cur_key = -1, first_key = -1;
                 bool have_first = false;
 #pragma unroll
-                for (int k = 0; k < STAT_KEYS; k++) { curv[k] = key_is_min(k) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF; firstv[k] = curv[k]; }
+                for (int k = 0; k < STAT_KEYS; k++) { curv[k] = key_is_min(k) ? Tr::inf() : -Tr::inf(); firstv[k] = curv[k]; }
+                auto flush = [&](int key, const T* v) {   // a complete (or wave-partial) run → LDS statistics
+                    Key* kk = s_keys + ((key >> 3) * NUM_BUCKETS + (key & 7)) * STAT_KEYS;
+#pragma unroll
+                    for (int k = 0; k < STAT_KEYS; k++) {
+                        if (key_is_min(k)) atomicMin(&kk[k], Tr::key(v[k]));
+                        else atomicMax(&kk[k], Tr::key(v[k]));
+                    }
+                };
 #pragma unroll
                 for (int j = 0; j < PPT; j++) {
                     if (sg[j] == SEG_NONE) continue;
@@ -702,12 +712,12 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
 #pragma unroll
                     for (int k = 1; k < NUM_BUCKETS; k++) b += (rel >= m->base[k]) ? 1 : 0;
                     const int key = sg[j] * 8 + b;
-                    Key v[STAT_KEYS];
+                    T v[STAT_KEYS];
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
                         const T mn = s_box[6 * p + k], mx = s_box[6 * p + 3 + k];
-                        v[k] = Tr::key(mn); v[3 + k] = Tr::key(mx);
-                        v[6 + k] = Tr::key(center1(mn, mx)); v[9 + k] = v[6 + k];
+                        v[k] = mn; v[3 + k] = mx;
+                        v[6 + k] = center1(mn, mx); v[9 + k] = v[6 + k];
                     }
                     if (key != cur_key) {
                         if (cur_key >= 0) {
@@ -716,9 +726,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
 #pragma unroll
                                 for (int k = 0; k < STAT_KEYS; k++) firstv[k] = curv[k];
                             } else {  // a run that starts and ends inside this thread
-                                Key* kk = s_keys + ((cur_key >> 3) * NUM_BUCKETS + (cur_key & 7)) * STAT_KEYS;
-#pragma unroll
-                                for (int k = 0; k < STAT_KEYS; k++) { if (key_is_min(k)) atomicMin(&kk[k], curv[k]); else atomicMax(&kk[k], curv[k]); }
+                                flush(cur_key, curv);
                             }
                         }
                         cur_key = key;
@@ -726,51 +734,51 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
                         for (int k = 0; k < STAT_KEYS; k++) curv[k] = v[k];
                     } else {
 #pragma unroll
-                        for (int k = 0; k < STAT_KEYS; k++) curv[k] = key_is_min(k) ? (v[k] < curv[k] ? v[k] : curv[k]) : (v[k] > curv[k] ? v[k] : curv[k]);
+                        for (int k = 0; k < STAT_KEYS; k++) curv[k] = key_is_min(k) ? join_min(curv[k], v[k]) : join_max(curv[k], v[k]);
                     }
                 }
-                // wave-level segmented inclusive scan over the threads' last runs
+                // wave-level segmented inclusive scan over the threads' LAST runs.  A lane heads a chain unless
+                // its only run continues the previous lane's last run; chain start = highest head at or below
+                // the lane.  A lane at the start of its chain fetches from itself (join(x, x) = x), and the 12
+                // cross-lane moves of a step are issued together.
                 const int fk = have_first ? first_key : cur_key;
                 const int prev_last = __shfl_up(cur_key, 1);
                 const bool cont_prev = lane > 0 && fk >= 0 && fk == prev_last;
-                bool hf = have_first || !cont_prev;
-                Key sv[STAT_KEYS];
+                const bool head = have_first || !cont_prev;
+                const unsigned long long heads = __ballot(head) | 1ull;
+                const unsigned long long below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+                const int chain0 = 63 - __clzll((long long)below);
+                T sv[STAT_KEYS];
 #pragma unroll
                 for (int k = 0; k < STAT_KEYS; k++) sv[k] = curv[k];
 #pragma unroll
                 for (int d = 1; d < WAVE; d <<= 1) {
-                    const int tf = __shfl_up((int)hf, d);
-                    const bool take = lane >= d && !hf;
+                    if (!__any((lane - chain0) >= d)) break;   // no chain is longer than d lanes
+                    const int up4 = ((lane - d) >= chain0 ? lane - d : lane) << 2;
+                    T u[STAT_KEYS];
 #pragma unroll
-                    for (int k = 0; k < STAT_KEYS; k++) {
-                        const Key u = __shfl_up(sv[k], d);
-                        const Key j2 = key_is_min(k) ? (u < sv[k] ? u : sv[k]) : (u > sv[k] ? u : sv[k]);
-                        sv[k] = take ? j2 : sv[k];
-                    }
-                    hf = take ? (tf != 0) : hf;
+                    for (int k = 0; k < STAT_KEYS; k++) u[k] = lane_fetch(sv[k], up4);
+#pragma unroll
+                    for (int k = 0; k < STAT_KEYS; k++) sv[k] = key_is_min(k) ? join_min(sv[k], u[k]) : join_max(sv[k], u[k]);
                 }
                 // the first run of a multi-run thread ends here: join the carry of the previous lane, flush
                 {
                     const bool need = have_first && cont_prev;
+                    const int pv4 = (lane > 0 ? lane - 1 : 0) << 2;
+                    T c[STAT_KEYS];
+#pragma unroll
+                    for (int k = 0; k < STAT_KEYS; k++) c[k] = lane_fetch(sv[k], pv4);
 #pragma unroll
                     for (int k = 0; k < STAT_KEYS; k++) {
-                        const Key c = __shfl_up(sv[k], 1);
-                        const Key j2 = key_is_min(k) ? (c < firstv[k] ? c : firstv[k]) : (c > firstv[k] ? c : firstv[k]);
+                        const T j2 = key_is_min(k) ? join_min(firstv[k], c[k]) : join_max(firstv[k], c[k]);
                         firstv[k] = need ? j2 : firstv[k];
                     }
-                    if (have_first) {
-                        Key* kk = s_keys + ((first_key >> 3) * NUM_BUCKETS + (first_key & 7)) * STAT_KEYS;
-#pragma unroll
-                        for (int k = 0; k < STAT_KEYS; k++) { if (key_is_min(k)) atomicMin(&kk[k], firstv[k]); else atomicMax(&kk[k], firstv[k]); }
-                    }
+                    if (have_first) flush(first_key, firstv);
                 }
                 // the last run is flushed by the last lane it reaches inside this wave
                 const int next_cont = __shfl_down((int)cont_prev, 1);
-                if (cur_key >= 0 && (lane == WAVE - 1 || !next_cont)) {
-                    Key* kk = s_keys + ((cur_key >> 3) * NUM_BUCKETS + (cur_key & 7)) * STAT_KEYS;
-#pragma unroll
-                    for (int k = 0; k < STAT_KEYS; k++) { if (key_is_min(k)) atomicMin(&kk[k], sv[k]); else atomicMax(&kk[k], sv[k]); }
-                }
+                // (a multi-run next lane that continues our run took our value as its carry and flushed it)
+                if (cur_key >= 0 && (lane == WAVE - 1 || !next_cont)) flush(cur_key, sv);
             }
             __syncthreads();
             MID_T(3);
