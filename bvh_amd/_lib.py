@@ -21,6 +21,7 @@ TRAVERSE_T_SLICE = 1
 TRAVERSE_STATS = 2
 TRAVERSE_TRIANGLES = 4
 TRAVERSE_CLOSEST = 8
+TRAVERSE_COHERENT = 16
 
 NODE_F32 = np.dtype([("l_min", "<f4", 3), ("l_max", "<f4", 3), ("r_min", "<f4", 3), ("r_max", "<f4", 3),
                      ("parent", "<u4"), ("l", "<u4"), ("r", "<u4"), ("shape", "<u4")])

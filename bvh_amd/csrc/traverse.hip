@@ -139,9 +139,20 @@ template <typename T, int MODE> struct LaneRay {
     }
 };
 
-constexpr uint32_t POOL_CHUNK = 64;  // >= 64: one wave-step reports at most 64 hits
+// Hit records go to the pool in per-wave chunks: one global atomic per chunk instead of one per wave-step with
+// a hit.  One address sustains only ≈88 atomics/µs on this chip, and a hit-heavy scene (58 M hits from 10 M
+// primary rays on the stand-in atrium) made the walk 8x slower with fixed 64-record chunks; a wave's chunk size
+// therefore doubles with every chunk it fills (64 → 8192), which bounds the slack by the records written.
+constexpr uint32_t POOL_CHUNK_MIN = 64;     // >= 64: one wave-step reports at most 64 hits
+constexpr uint32_t POOL_CHUNK_MAX = 8192;
 // wave-uniform cursor into this wave's current chunk of the hit pool
-struct PoolCursor { unsigned long long pos = 0; uint32_t left = 0; };
+struct PoolCursor { unsigned long long pos = 0; uint32_t left = 0; uint32_t next = POOL_CHUNK_MIN; };
+
+// mark the unused tail of a wave's chunk so that k_hits_scatter skips it
+__device__ __forceinline__ void pool_invalidate_tail(HitRec* pool, unsigned long long pool_cap, const PoolCursor& pc, int lane) {
+    for (uint32_t j = (uint32_t)lane; j < pc.left; j += WAVE)
+        if (pc.pos + j < pool_cap) pool[pc.pos + j].ray = NONE;
+}
 
 // A leaf box was hit (rec) in some lanes of the wave: do what the MODE asks for with the shape.
 template <typename T, int MODE>
@@ -161,15 +172,16 @@ __device__ __forceinline__ void report(bool rec, uint32_t shape, T t0, T t1, Lan
     constexpr int NV = ModeVals<MODE>::N;
     const uint32_t h = (uint32_t)__popcll(m);
     if (h > pc.left) {   // wave-uniform: start a new chunk, invalidate what is left of the old one
-        if ((uint32_t)lane < pc.left && pc.pos + lane < w.pool_cap) w.pool[pc.pos + lane].ray = NONE;
+        pool_invalidate_tail(w.pool, w.pool_cap, pc, lane);
         unsigned int blo = 0, bhi = 0;
         if (lane == 0) {
-            unsigned long long b = atomicAdd(&w.ctr[0], (unsigned long long)POOL_CHUNK);
+            unsigned long long b = atomicAdd(&w.ctr[0], (unsigned long long)pc.next);
             blo = (unsigned int)b; bhi = (unsigned int)(b >> 32);
         }
         blo = __builtin_amdgcn_readfirstlane(blo); bhi = __builtin_amdgcn_readfirstlane(bhi);
         pc.pos = ((unsigned long long)bhi << 32) | blo;
-        pc.left = POOL_CHUNK;
+        pc.left = pc.next;
+        pc.next = pc.next < POOL_CHUNK_MAX ? pc.next * 2 : POOL_CHUNK_MAX;
     }
     if (rec) {
         const unsigned long long slot = pc.pos + __popcll(m & lt);
@@ -188,7 +200,7 @@ template <typename T, int MODE>
 __device__ __forceinline__ void walk_epilogue(const WalkOut<T>& w, PoolCursor& pc, int lane, bool stats,
                                               unsigned long long steps, unsigned long long leaf_steps,
                                               unsigned long long wsteps, unsigned long long cands) {
-    if (MODE != MODE_CLOSEST && (uint32_t)lane < pc.left && pc.pos + lane < w.pool_cap) w.pool[pc.pos + lane].ray = NONE;
+    if (MODE != MODE_CLOSEST) pool_invalidate_tail(w.pool, w.pool_cap, pc, lane);
     if (stats) {
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
@@ -472,14 +484,14 @@ __global__ __launch_bounds__(256) void k_hits_scatter(const HitRec* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 template <typename T, int MODE, bool STATS>
-static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, const WalkOut<T>& w) {
+static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, const WalkOut<T>& w, bool coherent) {
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
     const uint32_t n_trav = (uint32_t)t->n_trav;
     const TravNode<T>* nodes = t->trav.as<TravNode<T>>();
     // variant 0: one ray per lane per launch; 2: persistent workgroups + LDS-resident top of the tree
     int variant = ctx->tune[BVHGPU_TUNE_TRAVERSE_VARIANT];
-    if (variant != 0 && (t->slot_entry.p == nullptr || n_rays < (size_t)ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS]))
+    if (variant != 0 && (t->slot_entry.p == nullptr || n_rays < (size_t)ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS] || coherent))
         variant = 0;
     if (variant == 0) {
         hipLaunchKernelGGL((k_traverse<T, MODE, STATS>), dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, nodes,
@@ -509,6 +521,7 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
     const bool stats = (flags & BVHGPU_TRAVERSE_STATS) != 0;
+    const bool coherent = (flags & BVHGPU_TRAVERSE_COHERENT) != 0;
     const int mode = (flags & BVHGPU_TRAVERSE_CLOSEST) ? MODE_CLOSEST
                    : (flags & BVHGPU_TRAVERSE_TRIANGLES) ? MODE_TRIANGLES
                    : (flags & BVHGPU_TRAVERSE_T_SLICE) ? MODE_T_SLICE : MODE_INDICES;
@@ -526,14 +539,14 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
 #define DISPATCH_WALK()                                                                              \
     do {                                                                                             \
         switch (mode) {                                                                              \
-            case MODE_INDICES: if (stats) launch_walk<T, MODE_INDICES, true>(t, rays_dev, n_rays, w);  \
-                               else launch_walk<T, MODE_INDICES, false>(t, rays_dev, n_rays, w); break; \
-            case MODE_T_SLICE: if (stats) launch_walk<T, MODE_T_SLICE, true>(t, rays_dev, n_rays, w);  \
-                               else launch_walk<T, MODE_T_SLICE, false>(t, rays_dev, n_rays, w); break; \
-            case MODE_TRIANGLES: if (stats) launch_walk<T, MODE_TRIANGLES, true>(t, rays_dev, n_rays, w); \
-                                 else launch_walk<T, MODE_TRIANGLES, false>(t, rays_dev, n_rays, w); break; \
-            default: if (stats) launch_walk<T, MODE_CLOSEST, true>(t, rays_dev, n_rays, w);           \
-                     else launch_walk<T, MODE_CLOSEST, false>(t, rays_dev, n_rays, w); break;         \
+            case MODE_INDICES: if (stats) launch_walk<T, MODE_INDICES, true>(t, rays_dev, n_rays, w, coherent);  \
+                               else launch_walk<T, MODE_INDICES, false>(t, rays_dev, n_rays, w, coherent); break; \
+            case MODE_T_SLICE: if (stats) launch_walk<T, MODE_T_SLICE, true>(t, rays_dev, n_rays, w, coherent);  \
+                               else launch_walk<T, MODE_T_SLICE, false>(t, rays_dev, n_rays, w, coherent); break; \
+            case MODE_TRIANGLES: if (stats) launch_walk<T, MODE_TRIANGLES, true>(t, rays_dev, n_rays, w, coherent); \
+                                 else launch_walk<T, MODE_TRIANGLES, false>(t, rays_dev, n_rays, w, coherent); break; \
+            default: if (stats) launch_walk<T, MODE_CLOSEST, true>(t, rays_dev, n_rays, w, coherent);           \
+                     else launch_walk<T, MODE_CLOSEST, false>(t, rays_dev, n_rays, w, coherent); break;         \
         }                                                                                            \
     } while (0)
 

@@ -59,6 +59,8 @@ typedef enum { BVHGPU_HOST = 0, BVHGPU_DEVICE = 1 } bvhgpu_mem;
 #define BVHGPU_TRAVERSE_CLOSEST 8u   /* triangle stage fused into the walk, no CSR: per ray the candidate with the smallest
                                         Intersection.distance (first one on ties) and its shape index */
 
+#define BVHGPU_TRAVERSE_COHERENT 16u /* hint: neighbouring rays are similar (primary rays): walk one ray per lane in lock-step */
+
 /* ---- POD layouts (little-endian, natural alignment, no packing pragmas) ---- */
 
 /* Aabb<T,3> (aabb_impl.rs:10-16) is passed as 6 scalars: min x,y,z, max x,y,z. */
