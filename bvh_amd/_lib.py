@@ -84,6 +84,8 @@ SYMBOLS = [
     ("bvhgpu_gen_rays_f64", _i, [_vp, C.c_uint64, _sz, _vp, _vp]),
     ("bvhgpu_gen_primary_rays_f32", _i, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint64, _sz, _vp]),
     ("bvhgpu_gen_primary_rays_f64", _i, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint64, _sz, _vp]),
+    ("bvhgpu_nearest_f32", _i, [_vp, _vp, _sz, _i, _i, _vp, _vp]),
+    ("bvhgpu_nearest_f64", _i, [_vp, _vp, _sz, _i, _i, _vp, _vp]),
     ("bvhgpu_ray_triangle_pairs_f32", _i, [_vp, _vp, _vp, _sz, _i, _vp]),
     ("bvhgpu_ray_triangle_pairs_f64", _i, [_vp, _vp, _vp, _sz, _i, _vp]),
     ("bvhgpu_traverse_f32", _i, [_vp, _vp, _sz, _i, _u, _pp]),

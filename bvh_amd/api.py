@@ -406,6 +406,24 @@ class _TreeBase:
         check(lib.bvhgpu_hits_fetch_closest(self._hits.h, ptr(isect), ptr(shape), HOST), self.ctx._h)
         return isect, shape, sd
 
+    # ---- point query ---------------------------------------------------------------------
+    def nearest_batch(self, points, triangles: bool = False):
+        """<FlatBvh as BoundingHierarchy>::nearest_to (flat_bvh.rs:513-562) for many points.  Shape distance: the
+        shape's own AABB (UnitBox, testbase.rs:101-105) or, with triangles=True, the closest point on the triangle
+        (testbase.rs:436-443; needs set_triangles).  returns (shape[n] u32 — NONE for an empty hierarchy, dist[n])"""
+        ft = np.float32 if self.sfx == "f32" else np.float64
+        p = np.ascontiguousarray(points, dtype=ft).reshape(-1, 3)
+        shape = np.zeros(len(p), dtype=np.uint32)
+        dist = np.zeros(len(p), dtype=ft)
+        fn = getattr(_lib.load(), f"bvhgpu_nearest_{self.sfx}")
+        check(fn(self._t, ptr(p), len(p), HOST, 1 if triangles else 0, ptr(shape), ptr(dist)), self.ctx._h)
+        return shape, dist
+
+    def nearest_to(self, query, shapes: Sequence, triangles: bool = False):
+        """BoundingHierarchy::nearest_to (bounding_hierarchy.rs:262-336): Option<(&Shape, distance)>."""
+        s, d = self.nearest_batch([query], triangles)
+        return None if s[0] == NONE else (shapes[int(s[0])], d[0])
+
     def hits_device(self) -> Tuple[int, int]:
         """device addresses of the last result's (offsets, indices) — valid until the next traverse."""
         o, i, t = C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -591,6 +609,12 @@ class Bvh(_TreeBase):
         (bvh_node.rs:288-319 visits the same boxes in the same order)."""
         self.flatten_in_place()
         return super().traverse(query, shapes)
+
+    def nearest_batch(self, points, triangles: bool = False):
+        """Bvh::nearest_to answered by the flat loop (flat_bvh.rs:513-562): the distance is the same as the
+        recursive form's (bvh_node.rs:327-374); on exact ties the two reference forms may name different shapes."""
+        self.flatten_in_place()
+        return super().nearest_batch(points, triangles)
 
 
 class _FlatView(FlatBvh):

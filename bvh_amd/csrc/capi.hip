@@ -253,6 +253,36 @@ int do_pairs(bvhgpu_ctx* ctx, const typename Traits<T>::Ray* rays, const T* tris
     });
 }
 
+template <typename T>
+int do_nearest(bvhgpu_tree* t, const T* points, size_t n, int mem, int kind, uint32_t* out_shape, T* out_dist) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    bvhgpu_ctx* ctx = t->ctx;
+    if (t->dtype != Traits<T>::dtype) return fail(ctx, BVHGPU_DTYPE_MISMATCH, "tree dtype differs from point dtype");
+    if (!t->flattened) return fail(ctx, BVHGPU_NOT_FLATTENED, "call bvhgpu_flatten first");
+    if (n && (!points || !out_shape || !out_dist)) return fail(ctx, BVHGPU_INVALID_ARG, "NULL argument");
+    if (kind != 0 && kind != 1) return fail(ctx, BVHGPU_INVALID_ARG, "shape kind must be 0 (AABB) or 1 (triangle)");
+    if (kind == 1 && !t->has_tris) return fail(ctx, BVHGPU_INVALID_ARG, "triangle distance needs bvhgpu_tree_set_triangles first");
+    if (n >= 0xFFFFFFFFull) return fail(ctx, BVHGPU_OVERFLOW, "too many points in one call");
+    return guarded(ctx, [&] {
+        use_device(ctx);
+        const T* pd = points; uint32_t* sd = out_shape; T* dd = out_dist;
+        if (mem == BVHGPU_HOST) {
+            const size_t pb = n * 3 * sizeof(T), sb = n * 4, db = n * sizeof(T);
+            ctx->upload.reserve(pb + sb + db + 64);
+            char* base = ctx->upload.as<char>();
+            if (pb) BVH_HIP(hipMemcpyAsync(base, points, pb, hipMemcpyHostToDevice, ctx->stream));
+            pd = reinterpret_cast<const T*>(base); dd = reinterpret_cast<T*>(base + pb); sd = reinterpret_cast<uint32_t*>(base + pb + db);
+        }
+        if (t->n == 0) {   // empty hierarchy → None for every query (flat_bvh.rs:518-520)
+            if (n) { BVH_HIP(hipMemsetAsync(sd, 0xFF, n * 4, ctx->stream)); BVH_HIP(hipMemsetAsync(dd, 0, n * sizeof(T), ctx->stream)); }
+        } else {
+            nearest_batch<T>(t, pd, n, kind, sd, dd);
+        }
+        if (mem == BVHGPU_HOST) { copy_out(ctx, out_dist, dd, n * sizeof(T), BVHGPU_HOST); copy_out(ctx, out_shape, sd, n * 4, BVHGPU_HOST); }
+        return (int)BVHGPU_OK;
+    });
+}
+
 }  // namespace
 
 #ifdef BVH_PROFILE_MID
@@ -537,6 +567,12 @@ int bvhgpu_gen_primary_rays_f64(bvhgpu_ctx* ctx, const float cam[14], uint32_t w
     if (!ctx || !cam || (n && !out_dev) || !width || !height) return fail(ctx, BVHGPU_INVALID_ARG, "bad argument");
     if (n >= 0xFFFFFFFFull) return fail(ctx, BVHGPU_OVERFLOW, "too many rays in one call");
     return guarded(ctx, [&] { use_device(ctx); gen_primary<double>(ctx, cam, width, height, first, n, out_dev); return (int)BVHGPU_OK; });
+}
+int bvhgpu_nearest_f32(bvhgpu_tree* t, const float* points, size_t n, int mem, int kind, uint32_t* out_shape, float* out_dist) {
+    return do_nearest<float>(t, points, n, mem, kind, out_shape, out_dist);
+}
+int bvhgpu_nearest_f64(bvhgpu_tree* t, const double* points, size_t n, int mem, int kind, uint32_t* out_shape, double* out_dist) {
+    return do_nearest<double>(t, points, n, mem, kind, out_shape, out_dist);
 }
 int bvhgpu_ray_triangle_pairs_f32(bvhgpu_ctx* ctx, const bvhgpu_ray_f32* rays, const float* tris, size_t n, int mem, float* out) {
     return do_pairs<float>(ctx, rays, tris, n, mem, out);

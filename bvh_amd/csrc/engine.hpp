@@ -122,6 +122,8 @@ template <typename T>
 void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, unsigned flags,
                     bvhgpu_hits* h);
 template <typename T>
+void nearest_batch(bvhgpu_tree* t, const T* points_dev, size_t n, int kind, uint32_t* out_shape_dev, T* out_dist_dev);
+template <typename T>
 void ray_triangle_pairs(bvhgpu_ctx* ctx, const typename Traits<T>::Ray* rays_dev, const T* tris_dev, size_t n, T* out_dev);
 template <typename T>
 void rays_new(bvhgpu_ctx* ctx, const T* origins_dev, const T* dirs_dev, size_t n, typename Traits<T>::Ray* out_dev);

@@ -648,6 +648,159 @@ template void traverse_batch<float>(bvhgpu_tree*, const bvhgpu_ray_f32*, size_t,
 template void traverse_batch<double>(bvhgpu_tree*, const bvhgpu_ray_f64*, size_t, unsigned, bvhgpu_hits*);
 
 // ------------------------------------------------------------------------------------------------
+// <FlatBvh as BoundingHierarchy>::nearest_to (flat_bvh.rs:513-562) for a batch of query points.
+// Shape distance = <Triangle as PointDistance>::distance_squared (testbase.rs:367-443: Embree's closest point on a
+// triangle with degenerate-triangle guards) or the shape's own Aabb::min_distance_squared (UnitBox,
+// testbase.rs:101-105; aabb_impl.rs:618-629).  Same operation order as the reference, no contraction.
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T aabb_min_dist2(const T mn[3], const T mx[3], const T p[3]) {
+    T out[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const T size = mx[k] - mn[k];
+        const T half = size * (T)0.5;
+        const T centre = mn[k] + half;
+        const T delta = p[k] - centre;
+        const T q = fabs(delta) - half;
+        out[k] = (q > (T)0) ? q : (T)0;   // x.max(0): NaN → 0
+    }
+    return dot3<T>(out, out);
+}
+template <typename T> __device__ __forceinline__ void closest_point_segment(const T p[3], const T a[3], const T b[3], T out[3]) {
+    T ab[3], ap[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ab[k] = b[k] - a[k]; ap[k] = p[k] - a[k]; }
+    const T m = dot3<T>(ab, ab);
+    T s12 = dot3<T>(ab, ap) / m;
+    s12 = s12 < (T)0 ? (T)0 : (s12 > (T)1 ? (T)1 : s12);   // f32::clamp (keeps NaN)
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const T t = s12 * ab[k]; out[k] = a[k] + t; }
+}
+template <typename T> __device__ void closest_point_triangle(const T p[3], const T a[3], const T b[3], const T c[3], T out[3]) {
+    const bool ab_eq = a[0] == b[0] && a[1] == b[1] && a[2] == b[2];
+    const bool bc_eq = b[0] == c[0] && b[1] == c[1] && b[2] == c[2];
+    const bool ac_eq = a[0] == c[0] && a[1] == c[1] && a[2] == c[2];
+    if (ab_eq && bc_eq && ac_eq) { out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; return; }
+    if (ab_eq) { closest_point_segment<T>(p, a, c, out); return; }
+    if (bc_eq || ac_eq) { closest_point_segment<T>(p, a, b, out); return; }
+    T ab[3], ac[3], ap[3], bp[3], cp[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { ab[k] = b[k] - a[k]; ac[k] = c[k] - a[k]; ap[k] = p[k] - a[k]; }
+    const T d1 = dot3<T>(ab, ap), d2 = dot3<T>(ac, ap);
+    if (d1 <= (T)0 && d2 <= (T)0) { out[0] = a[0]; out[1] = a[1]; out[2] = a[2]; return; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) bp[k] = p[k] - b[k];
+    const T d3 = dot3<T>(ab, bp), d4 = dot3<T>(ac, bp);
+    if (d3 >= (T)0 && d4 <= d3) { out[0] = b[0]; out[1] = b[1]; out[2] = b[2]; return; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) cp[k] = p[k] - c[k];
+    const T d5 = dot3<T>(ab, cp), d6 = dot3<T>(ac, cp);
+    if (d6 >= (T)0 && d5 <= d6) { out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; return; }
+    const T m1 = d1 * d4, m2 = d3 * d2;
+    const T vc = m1 - m2;
+    if (vc <= (T)0 && d1 >= (T)0 && d3 <= (T)0) {
+        const T den = d1 - d3;
+        const T v = d1 / den;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const T t = v * ab[k]; out[k] = a[k] + t; }
+        return;
+    }
+    const T m3 = d5 * d2, m4 = d1 * d6;
+    const T vb = m3 - m4;
+    if (vb <= (T)0 && d2 >= (T)0 && d6 <= (T)0) {
+        const T den = d2 - d6;
+        const T v = d2 / den;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const T t = v * ac[k]; out[k] = a[k] + t; }
+        return;
+    }
+    const T m5 = d3 * d6, m6 = d5 * d4;
+    const T va = m5 - m6;
+    const T e43 = d4 - d3, e56 = d5 - d6;
+    if (va <= (T)0 && e43 >= (T)0 && e56 >= (T)0) {
+        const T den = e43 + e56;
+        const T v = e43 / den;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const T cb = c[k] - b[k]; const T t = v * cb; out[k] = b[k] + t; }
+        return;
+    }
+    T sum = va + vb;
+    sum = sum + vc;
+    const T denom = (T)1 / sum;
+    const T v = vb * denom, w = vc * denom;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const T t1 = v * ab[k]; const T t2 = w * ac[k]; const T r = a[k] + t1; out[k] = r + t2; }
+}
+template <typename T> __device__ __forceinline__ T triangle_dist2(const T* __restrict__ tri, const T p[3]) {
+    const T a[3] = {tri[0], tri[1], tri[2]}, b[3] = {tri[3], tri[4], tri[5]}, c[3] = {tri[6], tri[7], tri[8]};
+    T nearest[3], diff[3];
+    closest_point_triangle<T>(p, a, b, c, nearest);
+#pragma unroll
+    for (int k = 0; k < 3; k++) diff[k] = p[k] - nearest[k];
+    return dot3<T>(diff, diff);
+}
+
+// one query point per lane, the same loop as flat_bvh.rs:533-558 over the folded array: a folded leaf entry
+// stands for the navigator (min_distance_squared test of its box) followed by the leaf (exact shape distance)
+template <typename T, bool TRIANGLE, bool UNFOLDED>
+__global__ __launch_bounds__(256) void k_nearest(const TravNode<T>* __restrict__ nodes, uint32_t n_trav,
+                                                 const T* __restrict__ shape_aabbs, const T* __restrict__ tris,
+                                                 const T* __restrict__ points, uint32_t n, uint32_t* __restrict__ out_shape,
+                                                 T* __restrict__ out_dist) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const T p[3] = {points[3 * (size_t)q], points[3 * (size_t)q + 1], points[3 * (size_t)q + 2]};
+    bool has = false;
+    T best = 0;
+    uint32_t bs = NONE;
+    uint32_t i = 0;
+    while (i < n_trav) {
+        const NodeRegs<T> nd = load_node(nodes + i);
+        const bool leaf = trav_is_leaf(nd.shape);
+        bool enter = true;
+        if (!(UNFOLDED && leaf)) {
+            const T md = aabb_min_dist2<T>(nd.mn, nd.mx, p);
+            enter = !has || md < best;                           // :550
+        }
+        if (leaf) {
+            if (enter) {
+                T d;
+                if (TRIANGLE) d = triangle_dist2<T>(tris + 9 * (size_t)nd.shape, p);
+                else {
+                    const T* sb = shape_aabbs + 6 * (size_t)nd.shape;
+                    const T mn[3] = {sb[0], sb[1], sb[2]}, mx[3] = {sb[3], sb[4], sb[5]};
+                    d = aabb_min_dist2<T>(mn, mx, p);
+                }
+                if (!has || d < best) { has = true; best = d; bs = nd.shape; }   // :540-542
+            }
+            i = nd.exit;
+        } else {
+            i = enter ? i + 1 : nd.exit;
+        }
+    }
+    out_shape[q] = bs;
+    out_dist[q] = has ? sqrt(best) : (T)0;                       // :561
+}
+
+template <typename T>
+void nearest_batch(bvhgpu_tree* t, const T* points_dev, size_t n, int kind, uint32_t* out_shape_dev, T* out_dist_dev) {
+    if (!n) return;
+    hipStream_t st = t->ctx->stream;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    const TravNode<T>* nodes = t->trav.as<TravNode<T>>();
+    const uint32_t n_trav = (uint32_t)t->n_trav;
+    const bool unfolded = t->unfolded || t->n == 1;   // a single-shape tree has one (leaf) entry and no navigator
+#define LAUNCH_NEAREST(TRI, UNF) hipLaunchKernelGGL((k_nearest<T, TRI, UNF>), grid, block, 0, st, nodes, n_trav, t->aabbs.as<T>(), \
+                                                    t->tris.as<T>(), points_dev, (uint32_t)n, out_shape_dev, out_dist_dev)
+    if (kind == 1) { if (unfolded) LAUNCH_NEAREST(true, true); else LAUNCH_NEAREST(true, false); }
+    else { if (unfolded) LAUNCH_NEAREST(false, true); else LAUNCH_NEAREST(false, false); }
+#undef LAUNCH_NEAREST
+    BVH_HIP(hipGetLastError());
+}
+template void nearest_batch<float>(bvhgpu_tree*, const float*, size_t, int, uint32_t*, float*);
+template void nearest_batch<double>(bvhgpu_tree*, const double*, size_t, int, uint32_t*, double*);
+
+// ------------------------------------------------------------------------------------------------
 // Ray::intersects_triangle for n independent (ray, triangle) pairs — ray_impl.rs:154-213
 // ------------------------------------------------------------------------------------------------
 template <typename T>

@@ -155,6 +155,15 @@ int bvhgpu_gen_rays_f32(bvhgpu_ctx *ctx, uint64_t first, size_t n, const float b
 /* same stream widened to f64 AFTER generation (f32 origin/target → f64 Ray::new), for the f64 config. */
 int bvhgpu_gen_rays_f64(bvhgpu_ctx *ctx, uint64_t first, size_t n, const float bounds[6], bvhgpu_ray_f64 *out_dev);
 
+/* ---- point query: replaces <FlatBvh as BoundingHierarchy>::nearest_to (flat_bvh.rs:513-562; trait
+ * bounding_hierarchy.rs:262-336) for n query points (n x 3).  The shape's PointDistance::distance_squared is a user
+ * callback in the reference; the two the reference's harness defines are built in: kind 0 = the shape's own
+ * Aabb::min_distance_squared (UnitBox, testbase.rs:101-105; aabb_impl.rs:618-629), kind 1 = closest point on the
+ * triangle (testbase.rs:367-443, needs bvhgpu_tree_set_triangles).  out_shape[i] = shape index (BVHGPU_NONE for an
+ * empty hierarchy), out_dist[i] = the distance (not squared, :561).  `mem` applies to all three buffers. ---- */
+int bvhgpu_nearest_f32(bvhgpu_tree *tree, const float *points, size_t n, int mem, int kind, uint32_t *out_shape, float *out_dist);
+int bvhgpu_nearest_f64(bvhgpu_tree *tree, const double *points, size_t n, int mem, int kind, uint32_t *out_shape, double *out_dist);
+
 /* Ray::intersects_triangle (ray_impl.rs:154-213) for n independent pairs: ray i against triangle i
  * (tris: n x [a xyz, b xyz, c xyz]); out: n x {distance,u,v}.  `mem` applies to all three buffers. */
 int bvhgpu_ray_triangle_pairs_f32(bvhgpu_ctx *ctx, const bvhgpu_ray_f32 *rays, const float *tris, size_t n, int mem, float *out);

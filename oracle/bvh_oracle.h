@@ -98,6 +98,12 @@ void orc_aligned_boxes(float *aabbs /* 21*6 */);
     int orc_ray_intersects_aabb_##S(const RAY *r, const T box[6]);     /* intersect_default.rs:16-37 */ \
     int orc_ray_slice_##S(const RAY *r, const T box[6], T out[2]);     /* ray_impl.rs:118-145 */ \
     T orc_ray_triangle_##S(const RAY *r, const T a[3], const T b[3], const T c[3], T uv[2]); /* :154-213 */ \
+    T orc_aabb_min_dist2_##S(const T box[6], const T p[3]); /* aabb_impl.rs:618-629 */                 \
+    T orc_triangle_dist2_##S(const T tri[9], const T p[3]); /* testbase.rs:367-443 */                    \
+    void orc_nearest_flat_##S(const FLAT *flat, size_t n_flat, const T *shape_aabbs, const T *tris, int kind, \
+                              const T *points, size_t n, uint32_t *out_shape, T *out_dist);               \
+    void orc_nearest_tree_##S(const NODE *nodes, size_t n_nodes, const T *shape_aabbs, const T *tris, int kind, \
+                              const T *points, size_t n, uint32_t *out_shape, T *out_dist);               \
     void orc_triangle_stage_##S(const T *tris, const RAY *rays, size_t n_rays, const uint32_t *offsets,  \
                                 const uint32_t *indices, T *isect, T *closest, uint32_t *closest_prim);  \
     T orc_surface_area_##S(const T box[6]);                            /* aabb_impl.rs:551-554 */\

@@ -260,6 +260,39 @@ def triangle_stage(tris, rays, offsets, indices):
     return isect, closest, prim
 
 
+def aabb_min_dist2(box, p, dtype=np.float32):
+    s = _sfx(dtype)
+    fn = getattr(lib(), f"orc_aabb_min_dist2_{s}")
+    fn.restype = C.c_float if s == "f32" else C.c_double
+    return dtype(fn(_p(np.ascontiguousarray(box, dtype=dtype).reshape(6)), _p(np.ascontiguousarray(p, dtype=dtype).reshape(3))))
+
+
+def triangle_dist2(tri, p, dtype=np.float32):
+    s = _sfx(dtype)
+    fn = getattr(lib(), f"orc_triangle_dist2_{s}")
+    fn.restype = C.c_float if s == "f32" else C.c_double
+    return dtype(fn(_p(np.ascontiguousarray(tri, dtype=dtype).reshape(9)), _p(np.ascontiguousarray(p, dtype=dtype).reshape(3))))
+
+
+def nearest(tree_or_flat, shape_aabbs, points, tris=None):
+    """BoundingHierarchy::nearest_to for n points: FlatBvh loop (flat_bvh.rs:513-562) if given a flat array,
+    Bvh recursion (bvh_node.rs:327-374) if given a node array.  Shape distance: triangles if `tris` is given,
+    else the shape's own AABB (UnitBox, testbase.rs:101-105).  returns (shape[n] u32, dist[n])"""
+    is_flat = tree_or_flat.dtype in (FLAT_F32, FLAT_F64)
+    s = "f32" if tree_or_flat.dtype in (FLAT_F32, NODE_F32) else "f64"
+    ft = _types(s)[0]
+    sa = np.ascontiguousarray(shape_aabbs, dtype=ft).reshape(-1, 6)
+    pts = np.ascontiguousarray(points, dtype=ft).reshape(-1, 3)
+    t = None if tris is None else np.ascontiguousarray(tris, dtype=ft).reshape(-1, 9)
+    shape = np.zeros(len(pts), dtype=np.uint32)
+    dist = np.zeros(len(pts), dtype=ft)
+    fn = getattr(lib(), f"orc_nearest_{'flat' if is_flat else 'tree'}_{s}")
+    fn.restype = None
+    fn(_p(np.ascontiguousarray(tree_or_flat)), C.c_size_t(len(tree_or_flat)), _p(sa), _p(t), C.c_int(0 if t is None else 1),
+       _p(pts), C.c_size_t(len(pts)), _p(shape), _p(dist))
+    return shape, dist
+
+
 def check_tree(nodes, aabbs) -> int:
     s = "f32" if nodes.dtype == NODE_F32 else "f64"
     ft = _types(s)[0]

@@ -294,3 +294,65 @@ def ray_triangle(ray, a, b, c):  # ray_impl.rs:154-213, written independently of
             return ft(np.inf), u, v
         dist = ft(dot(ac, vvec) * inv_det)
         return (dist if dist > np.finfo(ft).eps else ft(np.inf)), u, v
+
+
+def aabb_min_dist2(box, p, ft=np.float32):  # aabb_impl.rs:618-629, independent restatement
+    box = [ft(v) for v in box]
+    p = [ft(v) for v in p]
+    out = []
+    with np.errstate(all="ignore"):
+        for k in range(3):
+            half = ft((box[3 + k] - box[k]) * ft(0.5))
+            centre = ft(box[k] + half)
+            q = ft(abs(ft(p[k] - centre)) - half)
+            out.append(q if q > 0 else ft(0))
+        return ft(ft(out[0] * out[0] + out[1] * out[1]) + out[2] * out[2])
+
+
+def triangle_dist2(tri, p, ft=np.float32):  # testbase.rs:353-443, independent restatement
+    a, b, c = (np.asarray(tri, dtype=ft).reshape(3, 3)[i] for i in range(3))
+    p = np.asarray(p, dtype=ft)
+
+    def dot(x, y):
+        return ft(ft(ft(x[0] * y[0]) + ft(x[1] * y[1])) + ft(x[2] * y[2]))
+
+    def segment(a, b):
+        ab = b - a
+        s = ft(dot(ab, p - a) / dot(ab, ab))
+        s = ft(0) if s < 0 else (ft(1) if s > 1 else s)
+        return a + s * ab
+
+    def closest():
+        e_ab, e_bc, e_ac = bool((a == b).all()), bool((b == c).all()), bool((a == c).all())
+        if e_ab and e_bc and e_ac:
+            return a
+        if e_ab:
+            return segment(a, c)
+        if e_bc or e_ac:
+            return segment(a, b)
+        ab, ac, ap = b - a, c - a, p - a
+        d1, d2 = dot(ab, ap), dot(ac, ap)
+        if d1 <= 0 and d2 <= 0:
+            return a
+        bp = p - b
+        d3, d4 = dot(ab, bp), dot(ac, bp)
+        if d3 >= 0 and d4 <= d3:
+            return b
+        cp = p - c
+        d5, d6 = dot(ab, cp), dot(ac, cp)
+        if d6 >= 0 and d5 <= d6:
+            return c
+        vc = ft(ft(d1 * d4) - ft(d3 * d2))
+        if vc <= 0 and d1 >= 0 and d3 <= 0:
+            return a + ft(d1 / ft(d1 - d3)) * ab
+        vb = ft(ft(d5 * d2) - ft(d1 * d6))
+        if vb <= 0 and d2 >= 0 and d6 <= 0:
+            return a + ft(d2 / ft(d2 - d6)) * ac
+        va = ft(ft(d3 * d6) - ft(d5 * d4))
+        if va <= 0 and ft(d4 - d3) >= 0 and ft(d5 - d6) >= 0:
+            return b + ft(ft(d4 - d3) / ft(ft(d4 - d3) + ft(d5 - d6))) * (c - b)
+        denom = ft(ft(1) / ft(ft(va + vb) + vc))
+        return (a + ft(vb * denom) * ab) + ft(vc * denom) * ac
+    with np.errstate(all="ignore"):
+        d = p - closest()
+        return dot(d, d)

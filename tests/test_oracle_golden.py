@@ -201,6 +201,58 @@ def test_reference_ray_hits_triangle_property_on_oracle():
     assert np.all((inside | border)[front & ~near_edge])
 
 
+# ---------------------------------------------------------------- point queries (nearest_to)
+def test_reference_nearest_to_doc_tests():
+    """aabb_impl.rs:603-614 (min_distance_squared of (20,0,0) to [0,10]^3 is 10^2) and the nearest_to doc example
+    of bounding_hierarchy.rs / flat_bvh.rs:440-508: 1000 unit boxes at (i,i,i), query (5.0,5.7,5.3) → id 5."""
+    assert np.sqrt(orc.aabb_min_dist2([0, 0, 0, 10, 10, 10], [20, 0, 0])) == 10.0
+    pos = np.arange(1000, dtype=np.float32)[:, None].repeat(3, 1)
+    aabbs = np.concatenate([pos + np.float32(-0.5), pos + np.float32(0.5)], axis=1)
+    t = orc.build(aabbs)
+    for h in (orc.flatten(t.nodes), t.nodes):           # FlatBvh and Bvh implementations of the trait
+        shape, dist = orc.nearest(h, aabbs, [[5.0, 5.7, 5.3]])
+        assert shape[0] == 5 and abs(dist[0] - 0.2) < 1e-6
+    # empty hierarchy → None (flat_bvh.rs:518-520, bvh_impl.rs:229-231)
+    e = orc.build(np.zeros((0, 6), np.float32))
+    assert orc.nearest(orc.flatten(e.nodes), np.zeros((0, 6), np.float32), [[0, 0, 0]])[0][0] == 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_point_distance_two_restatements_agree(dtype):
+    from oracle import pyref
+    rng = np.random.default_rng(8)
+    tris = rng.uniform(-5, 5, size=(1500, 3, 3)).astype(dtype)
+    tris[:100, 1] = tris[:100, 0]                     # degenerate: a == b
+    tris[100:200, 2] = tris[100:200, 1]               # b == c
+    tris[200:300, 2] = tris[200:300, 0]               # a == c
+    tris[300:350, 1] = tris[300:350, 0]; tris[300:350, 2] = tris[300:350, 0]   # a point
+    pts = rng.uniform(-8, 8, size=(1500, 3)).astype(dtype)
+    pts[400:500] = tris[400:500, 0]                   # query on a vertex
+    for i in range(len(tris)):
+        a = orc.triangle_dist2(tris[i], pts[i], dtype)
+        b = pyref.triangle_dist2(tris[i], pts[i], dtype)
+        assert np.array([a]).tobytes() == np.array([b], dtype=dtype).tobytes() or (np.isnan(a) and np.isnan(b)), i
+        box = np.concatenate([tris[i].min(0), tris[i].max(0)])
+        assert orc.aabb_min_dist2(box, pts[i], dtype) == pyref.aabb_min_dist2(box, pts[i], dtype)
+
+
+def test_reference_nearest_to_some_bh_property():
+    """testbase.rs:270-312 (nearest_to_some_bh): nearest_to agrees with a brute-force scan, for both trait
+    implementations; the distance is what the test pins (several triangles of a cube tie on shared vertices)."""
+    tris, aabbs = orc.create_n_cubes(1000)
+    t = orc.build(aabbs)
+    flat = orc.flatten(t.nodes)
+    rng = np.random.default_rng(2)
+    pts = np.concatenate([rng.uniform(-1000, 1000, size=(40, 3)), rng.uniform(-1e5, 1e5, size=(40, 3))]).astype(np.float32)
+    fs, fd = orc.nearest(flat, aabbs, pts, tris)
+    ts, td = orc.nearest(t.nodes, aabbs, pts, tris)
+    assert np.array_equal(fd, td)
+    for i, p in enumerate(pts):
+        d2 = np.array([orc.triangle_dist2(tr, p) for tr in tris[:: 1]])
+        assert np.sqrt(d2.min()) == fd[i]
+        assert d2[fs[i]] == d2.min() and d2[ts[i]] == d2.min()
+
+
 # ---------------------------------------------------------------- scene generators
 def test_scene_shape_and_invariants_1200():
     tris, aabbs = orc.create_n_cubes(100)
