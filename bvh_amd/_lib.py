@@ -22,6 +22,8 @@ TRAVERSE_STATS = 2
 TRAVERSE_TRIANGLES = 4
 TRAVERSE_CLOSEST = 8
 TRAVERSE_COHERENT = 16
+TRAVERSE_NEAREST_FIRST = 32
+TRAVERSE_FARTHEST_FIRST = 64
 
 NODE_F32 = np.dtype([("l_min", "<f4", 3), ("l_max", "<f4", 3), ("r_min", "<f4", 3), ("r_max", "<f4", 3),
                      ("parent", "<u4"), ("l", "<u4"), ("r", "<u4"), ("shape", "<u4")])

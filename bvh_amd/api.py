@@ -21,7 +21,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (DEVICE, F32, F64, FLAT_F32, FLAT_F64, HOST, NODE_F32, NODE_F64, NONE, RAY_F32, RAY_F64,
-                   TRAVERSE_CLOSEST, TRAVERSE_COHERENT, TRAVERSE_STATS, TRAVERSE_T_SLICE, TRAVERSE_TRIANGLES, BvhGpuError, check, ptr)
+                   TRAVERSE_CLOSEST, TRAVERSE_COHERENT, TRAVERSE_FARTHEST_FIRST, TRAVERSE_NEAREST_FIRST, TRAVERSE_STATS, TRAVERSE_T_SLICE, TRAVERSE_TRIANGLES, BvhGpuError, check, ptr)
 
 
 def _sfx(dtype) -> str:
@@ -332,13 +332,14 @@ class _TreeBase:
 
     # ---- traversal -------------------------------------------------------------------------
     def traverse_batch(self, rays: RayBatch, want_t: bool = False, stats: bool = False, fetch: bool = True,
-                       coherent: bool = False):
+                       coherent: bool = False, order: Optional[str] = None):
         """<FlatBvh as BoundingHierarchy>::traverse for a batch (flat_bvh.rs:396-431).
         returns (offsets[n+1], indices[total], tslice[total,2]|None, stats dict)."""
         if rays.sfx != self.sfx:
             raise BvhGpuError(_lib.DTYPE_MISMATCH, "ray dtype differs from tree dtype")
         lib = _lib.load()
         flags = (TRAVERSE_T_SLICE if want_t else 0) | (TRAVERSE_STATS if stats else 0) | (TRAVERSE_COHERENT if coherent else 0)
+        flags |= {None: 0, "nearest": TRAVERSE_NEAREST_FIRST, "farthest": TRAVERSE_FARTHEST_FIRST}[order]
         fn = getattr(lib, f"bvhgpu_traverse_{self.sfx}")
         check(fn(self._t, rays._ptr(), rays.n, rays.mem, flags, C.byref(self._hits.h)), self.ctx._h)
         total = C.c_uint64()
@@ -367,11 +368,12 @@ class _TreeBase:
             a = np.ascontiguousarray(tris, dtype=ft).reshape(-1, 9)
             check(fn(self._t, ptr(a), len(a), HOST), self.ctx._h)
 
-    def intersect_triangles(self, rays: RayBatch, stats: bool = False, coherent: bool = False):
+    def intersect_triangles(self, rays: RayBatch, stats: bool = False, coherent: bool = False, order: Optional[str] = None):
         """traverse + Ray::intersects_triangle on every returned shape (testbase.rs:826-836).
         returns (offsets, indices, isect[total,3] = Intersection{distance,u,v}, stats)"""
         lib = _lib.load()
         flags = TRAVERSE_TRIANGLES | (TRAVERSE_STATS if stats else 0) | (TRAVERSE_COHERENT if coherent else 0)
+        flags |= {None: 0, "nearest": TRAVERSE_NEAREST_FIRST, "farthest": TRAVERSE_FARTHEST_FIRST}[order]
         check(getattr(lib, f"bvhgpu_traverse_{self.sfx}")(self._t, rays._ptr(), rays.n, rays.mem, flags,
                                                            C.byref(self._hits.h)), self.ctx._h)
         total = C.c_uint64()
@@ -387,11 +389,13 @@ class _TreeBase:
                   device_steps=int(st.device_steps), wave_steps=int(st.wave_steps))
         return offsets, indices, isect, sd
 
-    def closest_hits(self, rays: RayBatch, stats: bool = False, fetch: bool = True, coherent: bool = False):
+    def closest_hits(self, rays: RayBatch, stats: bool = False, fetch: bool = True, coherent: bool = False,
+                     order: Optional[str] = None):
         """triangle stage fused into the walk: per ray the nearest Intersection and its shape
         (distance +inf / shape NONE when nothing is hit).  returns (isect[n,3], shape[n], stats)"""
         lib = _lib.load()
         flags = TRAVERSE_CLOSEST | (TRAVERSE_STATS if stats else 0) | (TRAVERSE_COHERENT if coherent else 0)
+        flags |= {None: 0, "nearest": TRAVERSE_NEAREST_FIRST, "farthest": TRAVERSE_FARTHEST_FIRST}[order]
         check(getattr(lib, f"bvhgpu_traverse_{self.sfx}")(self._t, rays._ptr(), rays.n, rays.mem, flags,
                                                            C.byref(self._hits.h)), self.ctx._h)
         st = _lib.TraverseStats()
@@ -423,6 +427,16 @@ class _TreeBase:
         """BoundingHierarchy::nearest_to (bounding_hierarchy.rs:262-336): Option<(&Shape, distance)>."""
         s, d = self.nearest_batch([query], triangles)
         return None if s[0] == NONE else (shapes[int(s[0])], d[0])
+
+    def nearest_child_traverse(self, ray: "Ray", shapes: Sequence) -> List:
+        """Bvh::nearest_child_traverse_iterator (bvh_impl.rs:184-190) collected into a list."""
+        _, idx, _, _ = self.traverse_batch(ray._batch, order="nearest")
+        return [shapes[i] for i in idx.tolist()]
+
+    def farthest_child_traverse(self, ray: "Ray", shapes: Sequence) -> List:
+        """Bvh::farthest_child_traverse_iterator (bvh_impl.rs:206-212) collected into a list."""
+        _, idx, _, _ = self.traverse_batch(ray._batch, order="farthest")
+        return [shapes[i] for i in idx.tolist()]
 
     def hits_device(self) -> Tuple[int, int]:
         """device addresses of the last result's (offsets, indices) — valid until the next traverse."""

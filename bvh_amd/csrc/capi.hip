@@ -24,6 +24,8 @@ template <typename F> int guarded(bvhgpu_ctx* ctx, F&& f) {
         char buf[512];
         snprintf(buf, sizeof buf, "%s failed: %s (line %d)", e.what, hipGetErrorString(e.err), e.line);
         if (e.what && std::strcmp(e.what, "OVERFLOW") == 0) return fail(ctx, BVHGPU_OVERFLOW, "more than 2^32-1 hits in one batch");
+        if (e.what && std::strcmp(e.what, "ORDERED_DEPTH") == 0)
+            return fail(ctx, BVHGPU_OVERFLOW, "tree deeper than the ordered iterator's 32-entry stack (child_distance_traverse.rs:36)");
         if (e.err == hipErrorOutOfMemory) return fail(ctx, BVHGPU_OOM, buf);
         return fail(ctx, BVHGPU_HIP_ERROR, buf);
     } catch (const std::bad_alloc&) {
@@ -105,6 +107,13 @@ int do_traverse(bvhgpu_tree* tree, const typename Traits<T>::Ray* rays, size_t n
         return fail(ctx, BVHGPU_INVALID_ARG, "TRIANGLES / CLOSEST need bvhgpu_tree_set_triangles first");
     if ((flags & BVHGPU_TRAVERSE_T_SLICE) && (flags & (BVHGPU_TRAVERSE_TRIANGLES | BVHGPU_TRAVERSE_CLOSEST)))
         return fail(ctx, BVHGPU_INVALID_ARG, "T_SLICE cannot be combined with TRIANGLES / CLOSEST");
+    if (flags & (BVHGPU_TRAVERSE_NEAREST_FIRST | BVHGPU_TRAVERSE_FARTHEST_FIRST)) {
+        if (!tree->built) return fail(ctx, BVHGPU_INVALID_ARG, "ordered traversal walks the BvhNode array: the tree must have been built here");
+        if ((flags & BVHGPU_TRAVERSE_NEAREST_FIRST) && (flags & BVHGPU_TRAVERSE_FARTHEST_FIRST))
+            return fail(ctx, BVHGPU_INVALID_ARG, "NEAREST_FIRST and FARTHEST_FIRST are alternatives");
+        if (flags & (BVHGPU_TRAVERSE_T_SLICE | BVHGPU_TRAVERSE_STATS))
+            return fail(ctx, BVHGPU_INVALID_ARG, "ordered traversal supports the INDICES, TRIANGLES and CLOSEST outputs only");
+    }
     if ((flags & BVHGPU_TRAVERSE_TRIANGLES) && (flags & BVHGPU_TRAVERSE_CLOSEST))
         return fail(ctx, BVHGPU_INVALID_ARG, "TRIANGLES and CLOSEST are alternatives");
     return guarded(ctx, [&] {

@@ -14,6 +14,8 @@
 // If the pool was too small the totals are still exact; the host grows it and replays.
 // Two walk kernels: k_traverse (one ray per lane per launch; small batches) and k_traverse_lds (persistent
 // workgroups, top of the tree resident in LDS, ray refill; large batches).
+#include <type_traits>
+
 #include "engine.hpp"
 
 namespace bvhgpu {
@@ -256,6 +258,101 @@ __global__ __launch_bounds__(256) void k_traverse(const TravNode<T>* __restrict_
     const unsigned long long cands = active ? ray.cnt : 0;
     if (active) ray.retire(w);
     walk_epilogue<T, MODE>(w, pc, lane, STATS, steps, leaf_steps, wsteps, cands);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ordered traversal: Bvh::nearest_child_traverse_iterator / farthest_child_traverse_iterator
+// (bvh_impl.rs:184-212, bvh/child_distance_traverse.rs) collected per ray.  The iterator is a depth-first walk
+// over the BvhNode array that tests both child boxes of an inner node with intersection_slice_for_aabb and
+// visits the higher-priority hit child first ((left_dist > right_dist) ^ !ASCENDING → right first, :126), the
+// other afterwards; a leaf yields its shape.  One ray per lane; the iterator's 32-entry stack (:36) lives in LDS
+// (entry-major, so a wave's push/pop is conflict-free).  An entry holds what the iterator would do on pop:
+// nothing, "go to node X" (the rest child) or "yield shape S".  A tree deeper than 32 levels makes the reference
+// index out of bounds (panic); here it raises the overflow flag.
+// The same set of shapes as FlatBvh::traverse comes out (slice is Some exactly when intersects_aabb is true),
+// in the iterator's order; the output modes of the other walks apply.
+// ------------------------------------------------------------------------------------------------
+constexpr int ORD_STACK = 32;
+constexpr uint32_t ORD_NOTHING = 0xFFFFFFFFu;   // RestChild::None
+constexpr uint32_t ORD_YIELD = 0x80000000u;     // | shape index: a leaf was pushed (:143-147)
+
+template <typename T, int MODE, bool ASCENDING>
+__global__ __launch_bounds__(256) void k_traverse_ordered(const typename Traits<T>::Node* __restrict__ nodes, uint32_t n_nodes,
+                                                          const T* __restrict__ shape_aabbs,
+                                                          const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_rays,
+                                                          WalkOut<T> w, uint32_t* __restrict__ overflow) {
+    __shared__ uint32_t s_stack[ORD_STACK][256];
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = lane_id();
+    const unsigned long long lt = lanemask_lt();
+    const bool active = r < n_rays;
+    LaneRay<T, MODE> ray;
+    ray.clear();
+    if (active) ray.load(rays, r);
+    uint32_t node_index = 0;
+    int sp = 0;
+    bool has_node = false;
+    if (active && n_nodes) {   // iter_initially_has_node (iter.rs:164-182): a root leaf is pre-tested with the shape's AABB
+        const uint32_t rs = nodes[0].shape;
+        if (rs != NONE) {
+            const T* sb = shape_aabbs + 6 * (size_t)rs;
+            const T mn[3] = {sb[0], sb[1], sb[2]}, mx[3] = {sb[3], sb[4], sb[5]};
+            T t0, t1;
+            has_node = slab_hit<T>(ray.o, ray.inv, mn, mx, t0, t1);
+        } else {
+            has_node = true;
+        }
+    }
+    PoolCursor pc;
+    bool ovf = false;
+    while (true) {
+        const bool run = has_node || sp > 0;
+        if (!__any(run)) break;
+        bool rec = false;
+        uint32_t shape = NONE;
+        if (run) {
+            if (has_node) {   // move_first_priority (:88-148) + stack_push (:211-213)
+                const typename Traits<T>::Node* nd = nodes + node_index;
+                const uint32_t ns = nd->shape;
+                uint32_t entry = ORD_NOTHING;
+                if (ns != NONE) {
+                    has_node = false;
+                    entry = ORD_YIELD | ns;
+                } else {
+                    T lmn[3], lmx[3], rmn[3], rmx[3];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { lmn[k] = nd->l_min[k]; lmx[k] = nd->l_max[k]; rmn[k] = nd->r_min[k]; rmx[k] = nd->r_max[k]; }
+                    const uint32_t li = nd->l, ri = nd->r;
+                    T ld, rd, t1;
+                    const bool lh = slab_hit<T>(ray.o, ray.inv, lmn, lmx, ld, t1);   // slice is Some ⇔ hit; entry = max(tmin, 0)
+                    const bool rh = slab_hit<T>(ray.o, ray.inv, rmn, rmx, rd, t1);
+                    if (!lh && !rh) has_node = false;
+                    else if (lh && !rh) node_index = li;
+                    else if (!lh && rh) node_index = ri;
+                    else if ((ld > rd) != !ASCENDING) { node_index = ri; entry = li; }   // right first, left rests (:126-131)
+                    else { node_index = li; entry = ri; }
+                }
+                if (sp >= ORD_STACK) { ovf = true; has_node = false; sp = 0; }
+                else { s_stack[sp][threadIdx.x] = entry; sp++; }
+            } else {          // stack_pop (:215-229)
+                sp--;
+                const uint32_t entry = s_stack[sp][threadIdx.x];
+                if (entry == ORD_NOTHING) {
+                    has_node = false;
+                } else if (entry & ORD_YIELD) {
+                    shape = entry & ~ORD_YIELD;
+                    rec = true;
+                } else {
+                    node_index = entry;   // move_rest (:152-176)
+                    has_node = true;
+                }
+            }
+        }
+        report<T, MODE>(rec, shape, (T)0, (T)0, ray, w, pc, lane, lt);
+    }
+    if (ovf) atomicOr(overflow, 1u);
+    if (active) ray.retire(w);
+    walk_epilogue<T, MODE>(w, pc, lane, false, 0, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -522,6 +619,7 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
     hipStream_t st = ctx->stream;
     const bool stats = (flags & BVHGPU_TRAVERSE_STATS) != 0;
     const bool coherent = (flags & BVHGPU_TRAVERSE_COHERENT) != 0;
+    const int ordered = (flags & BVHGPU_TRAVERSE_NEAREST_FIRST) ? 1 : ((flags & BVHGPU_TRAVERSE_FARTHEST_FIRST) ? 2 : 0);
     const int mode = (flags & BVHGPU_TRAVERSE_CLOSEST) ? MODE_CLOSEST
                    : (flags & BVHGPU_TRAVERSE_TRIANGLES) ? MODE_TRIANGLES
                    : (flags & BVHGPU_TRAVERSE_T_SLICE) ? MODE_T_SLICE : MODE_INDICES;
@@ -536,8 +634,27 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
     w.counts = nullptr; w.pool = nullptr; w.pool_v = nullptr; w.pool_cap = 0; w.ctr = ctr;
     w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr;
 
+    uint32_t* ovf_flag = reinterpret_cast<uint32_t*>(ctr + 7);   // ordered walk: iterator stack overflow
+    auto launch_ordered = [&](auto mode_tag, auto asc_tag) {
+        constexpr int M = decltype(mode_tag)::value;
+        constexpr bool A = decltype(asc_tag)::value;
+        hipLaunchKernelGGL((k_traverse_ordered<T, M, A>), dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st,
+                           t->nodes.as<typename Traits<T>::Node>(), (uint32_t)t->n_nodes, t->aabbs.as<T>(), rays_dev,
+                           (uint32_t)n_rays, w, ovf_flag);
+    };
+    auto dispatch_ordered = [&](auto mode_tag) {
+        if (ordered == 1) launch_ordered(mode_tag, std::true_type{}); else launch_ordered(mode_tag, std::false_type{});
+    };
 #define DISPATCH_WALK()                                                                              \
     do {                                                                                             \
+        if (ordered) {                                                                               \
+            switch (mode) {                                                                          \
+                case MODE_INDICES: dispatch_ordered(std::integral_constant<int, MODE_INDICES>{}); break;     \
+                case MODE_TRIANGLES: dispatch_ordered(std::integral_constant<int, MODE_TRIANGLES>{}); break; \
+                default: dispatch_ordered(std::integral_constant<int, MODE_CLOSEST>{}); break;       \
+            }                                                                                        \
+            break;                                                                                   \
+        }                                                                                            \
         switch (mode) {                                                                              \
             case MODE_INDICES: if (stats) launch_walk<T, MODE_INDICES, true>(t, rays_dev, n_rays, w, coherent);  \
                                else launch_walk<T, MODE_INDICES, false>(t, rays_dev, n_rays, w, coherent); break; \
@@ -562,6 +679,7 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
         BVH_HIP(hipMemcpyAsync(pin, ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         BVH_HIP(hipStreamSynchronize(st));
         BVH_HIP(hipGetLastError());
+        if (ordered && (pin[7] & 0xFFFFFFFFull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
         if (stats) {
             const bool one_to_one = t->unfolded || t->n == 1;
             h->stats.hits = pin[5];
@@ -618,6 +736,7 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
         BVH_HIP(hipMemcpyAsync(pin, ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         BVH_HIP(hipStreamSynchronize(st));
         BVH_HIP(hipGetLastError());
+        if (ordered && (pin[7] & 0xFFFFFFFFull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
         const unsigned long long used = pin[0];   // pool slots taken (whole chunks)
         const unsigned long long total = pin[3];  // sum of the per-ray counts = number of hits
         if (used < total) throw HipFail{hipErrorUnknown, "hit pool / count scan mismatch", __LINE__};

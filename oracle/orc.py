@@ -293,6 +293,26 @@ def nearest(tree_or_flat, shape_aabbs, points, tris=None):
     return shape, dist
 
 
+def traverse_child_ordered(nodes, shape_aabbs, rays, ascending: bool = True):
+    """Bvh::nearest_child_traverse_iterator / farthest_child_traverse_iterator collected per ray → (offsets, indices)"""
+    s = "f32" if nodes.dtype == NODE_F32 else "f64"
+    ft = _types(s)[0]
+    sa = np.ascontiguousarray(shape_aabbs, dtype=ft).reshape(-1, 6)
+    rays = np.ascontiguousarray(rays)
+    nr = len(rays)
+    offsets = np.zeros(nr + 1, dtype=np.uint32)
+    fn = getattr(lib(), f"orc_traverse_child_ordered_{s}")
+    fn.restype = C.c_uint64
+    total = fn(_p(nodes), C.c_size_t(len(nodes)), _p(sa), _p(rays), C.c_size_t(nr), C.c_int(int(ascending)), _p(offsets),
+               None, C.c_uint64(0))
+    if total == 0xFFFFFFFFFFFFFFFF:
+        raise OverflowError("tree deeper than the iterator's 32-entry stack (the reference panics)")
+    indices = np.zeros(total, dtype=np.uint32)
+    fn(_p(nodes), C.c_size_t(len(nodes)), _p(sa), _p(rays), C.c_size_t(nr), C.c_int(int(ascending)), _p(offsets),
+       _p(indices), C.c_uint64(total))
+    return offsets, indices
+
+
 def check_tree(nodes, aabbs) -> int:
     s = "f32" if nodes.dtype == NODE_F32 else "f64"
     ft = _types(s)[0]

@@ -356,3 +356,47 @@ def triangle_dist2(tri, p, ft=np.float32):  # testbase.rs:353-443, independent r
     with np.errstate(all="ignore"):
         d = p - closest()
         return dot(d, d)
+
+
+def ray_slice(ray, box):  # ray_impl.rs:118-145 → (tmin, tmax) or None
+    o, _, inv = ray
+    with np.errstate(all="ignore"):
+        lbr = [(box[k] - o[k]) * inv[k] for k in range(3)]
+        rtr = [(box[3 + k] - o[k]) * inv[k] for k in range(3)]
+    if any(np.isnan(v) for v in lbr) or any(np.isnan(v) for v in rtr):
+        return None
+    inf = [_min(a, b) for a, b in zip(lbr, rtr)]
+    sup = [_max(a, b) for a, b in zip(lbr, rtr)]
+    tmin = max(max(inf), type(inf[0])(0))
+    tmax = min(sup)
+    return None if tmin > tmax else (tmin, tmax)
+
+
+def traverse_child_ordered(nodes, shape_aabbs, ray, ascending=True):
+    """ChildDistanceTraverseIterator (child_distance_traverse.rs) as the RECURSION it unrolls: at every inner node
+    test both child boxes, visit the higher-priority hit child first, then the other; a leaf yields its shape."""
+    out = []
+    if len(nodes) == 0:
+        return out
+    if nodes[0]["shape"] != 0xFFFFFFFF and not ray_hit(ray, shape_aabbs[nodes[0]["shape"]]):
+        return out   # iter_initially_has_node (iter.rs:164-182)
+
+    def visit(ni):
+        nd = nodes[ni]
+        if nd["shape"] != 0xFFFFFFFF:
+            out.append(int(nd["shape"]))
+            return
+        ls = ray_slice(ray, list(nd["l_min"]) + list(nd["l_max"]))
+        rs = ray_slice(ray, list(nd["r_min"]) + list(nd["r_max"]))
+        order = []
+        if ls and rs:
+            right_first = (ls[0] > rs[0]) != (not ascending)
+            order = [nd["r"], nd["l"]] if right_first else [nd["l"], nd["r"]]
+        elif ls:
+            order = [nd["l"]]
+        elif rs:
+            order = [nd["r"]]
+        for c in order:
+            visit(int(c))
+    visit(0)
+    return out

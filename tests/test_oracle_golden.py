@@ -387,3 +387,36 @@ def test_workload_statistics_120k():
     off, idx, _, stats = orc.traverse_flat(flat, aabbs, rays, threads=orc.max_threads())
     assert stats["hits"] == 10_000  # first 5 000 rays start inside a cube and return exactly 2 candidates
     assert np.all(np.diff(off)[:5000] == 2) and np.all(np.diff(off)[5000:] == 0)
+
+
+# ---------------------------------------------------------------- ordered traversal
+def test_ordered_iterator_restatements_agree_and_match_golden_sets():
+    """oracle (state machine of child_distance_traverse.rs) vs pyref (the recursion it unrolls), both directions;
+    on the 21 aligned boxes the sets are the reference's golden hit sets (testbase.rs:174-225) and the entry
+    distances come out sorted, as the reference's own iterator tests assert."""
+    from oracle import pyref
+    aabbs = orc.aligned_boxes()
+    t = orc.build(aabbs)
+    for case in GOLD["aligned_boxes"]["rays"]:
+        rays = orc.make_rays([case["origin"]], [case["direction"]])
+        for asc in (True, False):
+            off, idx = orc.traverse_child_ordered(t.nodes, aabbs, rays, asc)
+            ids = [int(i) - 10 for i in idx]
+            assert sorted(ids) == sorted(case["hit_ids"])
+            entry = [orc.ray_slice(rays[0], aabbs[i])[0] for i in idx]
+            assert entry == sorted(entry, reverse=not asc)
+            assert pyref.traverse_child_ordered(t.nodes, aabbs, (rays[0]["o"], rays[0]["d"], rays[0]["inv"]), asc) == idx.tolist()
+    tris, ab = orc.create_n_cubes(150)
+    tt = orc.build(ab)
+    rng = np.random.default_rng(4)
+    c = tris.reshape(150, 36, 3).mean(axis=1)
+    o = rng.uniform(-1e5, 1e5, size=(200, 3)).astype(np.float32)
+    rays = orc.make_rays(o, (c[rng.integers(0, 150, 200)] - o).astype(np.float32))
+    foff, fidx, _, _ = orc.traverse_flat(orc.flatten(tt.nodes), ab, rays)
+    for asc in (True, False):
+        off, idx = orc.traverse_child_ordered(tt.nodes, ab, rays, asc)
+        assert np.array_equal(off, foff)
+        for i in range(len(rays)):
+            assert pyref.traverse_child_ordered(tt.nodes, ab, (rays[i]["o"], rays[i]["d"], rays[i]["inv"]), asc) == \
+                idx[off[i]:off[i + 1]].tolist()
+            assert sorted(idx[off[i]:off[i + 1]]) == sorted(fidx[foff[i]:foff[i + 1]])
