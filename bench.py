@@ -109,8 +109,7 @@ def main():
     def step():
         nonlocal peer
         if builder:
-            bvh.rebuild(aabbs)            # Bvh::build_par
-            bvh.flatten_in_place()        # Bvh::flatten
+            bvh.rebuild(aabbs, flatten=True)   # Bvh::build_par + Bvh::flatten (FlatBvh::build, flat_bvh.rs:328-331)
         if blob is not None:
             if rank == 0:
                 bvh.scene_export(blob)

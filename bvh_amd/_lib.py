@@ -68,6 +68,10 @@ SYMBOLS = [
     ("bvhgpu_build_f64", _i, [_vp, _vp, _sz, _i, _pp]),
     ("bvhgpu_rebuild_f32", _i, [_vp, _vp, _sz, _i]),
     ("bvhgpu_rebuild_f64", _i, [_vp, _vp, _sz, _i]),
+    ("bvhgpu_build_flat_f32", _i, [_vp, _vp, _sz, _i, _pp]),
+    ("bvhgpu_build_flat_f64", _i, [_vp, _vp, _sz, _i, _pp]),
+    ("bvhgpu_rebuild_flat_f32", _i, [_vp, _vp, _sz, _i]),
+    ("bvhgpu_rebuild_flat_f64", _i, [_vp, _vp, _sz, _i]),
     ("bvhgpu_tree_destroy", None, [_vp]),
     ("bvhgpu_tree_info", _i, [_vp, C.POINTER(_i), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
     ("bvhgpu_tree_nodes", _i, [_vp, _vp, _i]),

@@ -544,16 +544,18 @@ class Bvh(_TreeBase):
             check(getattr(lib, f"bvhgpu_build_{s}")(ctx._h, ptr(a), len(a), HOST, C.byref(h)), ctx._h)
         return Bvh(ctx, h, s)
 
-    def rebuild(self, aabbs) -> "Bvh":
-        """Bvh::build again into the same device buffers (no allocation when n fits)."""
+    def rebuild(self, aabbs, flatten: bool = False) -> "Bvh":
+        """Bvh::build again into the same device buffers (no allocation when n fits).  flatten=True: FlatBvh::build
+        (flat_bvh.rs:328-331) — build + flatten in one call."""
         lib = _lib.load()
+        fn = getattr(lib, f"bvhgpu_rebuild_flat_{self.sfx}" if flatten else f"bvhgpu_rebuild_{self.sfx}")
         if _is_device_tensor(aabbs):
             n = aabbs.numel() // 6
-            check(getattr(lib, f"bvhgpu_rebuild_{self.sfx}")(self._t, ptr(aabbs.data_ptr()), n, DEVICE), self.ctx._h)
+            check(fn(self._t, ptr(aabbs.data_ptr()), n, DEVICE), self.ctx._h)
         else:
             ft = np.float32 if self.sfx == "f32" else np.float64
             a = np.ascontiguousarray(aabbs, dtype=ft).reshape(-1, 6)
-            check(getattr(lib, f"bvhgpu_rebuild_{self.sfx}")(self._t, ptr(a), len(a), HOST), self.ctx._h)
+            check(fn(self._t, ptr(a), len(a), HOST), self.ctx._h)
         return self
 
     @staticmethod

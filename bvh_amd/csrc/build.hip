@@ -28,6 +28,7 @@ namespace bvhgpu {
 constexpr int MAXLV = 96;        // counter slots (levels beyond reuse the last two, host-synchronised)
 constexpr int CTR_SMALL = 0;     // u32: number of small items (<= 64 shapes, wave-subtree tier)
 constexpr int CTR_MID = 1;       // u32: number of mid items (65 .. MID_MAX shapes, workgroup tier)
+constexpr int CTR_TICKET = 3;    // u32: k_prep arrival ticket (the last workgroup creates the root item)
 constexpr int CTR_MID2 = 2;      // u32: number of second-mid-tier items (65 .. MidB::MAXN shapes)
 // Workgroup tiers.  A: nodes up to MidA::MAXN shapes, one 512-thread workgroup per node (LDS holds all its
 // AABBs, so one workgroup per CU and only n/MAXN of them): it splits until a child fits tier B and hands it
@@ -56,7 +57,8 @@ template <typename T> struct ItemStats {
 };
 
 template <typename T> struct BuildArgs {
-    const T* aabbs;
+    const T* aabbs;          // the tree's own copy (what every later kernel gathers from)
+    const T* src;            // the caller's array: k_prep copies it into `aabbs` while it reduces the bounds
     typename Traits<T>::Node* nodes;
     uint32_t* node_start;
     uint32_t* node_count;
@@ -84,6 +86,10 @@ __device__ __forceinline__ bool key_is_min(int j) { return j < 3 || (j >= 6 && j
 // ------------------------------------------------------------------------------------------------
 // K1 prep: identity permutation (bvh_impl.rs:61-63) + joint_aabb_of_shapes over all shapes (:74)
 // ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, uint32_t parent, uint32_t start,
+                          uint32_t count, const T* A, const T* C, uint32_t heap, int lane);
+
 template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T> a) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
@@ -93,12 +99,20 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T>
     Key loc[STAT_KEYS];
 #pragma unroll
     for (int j = 0; j < STAT_KEYS; j++) loc[j] = key_is_min(j) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
+    if (blockIdx.x == 0)   // the LDS slot table of the previous tree (filled again by flatten)
+        for (uint32_t i = threadIdx.x; i < a.n_slots; i += blockDim.x) a.slot_entry[i] = NONE;
+    const bool copy = a.src != a.aabbs;
+    T* own = const_cast<T*>(a.aabbs);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
         a.idx[0][i] = i;
-        const T* b = a.aabbs + 6 * (size_t)i;
+        const T* b = a.src + 6 * (size_t)i;
         T bx[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) bx[k] = b[k];
+        if (copy) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) own[6 * (size_t)i + k] = bx[k];
+        }
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             Key kmn = Tr::key(bx[k]), kmx = Tr::key(bx[3 + k]);
@@ -127,6 +141,23 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T>
         int j = threadIdx.x;
         if (key_is_min(j)) atomicMin(&a.rootkeys[j], sk[j]);
         else atomicMax(&a.rootkeys[j], sk[j]);
+    }
+    // the workgroup that arrives last sees every contribution and creates the root item
+    // (BvhNodeBuildArgs of bvh_impl.rs:75-87) — saves a kernel boundary on the latency-bound build
+    __shared__ uint32_t s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&a.ctr[CTR_TICKET], 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last && threadIdx.x < WAVE) {
+        __threadfence();
+        T A[6], C[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            A[k] = Tr::unkey(__hip_atomic_load(&a.rootkeys[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            C[k] = Tr::unkey(__hip_atomic_load(&a.rootkeys[6 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        push_item<T>(a, 0, 0u, 0u, 0u, a.n, A, C, 1u, (int)threadIdx.x);
     }
 }
 
@@ -175,21 +206,7 @@ __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, ui
 template <typename T> __global__ __launch_bounds__(256) void k_init(BuildArgs<T> a) {
     using Tr = Traits<T>;
     for (int i = threadIdx.x; i < (int)(ROOTKEY_OFF / 4); i += 256) a.ctr[i] = 0;
-    for (uint32_t i = threadIdx.x; i < a.n_slots; i += 256) a.slot_entry[i] = NONE;
     if (threadIdx.x < STAT_KEYS) a.rootkeys[threadIdx.x] = key_is_min(threadIdx.x) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
-}
-
-// root item: BvhNodeBuildArgs of bvh_impl.rs:75-87
-template <typename T> __global__ __launch_bounds__(64) void k_root(BuildArgs<T> a) {
-    using Tr = Traits<T>;
-    const int lane = lane_id();
-    T A[6], C[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        A[k] = Tr::unkey(a.rootkeys[k]);
-        C[k] = Tr::unkey(a.rootkeys[6 + k]);
-    }
-    push_item<T>(a, 0, 0u, 0u, 0u, a.n, A, C, 1u, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1069,7 +1086,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
 // ------------------------------------------------------------------------------------------------
 // host driver
 // ------------------------------------------------------------------------------------------------
-template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t n) {
+template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
     bvhgpu_ctx* ctx = t->ctx;
@@ -1105,13 +1122,13 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     t->mid2.reserve(max_mid2 * sizeof(Item<T>));
     t->small.reserve((n + 1) * sizeof(Item<T>));
     t->tile_cnt.reserve(max_tiles * NUM_BUCKETS * 4);
+    const void* ctr_before = t->ctr.p;
     t->ctr.reserve(ROOTKEY_OFF + STAT_KEYS * sizeof(Key));
-
-    if ((const void*)aabbs_dev != t->aabbs.p)
-        BVH_HIP(hipMemcpyAsync(t->aabbs.p, aabbs_dev, n * 6 * sizeof(T), hipMemcpyDeviceToDevice, st));
+    if (t->ctr.p != ctr_before) t->ctr_ready = false;   // a fresh buffer has not been zeroed by the previous build
 
     BuildArgs<T> a;
     a.aabbs = t->aabbs.as<T>();
+    a.src = aabbs_dev;
     a.nodes = t->nodes.as<typename Tr::Node>();
     a.node_start = t->node_start.as<uint32_t>();
     a.node_count = t->node_count.as<uint32_t>();
@@ -1132,10 +1149,11 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     a.rootkeys = reinterpret_cast<Key*>(reinterpret_cast<char*>(t->ctr.p) + ROOTKEY_OFF);
     a.n = (uint32_t)n;
 
-    hipLaunchKernelGGL(k_init<T>, dim3(1), dim3(256), 0, st, a);
+    // counters and root keys were reset at the end of the previous build of this tree (off the critical path)
+    if (!t->ctr_ready) hipLaunchKernelGGL(k_init<T>, dim3(1), dim3(256), 0, st, a);
+    t->ctr_ready = false;
     const int prep_grid = (int)std::min<size_t>((n + 1023) / 1024, 256);
-    hipLaunchKernelGGL(k_prep<T>, dim3(prep_grid), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_root<T>, dim3(1), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_prep<T>, dim3(prep_grid), dim3(256), 0, st, a);   // + aabbs copy + root item
 
     const int tile_grid = (int)std::min<size_t>(max_tiles, 2048);
     const int sel_grid = (int)std::min<size_t>((max_big + 3) / 4, 1024);
@@ -1153,7 +1171,7 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     // at the end checks that nothing is left in the level queue; unbalanced trees continue from there.
     int level = 0;
     if (n > (size_t)MID_MAX) {
-        int fixed = 2;
+        int fixed = 1;   // levels of a balanced tree; an unbalanced one continues below, one host round trip per level
         for (size_t m = n; m > (size_t)MID_MAX; m = (m + 1) / 2) fixed++;
         if (fixed > MAXLV - 4) fixed = MAXLV - 4;
         for (; level < fixed; level++) run_level(level);
@@ -1165,6 +1183,7 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
         if (n > (size_t)SMALL_MAX)
             hipLaunchKernelGGL((k_mid<T, MidB<T>, false>), dim3(mid2_grid), dim3(MidB<T>::THREADS), 0, st, a, mid2_done);
         hipLaunchKernelGGL(k_small<T>, dim3(small_grid), dim3(256), 0, st, a, small_done);
+        if (flatten_after) flatten_tree<T>(t);   // optimistic too: redone if the build turns out to be unfinished
         BVH_HIP(hipMemcpyAsync(pin, a.ctr, ROOTKEY_OFF, hipMemcpyDeviceToHost, st));
         BVH_HIP(hipStreamSynchronize(st));
         BVH_HIP(hipGetLastError());
@@ -1188,6 +1207,8 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     while (used > 0 && used - 1 < MAXLV - 2 && pin[CTR_LEVEL0 + 2 * (used - 1)] == 0) used--;
     t->levels = used;
     t->built = true;
+    hipLaunchKernelGGL(k_init<T>, dim3(1), dim3(256), 0, st, a);   // reset for the next build of this tree
+    t->ctr_ready = true;
 }
 
 #ifdef BVH_PROFILE_MID
@@ -1198,7 +1219,7 @@ void debug_mid_prof(unsigned long long* out, bool reset) {
 }
 #endif
 
-template void build_tree<float>(bvhgpu_tree*, const float*, size_t);
-template void build_tree<double>(bvhgpu_tree*, const double*, size_t);
+template void build_tree<float>(bvhgpu_tree*, const float*, size_t, bool);
+template void build_tree<double>(bvhgpu_tree*, const double*, size_t, bool);
 
 }  // namespace bvhgpu

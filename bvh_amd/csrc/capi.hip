@@ -63,7 +63,7 @@ void free_tree_buffers(bvhgpu_tree* t) {
 
 constexpr size_t MAX_SHAPES = (0xFFFFFFFFull - 1) / 3;  // flat indices are u32 (flat_bvh.rs:136)
 
-template <typename T> int do_build(bvhgpu_tree* t, const T* aabbs, size_t n, int mem) {
+template <typename T> int do_build(bvhgpu_tree* t, const T* aabbs, size_t n, int mem, bool flat = false) {
     bvhgpu_ctx* ctx = t->ctx;
     if (n && !aabbs) return fail(ctx, BVHGPU_INVALID_ARG, "aabbs is NULL");
     if (n > MAX_SHAPES) return fail(ctx, BVHGPU_OVERFLOW, "too many shapes for u32 flat indices");
@@ -76,18 +76,19 @@ template <typename T> int do_build(bvhgpu_tree* t, const T* aabbs, size_t n, int
         BVH_HIP(hipMemcpyAsync(t->aabbs.p, aabbs, n * 6 * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
         dev = t->aabbs.as<T>();
     }
-    build_tree<T>(t, dev, n);
+    build_tree<T>(t, dev, n, flat);
+    if (flat && n == 0) t->flattened = true;
     if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[1], ctx->stream)); ctx->ev_set |= 1u; }
     return BVHGPU_OK;
 }
 
-template <typename T> int new_build(bvhgpu_ctx* ctx, const T* aabbs, size_t n, int mem, bvhgpu_tree** out) {
+template <typename T> int new_build(bvhgpu_ctx* ctx, const T* aabbs, size_t n, int mem, bvhgpu_tree** out, bool flat = false) {
     if (!ctx || !out) return fail(ctx, BVHGPU_INVALID_ARG, "ctx/out is NULL");
     *out = nullptr;
     bvhgpu_tree* t = new bvhgpu_tree();
     t->ctx = ctx;
     t->dtype = Traits<T>::dtype;
-    int rc = guarded(ctx, [&] { return do_build<T>(t, aabbs, n, mem); });
+    int rc = guarded(ctx, [&] { return do_build<T>(t, aabbs, n, mem, flat); });
     if (rc != BVHGPU_OK) { free_tree_buffers(t); delete t; return rc; }
     *out = t;
     return BVHGPU_OK;
@@ -385,6 +386,24 @@ int bvhgpu_rebuild_f64(bvhgpu_tree* t, const double* aabbs, size_t n, int mem) {
     if (!t) return BVHGPU_INVALID_ARG;
     if (t->dtype != BVHGPU_F64) return fail(t->ctx, BVHGPU_DTYPE_MISMATCH, "tree is f32");
     return guarded(t->ctx, [&] { return do_build<double>(t, aabbs, n, mem); });
+}
+
+// FlatBvh::build (flat_bvh.rs:328-331) = Bvh::build + flatten in one call: one host round trip instead of two
+int bvhgpu_build_flat_f32(bvhgpu_ctx* ctx, const float* aabbs, size_t n, int mem, bvhgpu_tree** out) {
+    return new_build<float>(ctx, aabbs, n, mem, out, true);
+}
+int bvhgpu_build_flat_f64(bvhgpu_ctx* ctx, const double* aabbs, size_t n, int mem, bvhgpu_tree** out) {
+    return new_build<double>(ctx, aabbs, n, mem, out, true);
+}
+int bvhgpu_rebuild_flat_f32(bvhgpu_tree* t, const float* aabbs, size_t n, int mem) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    if (t->dtype != BVHGPU_F32) return fail(t->ctx, BVHGPU_DTYPE_MISMATCH, "tree is f64");
+    return guarded(t->ctx, [&] { return do_build<float>(t, aabbs, n, mem, true); });
+}
+int bvhgpu_rebuild_flat_f64(bvhgpu_tree* t, const double* aabbs, size_t n, int mem) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    if (t->dtype != BVHGPU_F64) return fail(t->ctx, BVHGPU_DTYPE_MISMATCH, "tree is f32");
+    return guarded(t->ctx, [&] { return do_build<double>(t, aabbs, n, mem, true); });
 }
 
 void bvhgpu_tree_destroy(bvhgpu_tree* t) {

@@ -64,6 +64,7 @@ struct bvhgpu_tree {
     bool built = false;     // has nodes / shape_node (false for imported scenes)
     bool flattened = false; // has trav (+ flat if built)
     bool unfolded = false;  // trav mirrors an uploaded FlatBvh 1:1 (nav and leaf entries kept apart)
+    bool ctr_ready = false; // build counters / root keys were reset by the previous build
     int levels = 0;
     // persistent device arrays
     bvhgpu::DevBuf aabbs;       // n * 6 T
@@ -114,7 +115,7 @@ struct bvhgpu_hits {
 namespace bvhgpu {
 
 // build.hip
-template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t n);
+template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after);
 // flatten.hip
 template <typename T> void flatten_tree(bvhgpu_tree* t);
 // traverse.hip

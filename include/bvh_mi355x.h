@@ -116,6 +116,12 @@ int bvhgpu_build_f64(bvhgpu_ctx *ctx, const double *aabbs, size_t n, int mem, bv
 /* Rebuild in place (same dtype, n <= capacity of the first build): no allocation on the hot loop. */
 int bvhgpu_rebuild_f32(bvhgpu_tree *tree, const float *aabbs, size_t n, int mem);
 int bvhgpu_rebuild_f64(bvhgpu_tree *tree, const double *aabbs, size_t n, int mem);
+/* FlatBvh::build (flat_bvh.rs:328-331) = Bvh::build + Bvh::flatten in ONE call (one host round trip): the tree is
+ * both built and flattened on return. */
+int bvhgpu_build_flat_f32(bvhgpu_ctx *ctx, const float *aabbs, size_t n, int mem, bvhgpu_tree **out);
+int bvhgpu_build_flat_f64(bvhgpu_ctx *ctx, const double *aabbs, size_t n, int mem, bvhgpu_tree **out);
+int bvhgpu_rebuild_flat_f32(bvhgpu_tree *tree, const float *aabbs, size_t n, int mem);
+int bvhgpu_rebuild_flat_f64(bvhgpu_tree *tree, const double *aabbs, size_t n, int mem);
 void bvhgpu_tree_destroy(bvhgpu_tree *tree);
 
 int bvhgpu_tree_info(const bvhgpu_tree *tree, int *dtype, size_t *n_shapes, size_t *n_nodes, size_t *n_flat);
