@@ -202,6 +202,47 @@ __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, ui
     }
 }
 
+// enqueue BOTH children of a node.  The queue slots are reserved by lanes 0 and 1 at the same time (one atomic
+// each; a level-tier child takes its item slot and its tile range with ONE 64-bit add on the adjacent
+// (items, tiles) counters), so the select kernel pays one atomic round trip per node instead of four.
+template <typename T>
+__device__ void push_pair(const BuildArgs<T>& a, int next_level, uint32_t parent, uint32_t li, uint32_t lstart, uint32_t lcount,
+                          const T* AL, const T* CL, uint32_t lheap, uint32_t ri, uint32_t rstart, uint32_t rcount,
+                          const T* AR, const T* CR, uint32_t rheap, int lane) {
+    const int nslot = lvl_slot(next_level);
+    const int npar = next_level & 1;
+    const uint32_t mycount = lane == 0 ? lcount : rcount;
+    const int mykind = mycount <= (uint32_t)SMALL_MAX ? 0 : (mycount <= (uint32_t)MidB<T>::MAXN ? 1 : (mycount <= (uint32_t)MidA<T>::MAXN ? 2 : 3));
+    const uint32_t myntile = (mycount + TILE - 1) / TILE;
+    uint32_t slot = 0, tb = 0;
+    if (lane < 2) {
+        if (mykind == 0) slot = atomicAdd(&a.ctr[CTR_SMALL], 1u);
+        else if (mykind == 1) slot = atomicAdd(&a.ctr[CTR_MID2], 1u);
+        else if (mykind == 2) slot = atomicAdd(&a.ctr[CTR_MID], 1u);
+        else {
+            const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(&a.ctr[CTR_LEVEL0 + 2 * nslot]),
+                                                     1ull | ((unsigned long long)myntile << 32));
+            slot = (uint32_t)old; tb = (uint32_t)(old >> 32);
+        }
+    }
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        const uint32_t cslot = __shfl(slot, side), ctb = __shfl(tb, side);
+        const int kind = __shfl(mykind, side);
+        const uint32_t ccount = side ? rcount : lcount, ntile = (ccount + TILE - 1) / TILE;
+        Item<T>* it = kind == 0 ? &a.small[cslot] : (kind == 1 ? &a.mid2[cslot] : (kind == 2 ? &a.mid[cslot] : &a.big[npar][cslot]));
+        if (lane == 0) {
+            it->ni = side ? ri : li; it->parent = parent; it->start = side ? rstart : lstart; it->count = ccount;
+            it->tile_base = ctb; it->parity = (uint32_t)npar; it->heap = side ? rheap : lheap; it->_r1 = 0;
+        }
+        if (lane < 6) { it->A[lane] = side ? AR[lane] : AL[lane]; it->C[lane] = side ? CR[lane] : CL[lane]; }
+        if (kind == 3) {
+            for (uint32_t j = lane; j < ntile; j += WAVE) a.tile_item[npar][ctb + j] = cslot;
+            init_stats<T>(&a.stats[npar][cslot], lane);
+        }
+    }
+}
+
 // counters = 0, root keys = identities of min / max
 template <typename T> __global__ __launch_bounds__(256) void k_init(BuildArgs<T> a) {
     using Tr = Traits<T>;
@@ -434,8 +475,8 @@ template <typename T> __global__ __launch_bounds__(256) void k_select(BuildArgs<
             a.node_count[ni] = count;
             a.node_slot[ni] = (uint16_t)it->heap;
         }
-        push_item<T>(a, level + 1, li, ni, start, nl, AL, CL, heap_child(it->heap, 0u), lane);
-        push_item<T>(a, level + 1, ri, ni, start + nl, count - nl, AR, CR, heap_child(it->heap, 1u), lane);
+        push_pair<T>(a, level + 1, ni, li, start, nl, AL, CL, heap_child(it->heap, 0u), ri, start + nl, count - nl, AR, CR,
+                     heap_child(it->heap, 1u), lane);
 
         // per-tile exclusive offsets for the stable scatter: dest = start + tile_cnt[t][b] + rank
         uint32_t base[NUM_BUCKETS];

@@ -21,7 +21,7 @@ constexpr uint32_t NONE = BVHGPU_NONE;
 constexpr int NUM_BUCKETS = 6;        // reference: src/bvh/bucket.rs:5
 constexpr int WAVE = 64;              // gfx950 wavefront
 constexpr int SMALL_MAX = 64;         // segments <= one wave are finished by the wave-subtree kernel
-constexpr int TILE = 1024;            // positions per workgroup tile in the level-synchronous tier
+constexpr int TILE = 512;             // positions per workgroup tile in the level-synchronous tier
 constexpr int STAT_KEYS = 12;         // aabb min3,max3, centroid min3,max3
 
 // ------------------------------------------------------------------------------------------------
