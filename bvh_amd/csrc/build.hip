@@ -488,17 +488,23 @@ template <typename T> __global__ __launch_bounds__(256) void k_select(BuildArgs<
             const uint32_t tl = c0 + lane;
             const bool valid = tl < ntile;
             uint32_t* tc = a.tile_cnt + (size_t)(it->tile_base + tl) * NUM_BUCKETS;
+            // the six bucket columns are scanned together: one batch of cross-lane moves per step
+            uint32_t v[NUM_BUCKETS], inc[NUM_BUCKETS];
+#pragma unroll
+            for (int b = 0; b < NUM_BUCKETS; b++) { v[b] = valid ? tc[b] : 0u; inc[b] = v[b]; }
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                if (c0 + d >= ntile && d >= (int)(ntile - c0)) break;   // no lane of this chunk has a valid lane d below it
+                uint32_t u[NUM_BUCKETS];
+#pragma unroll
+                for (int b = 0; b < NUM_BUCKETS; b++) u[b] = __shfl_up(inc[b], d);
+#pragma unroll
+                for (int b = 0; b < NUM_BUCKETS; b++) inc[b] += lane >= d ? u[b] : 0u;
+            }
 #pragma unroll
             for (int b = 0; b < NUM_BUCKETS; b++) {
-                uint32_t v = valid ? tc[b] : 0u;
-                uint32_t inc = v;
-#pragma unroll
-                for (int d = 1; d < WAVE; d <<= 1) {
-                    uint32_t u = __shfl_up(inc, d);
-                    if (lane >= d) inc += u;
-                }
-                if (valid) tc[b] = base[b] + inc - v;
-                base[b] += __shfl(inc, WAVE - 1);
+                if (valid) tc[b] = base[b] + inc[b] - v[b];
+                base[b] += __shfl(inc[b], WAVE - 1);
             }
         }
     }
