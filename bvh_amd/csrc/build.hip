@@ -96,9 +96,9 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T>
     __shared__ Key sk[STAT_KEYS];
     if (threadIdx.x < STAT_KEYS) sk[threadIdx.x] = key_is_min(threadIdx.x) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
     __syncthreads();
-    Key loc[STAT_KEYS];
+    T loc[STAT_KEYS];   // joined on floats (one v_min/v_max each); keys only for the atomics that merge waves
 #pragma unroll
-    for (int j = 0; j < STAT_KEYS; j++) loc[j] = key_is_min(j) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
+    for (int j = 0; j < STAT_KEYS; j++) loc[j] = key_is_min(j) ? Tr::inf() : -Tr::inf();
     if (blockIdx.x == 0)   // the LDS slot table of the previous tree (filled again by flatten)
         for (uint32_t i = threadIdx.x; i < a.n_slots; i += blockDim.x) a.slot_entry[i] = NONE;
     const bool copy = a.src != a.aabbs;
@@ -115,25 +115,29 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T>
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            Key kmn = Tr::key(bx[k]), kmx = Tr::key(bx[3 + k]);
-            Key kc = Tr::key(center1(bx[k], bx[3 + k]));
-            loc[k] = loc[k] < kmn ? loc[k] : kmn;
-            loc[3 + k] = loc[3 + k] > kmx ? loc[3 + k] : kmx;
-            loc[6 + k] = loc[6 + k] < kc ? loc[6 + k] : kc;
-            loc[9 + k] = loc[9 + k] > kc ? loc[9 + k] : kc;
+            const T c = center1(bx[k], bx[3 + k]);
+            loc[k] = join_min(loc[k], bx[k]);
+            loc[3 + k] = join_max(loc[3 + k], bx[3 + k]);
+            loc[6 + k] = join_min(loc[6 + k], c);
+            loc[9 + k] = join_max(loc[9 + k], c);
         }
     }
-#pragma unroll
-    for (int j = 0; j < STAT_KEYS; j++) {  // wave butterfly first: one LDS atomic per wave, not per lane
-        Key v = loc[j];
+    {   // wave butterfly (all 12 moves of a step in one batch), then one LDS key atomic per wave and value
+        const int lane = lane_id();
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) {
-            Key u = __shfl_xor(v, d);
-            v = key_is_min(j) ? (u < v ? u : v) : (u > v ? u : v);
+            T u[STAT_KEYS];
+#pragma unroll
+            for (int j = 0; j < STAT_KEYS; j++) u[j] = lane_fetch(loc[j], (lane ^ d) << 2);
+#pragma unroll
+            for (int j = 0; j < STAT_KEYS; j++) loc[j] = key_is_min(j) ? join_min(loc[j], u[j]) : join_max(loc[j], u[j]);
         }
-        if (lane_id() == 0) {
-            if (key_is_min(j)) atomicMin(&sk[j], v);
-            else atomicMax(&sk[j], v);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < STAT_KEYS; j++) {
+                if (key_is_min(j)) atomicMin(&sk[j], Tr::key(loc[j]));
+                else atomicMax(&sk[j], Tr::key(loc[j]));
+            }
         }
     }
     __syncthreads();
@@ -1199,7 +1203,7 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     // counters and root keys were reset at the end of the previous build of this tree (off the critical path)
     if (!t->ctr_ready) hipLaunchKernelGGL(k_init<T>, dim3(1), dim3(256), 0, st, a);
     t->ctr_ready = false;
-    const int prep_grid = (int)std::min<size_t>((n + 1023) / 1024, 256);
+    const int prep_grid = (int)std::min<size_t>((n + 511) / 512, 1024);
     hipLaunchKernelGGL(k_prep<T>, dim3(prep_grid), dim3(256), 0, st, a);   // + aabbs copy + root item
 
     const int tile_grid = (int)std::min<size_t>(max_tiles, 2048);
