@@ -181,15 +181,19 @@ class Tree:
     shape_node: np.ndarray
 
 
-def build(aabbs, parallel: bool = False) -> Tree:
+def build(aabbs, parallel: bool = False, threads: int = 0) -> Tree:
+    """threads > 0: task-parallel build (the rayon_executor restatement) on a team of that size"""
     s = _sfx(aabbs.dtype)
     ft, nt, _, _ = _types(s)
     a = np.ascontiguousarray(aabbs, dtype=ft).reshape(-1, 6)
     n = len(a)
     nodes = np.zeros(max(2 * n - 1, 0), dtype=nt)
     shape_node = np.zeros(n, dtype=np.uint32)
-    fn = getattr(lib(), f"orc_build_par_{s}" if parallel else f"orc_build_{s}")
-    rc = fn(_p(a), C.c_size_t(n), _p(nodes), _p(shape_node))
+    if threads > 0:
+        rc = getattr(lib(), f"orc_build_threads_{s}")(_p(a), C.c_size_t(n), _p(nodes), _p(shape_node), C.c_int(threads))
+    else:
+        fn = getattr(lib(), f"orc_build_par_{s}" if parallel else f"orc_build_{s}")
+        rc = fn(_p(a), C.c_size_t(n), _p(nodes), _p(shape_node))
     if rc != 0:
         raise MemoryError("oracle build failed")
     return Tree(nodes, shape_node)
