@@ -621,3 +621,21 @@ def test_ordered_traversal_matches_iterator_restatement(eng, orc, dtype):
     with pytest.raises(eng.BvhGpuError) as e:
         db.traverse_batch(_rb(eng, along), order="nearest")
     assert "32" in str(e.value)
+
+
+def test_parity_1_2m_triangles(eng, orc):
+    """ten times the BASELINE scene (create_n_cubes(100 000) = 1.2 M triangles): more level-synchronous passes,
+    many tier-A/B items, multi-chunk tile-offset scans — node, flat and CSR arrays byte-identical to the oracle."""
+    from bvh_amd import testbase as tb
+    _, aabbs = tb.create_n_cubes(100_000)
+    rays = orc.create_rays(0, 100_000)
+    bvh = eng.Bvh.from_aabbs(aabbs)
+    ot = orc.build(aabbs, threads=min(8, orc.max_threads()))
+    assert bvh.nodes.tobytes() == ot.nodes.tobytes()
+    assert np.array_equal(bvh.shape_nodes, ot.shape_node)
+    flat = bvh.flatten()
+    oflat = orc.flatten(ot.nodes)
+    assert flat.nodes.tobytes() == oflat.tobytes()
+    off, idx, _, st = flat.traverse_batch(_rb(eng, rays), stats=True)
+    ooff, oidx, _, ost = orc.traverse_flat(oflat, aabbs, rays, threads=orc.max_threads())
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx) and st["visited"] == ost["visited"]
