@@ -114,7 +114,7 @@ SYMBOLS = [
     ("bvhgpu_get_tuning", _i, [_vp, _i, C.POINTER(_i)]),
 ]
 TUNE_TRAVERSE_VARIANT = 0
-TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_TRAVERSE_LDS_SLOTS, TUNE_TRAVERSE_LDS_THREADS = 3, 4, 5
+TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_TRAVERSE_LDS_SLOTS, TUNE_TRAVERSE_LDS_THREADS, TUNE_TRAVERSE_SPLIT = 3, 4, 5, 6
 
 _lib = None
 

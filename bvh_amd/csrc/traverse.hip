@@ -418,12 +418,18 @@ constexpr int LDS_INNER = 8;   // walk steps between two refill phases
 template <typename T, int MODE, bool STATS>
 __global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>* __restrict__ nodes, uint32_t n_trav,
                                                                const uint32_t* __restrict__ slot_entry, uint32_t K,
-                                                               uint32_t first_slot,
+                                                               uint32_t first_slot, uint32_t split,
                                                                const typename Traits<T>::Ray* __restrict__ rays,
                                                                uint32_t n_rays, uint32_t rays_per_wg, WalkOut<T> w) {
+    // split != 0: every ray is walked as TWO independent items, item 2r over the entries of the root's left
+    // subtree [0, split_at) and item 2r+1 over the right one [split_at, n_trav).  The per-ray list is the
+    // concatenation of the two (pre-order!), so the CSR machinery simply runs over 2R items.  At 1 M rays a lane
+    // only gets ~2 rays; halving the longest walks and doubling the items per lane shortens the tail of the launch.
+    // (n_rays and rays_per_wg count items here.)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t& s_next = *reinterpret_cast<uint32_t*>(smem);
     TopLds<T> top(smem + 16, K);
+    const uint32_t split_at = split ? load_node(nodes).exit : 0u;   // wave-uniform
     const unsigned long long g0 = (unsigned long long)blockIdx.x * rays_per_wg;
     const unsigned long long g1 = g0 + rays_per_wg;
     const uint32_t wg_begin = (uint32_t)(g0 < n_rays ? g0 : n_rays);
@@ -439,13 +445,13 @@ __global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>*
     const unsigned long long lt = lanemask_lt();
     LaneRay<T, MODE> ray;
     ray.clear();
-    uint32_t i = n_trav, slot = SLOT_NONE;
+    uint32_t i = 0, limit = 0, slot = SLOT_NONE;   // the walk runs while i < limit
     bool exhausted = wg_begin >= wg_end;   // wave-uniform: the workgroup's range has been handed out
     PoolCursor pc;
     unsigned long long steps = 0, leaf_steps = 0, wsteps = 0, cands = 0;
     while (true) {
         // ---- refill phase
-        bool run = i < n_trav;
+        bool run = i < limit;
         const unsigned long long idle = __ballot(!run);
         if (idle) {
             if (!run && ray.r != NONE) { cands += ray.cnt; ray.retire(w); }
@@ -456,8 +462,17 @@ __global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>*
                 base = __builtin_amdgcn_readfirstlane(base);
                 const uint32_t mine = base + (uint32_t)__popcll(idle & lt);
                 if (!run && base < wg_end && mine < wg_end) {
-                    ray.load(rays, mine);
-                    i = 0; slot = first_slot; run = true;
+                    if (split_at) {
+                        const bool right = (mine & 1u) != 0u;
+                        ray.load(rays, mine >> 1);
+                        ray.r = mine;                       // counts / pool records are per item
+                        i = right ? split_at : 0u; limit = right ? n_trav : split_at;
+                        slot = right ? 3u : 2u;             // heap numbers of the root's children
+                    } else {
+                        ray.load(rays, mine);
+                        i = 0; limit = n_trav; slot = first_slot;
+                    }
+                    run = true;
                 }
                 exhausted = base >= wg_end || (wg_end - base) <= nidle;
             }
@@ -470,7 +485,7 @@ __global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>*
             uint32_t shape = NONE;
             T t0 = 0, t1 = 0;
             if (STATS) wsteps++;
-            if (i < n_trav) {
+            if (i < limit) {
                 NodeRegs<T> nd;
                 if (slot < K) nd = top.load(slot);
                 else nd = load_node(nodes + i);
@@ -495,13 +510,21 @@ __global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>*
 constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;
 
+// PAIR: every ray was walked as two items (k_traverse_lds split): its count is counts[2r] + counts[2r+1]
+template <bool PAIR> __device__ __forceinline__ uint32_t ray_count(const uint32_t* __restrict__ counts, uint32_t r) {
+    if (!PAIR) return counts[r];
+    const uint2 c = reinterpret_cast<const uint2*>(counts)[r];
+    return c.x + c.y;
+}
+
+template <bool PAIR>
 __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict__ counts, uint32_t n,
                                                      unsigned long long* __restrict__ blocksums) {
     __shared__ unsigned long long ws[4];
     const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
     unsigned long long s = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) s += (base + j < n) ? counts[base + j] : 0u;
+    for (int j = 0; j < SCAN_ITEMS; j++) s += (base + j < n) ? ray_count<PAIR>(counts, base + j) : 0u;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
     if (lane_id() == 0) ws[threadIdx.x >> 6] = s;
@@ -531,6 +554,7 @@ __global__ __launch_bounds__(256) void k_scan_sums(unsigned long long* __restric
     if (threadIdx.x == 0) *total_out = carry;
 }
 
+template <bool PAIR>
 __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__ counts, uint32_t n,
                                                     const unsigned long long* __restrict__ blocksums,
                                                     const unsigned long long* __restrict__ total,
@@ -540,7 +564,7 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__
     uint32_t v[SCAN_ITEMS];
     uint32_t s = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) { v[j] = (base + j < n) ? counts[base + j] : 0u; s += v[j]; }
+    for (int j = 0; j < SCAN_ITEMS; j++) { v[j] = (base + j < n) ? ray_count<PAIR>(counts, base + j) : 0u; s += v[j]; }
     uint32_t inc = s;
     const int lane = lane_id();
 #pragma unroll
@@ -565,6 +589,7 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void k_hits_scatter(const HitRec* __restrict__ pool, const T* __restrict__ pool_v,
                                                       const unsigned long long* __restrict__ ctr,
                                                       unsigned long long pool_cap, const uint32_t* __restrict__ offsets,
+                                                      const uint32_t* __restrict__ pair_counts,
                                                       uint32_t* __restrict__ indices, T* __restrict__ vals) {
     const unsigned long long n = ctr[0];
     if (n > pool_cap) return;  // pool overflowed: indices[] is too small as well; the host grows both and replays
@@ -572,7 +597,9 @@ __global__ __launch_bounds__(256) void k_hits_scatter(const HitRec* __restrict__
          j += (unsigned long long)gridDim.x * blockDim.x) {
         const HitRec h = pool[j];
         if (h.ray == NONE) continue;   // unused tail of a per-wave chunk
-        const uint32_t d = offsets[h.ray] + h.k;
+        // pair_counts: h.ray is an ITEM (2*ray + side); the right item's records follow the left item's
+        const uint32_t d = pair_counts ? offsets[h.ray >> 1] + ((h.ray & 1u) ? pair_counts[h.ray - 1] : 0u) + h.k
+                                       : offsets[h.ray] + h.k;
         indices[d] = h.shape;
 #pragma unroll
         for (int k = 0; k < NV; k++) vals[NV * (size_t)d + k] = pool_v[NV * j + k];
@@ -581,16 +608,13 @@ __global__ __launch_bounds__(256) void k_hits_scatter(const HitRec* __restrict__
 
 // ------------------------------------------------------------------------------------------------
 template <typename T, int MODE, bool STATS>
-static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, const WalkOut<T>& w, bool coherent) {
+static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, const WalkOut<T>& w, bool use_lds,
+                        uint32_t split_at) {
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
     const uint32_t n_trav = (uint32_t)t->n_trav;
     const TravNode<T>* nodes = t->trav.as<TravNode<T>>();
-    // variant 0: one ray per lane per launch; 2: persistent workgroups + LDS-resident top of the tree
-    int variant = ctx->tune[BVHGPU_TUNE_TRAVERSE_VARIANT];
-    if (variant != 0 && (t->slot_entry.p == nullptr || n_rays < (size_t)ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS] || coherent))
-        variant = 0;
-    if (variant == 0) {
+    if (!use_lds) {   // one ray per lane per launch
         hipLaunchKernelGGL((k_traverse<T, MODE, STATS>), dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, nodes,
                            n_trav, rays_dev, (uint32_t)n_rays, w);
         return;
@@ -601,15 +625,16 @@ static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
     const uint32_t K = (uint32_t)std::min<int>((int)TopCfg<T>::SLOTS, std::max(4, ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_SLOTS]));
     const size_t lds_bytes = 16 + (size_t)K * TopLds<T>::BYTES_PER_SLOT;
     const uint32_t wg_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>((160 * 1024) / lds_bytes, 2048 / lds_threads));
-    const size_t full = (n_rays + WAVE - 1) / WAVE;
+    const size_t n_items = split_at ? 2 * n_rays : n_rays;
+    const size_t full = (n_items + WAVE - 1) / WAVE;
     const uint32_t n_waves = (uint32_t)std::min<size_t>(full, (size_t)ctx->n_cu * wg_per_cu * (lds_threads / WAVE));
     const dim3 lgrid((n_waves + lds_threads / WAVE - 1) / (lds_threads / WAVE));
-    const uint32_t rpg = (uint32_t)((n_rays + lgrid.x - 1) / lgrid.x);   // rays per workgroup
+    const uint32_t rpg = (uint32_t)((n_items + lgrid.x - 1) / lgrid.x);   // items per workgroup
     const uint32_t first_slot = t->n >= 2 ? 2u : SLOT_NONE;               // entry 0 is the root's left child (heap number 2)
     BVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse_lds<T, MODE, STATS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL((k_traverse_lds<T, MODE, STATS>), lgrid, dim3(lds_threads), lds_bytes, st, nodes, n_trav,
-                       t->slot_entry.as<uint32_t>(), K, first_slot, rays_dev, (uint32_t)n_rays, rpg, w);
+                       t->slot_entry.as<uint32_t>(), K, first_slot, split_at, rays_dev, (uint32_t)n_items, rpg, w);
 }
 
 template <typename T>
@@ -624,6 +649,16 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
                    : (flags & BVHGPU_TRAVERSE_TRIANGLES) ? MODE_TRIANGLES
                    : (flags & BVHGPU_TRAVERSE_T_SLICE) ? MODE_T_SLICE : MODE_INDICES;
     const int nv = mode == MODE_T_SLICE ? 2 : (mode == MODE_TRIANGLES ? 3 : 0);
+    // walk kernel: one ray per lane per launch, or persistent workgroups with the top of the tree in LDS
+    const bool use_lds = ctx->tune[BVHGPU_TUNE_TRAVERSE_VARIANT] != 0 && t->slot_entry.p != nullptr && !coherent && !ordered &&
+                         n_rays >= (size_t)ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS];
+    // two items per ray (left / right subtree of the root) for the CSR modes: see k_traverse_lds
+    uint32_t split_at = 0;
+    if (use_lds && mode != MODE_CLOSEST && ctx->tune[BVHGPU_TUNE_TRAVERSE_SPLIT] != 0 && t->n >= 2 && !t->unfolded &&
+        n_rays < (size_t)ctx->n_cu * 2048 * 4) {   // fewer than 4 rays per resident lane: the tail dominates
+        split_at = 1;   // the kernel reads the boundary itself: exit index of entry 0 (the root's left child)
+    }
+    const size_t n_items = split_at ? 2 * n_rays : n_rays;
     h->ctx = ctx; h->dtype = Traits<T>::dtype; h->n_rays = n_rays; h->flags = flags; h->total = 0;
     h->stats = bvhgpu_traverse_stats{0, 0, 0, 0, 0};
     h->ctr.reserve(8 * sizeof(unsigned long long));
@@ -656,14 +691,14 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
             break;                                                                                   \
         }                                                                                            \
         switch (mode) {                                                                              \
-            case MODE_INDICES: if (stats) launch_walk<T, MODE_INDICES, true>(t, rays_dev, n_rays, w, coherent);  \
-                               else launch_walk<T, MODE_INDICES, false>(t, rays_dev, n_rays, w, coherent); break; \
-            case MODE_T_SLICE: if (stats) launch_walk<T, MODE_T_SLICE, true>(t, rays_dev, n_rays, w, coherent);  \
-                               else launch_walk<T, MODE_T_SLICE, false>(t, rays_dev, n_rays, w, coherent); break; \
-            case MODE_TRIANGLES: if (stats) launch_walk<T, MODE_TRIANGLES, true>(t, rays_dev, n_rays, w, coherent); \
-                                 else launch_walk<T, MODE_TRIANGLES, false>(t, rays_dev, n_rays, w, coherent); break; \
-            default: if (stats) launch_walk<T, MODE_CLOSEST, true>(t, rays_dev, n_rays, w, coherent);           \
-                     else launch_walk<T, MODE_CLOSEST, false>(t, rays_dev, n_rays, w, coherent); break;         \
+            case MODE_INDICES: if (stats) launch_walk<T, MODE_INDICES, true>(t, rays_dev, n_rays, w, use_lds, split_at);  \
+                               else launch_walk<T, MODE_INDICES, false>(t, rays_dev, n_rays, w, use_lds, split_at); break; \
+            case MODE_T_SLICE: if (stats) launch_walk<T, MODE_T_SLICE, true>(t, rays_dev, n_rays, w, use_lds, split_at);  \
+                               else launch_walk<T, MODE_T_SLICE, false>(t, rays_dev, n_rays, w, use_lds, split_at); break; \
+            case MODE_TRIANGLES: if (stats) launch_walk<T, MODE_TRIANGLES, true>(t, rays_dev, n_rays, w, use_lds, split_at); \
+                                 else launch_walk<T, MODE_TRIANGLES, false>(t, rays_dev, n_rays, w, use_lds, split_at); break; \
+            default: if (stats) launch_walk<T, MODE_CLOSEST, true>(t, rays_dev, n_rays, w, use_lds, split_at);           \
+                     else launch_walk<T, MODE_CLOSEST, false>(t, rays_dev, n_rays, w, use_lds, split_at); break;         \
         }                                                                                            \
     } while (0)
 
@@ -692,7 +727,7 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
         return;
     }
 
-    h->counts.reserve((n_rays + 1) * 4);
+    h->counts.reserve((n_items + 1) * 4);
     h->offsets.reserve((n_rays + 1) * 4);
     const uint32_t nb = (uint32_t)((n_rays + SCAN_BLOCK - 1) / SCAN_BLOCK);
     h->blocksums.reserve((nb + 1) * sizeof(unsigned long long));
@@ -717,21 +752,24 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
         DISPATCH_WALK();
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); }
         unsigned long long* bs = h->blocksums.as<unsigned long long>();
-        hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs);
+        uint32_t* offs = h->offsets.as<uint32_t>();
+        if (split_at) hipLaunchKernelGGL(k_scan_reduce<true>, dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs);
+        else hipLaunchKernelGGL(k_scan_reduce<false>, dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, bs, nb, ctr + 3);
-        hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs, ctr + 3,
-                           h->offsets.as<uint32_t>());
+        if (split_at) hipLaunchKernelGGL(k_scan_final<true>, dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs, ctr + 3, offs);
+        else hipLaunchKernelGGL(k_scan_final<false>, dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs, ctr + 3, offs);
+        const uint32_t* pair_counts = split_at ? counts : nullptr;
         const int sgrid = (int)std::min<size_t>((cap + 255) / 256, (size_t)ctx->n_cu * 8);
         T* vals = mode == MODE_T_SLICE ? h->tslice.as<T>() : h->isect.as<T>();
         if (nv == 2)
             hipLaunchKernelGGL((k_hits_scatter<T, 2>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap,
-                               h->offsets.as<uint32_t>(), h->indices.as<uint32_t>(), vals);
+                               offs, pair_counts, h->indices.as<uint32_t>(), vals);
         else if (nv == 3)
             hipLaunchKernelGGL((k_hits_scatter<T, 3>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap,
-                               h->offsets.as<uint32_t>(), h->indices.as<uint32_t>(), vals);
+                               offs, pair_counts, h->indices.as<uint32_t>(), vals);
         else
             hipLaunchKernelGGL((k_hits_scatter<T, 0>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap,
-                               h->offsets.as<uint32_t>(), h->indices.as<uint32_t>(), vals);
+                               offs, pair_counts, h->indices.as<uint32_t>(), vals);
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
         BVH_HIP(hipMemcpyAsync(pin, ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         BVH_HIP(hipStreamSynchronize(st));

@@ -24,8 +24,8 @@ rays = RayBatch.generate(0, R, bounds, buf, np.float32, ctx)
 torch.cuda.synchronize()
 
 
-def run(variant, wpc=32, refill=1, reps=10, rpl=1, K=2048, thr=1024):
-    ctx.set_tuning(0, variant); ctx.set_tuning(1, wpc); ctx.set_tuning(2, refill); ctx.set_tuning(4, K); ctx.set_tuning(5, thr)
+def run(variant, wpc=32, refill=1, reps=10, rpl=1, K=2048, thr=1024, split=1):
+    ctx.set_tuning(0, variant); ctx.set_tuning(4, K); ctx.set_tuning(5, thr); ctx.set_tuning(6, split)
     ctx.enable_timing(False)
     off, idx, _, st = bvh.traverse_batch(rays, stats=True)
     ctx.enable_timing(True)
@@ -39,13 +39,7 @@ def run(variant, wpc=32, refill=1, reps=10, rpl=1, K=2048, thr=1024):
 
 ref = run(0)
 print(f"variant 0 (one ray per lane): median {ref[3]:.4f} ms  min {ref[4]:.4f} ms  stats {ref[2]} util={ref[2]['device_steps'] / 64 / ref[2]['wave_steps']:.3f}")
-for K, thr in ((5056, 1024), (2048, 1024), (1280, 512)):
-    rpl = K; refill = thr
-    off, idx, st, med, mn = run(2, 16, 1, K=K, thr=thr)
+for K, thr, split in ((2048, 1024, 0), (2048, 1024, 1), (5056, 1024, 1), (1280, 512, 1)):
+    off, idx, st, med, mn = run(2, K=K, thr=thr, split=split)
     same = np.array_equal(off, ref[0]) and np.array_equal(idx, ref[1]) and {k: v for k, v in st.items() if k != 'wave_steps'} == {k: v for k, v in ref[2].items() if k != 'wave_steps'}
-    print(f"lds-top K={rpl} threads={refill:2d}: median {med:.4f} ms  min {mn:.4f} ms  same={same} util={st['device_steps'] / 64 / st['wave_steps']:.3f} wsteps={st['wave_steps']}", flush=True)
-for wpc in (32,):
-    for refill in (1,):
-        off, idx, st, med, mn = run(1, wpc, refill)
-        same = np.array_equal(off, ref[0]) and np.array_equal(idx, ref[1]) and {k: v for k, v in st.items() if k != 'wave_steps'} == {k: v for k, v in ref[2].items() if k != 'wave_steps'}
-        print(f"persist wpc={wpc:2d} refill_min={refill:2d}: median {med:.4f} ms  min {mn:.4f} ms  same={same} util={st['device_steps'] / 64 / st['wave_steps']:.3f} wsteps={st['wave_steps']}", flush=True)
+    print(f"lds-top K={K} threads={thr} split={split}: median {med:.4f} ms  min {mn:.4f} ms  same={same} util={st['device_steps'] / 64 / st['wave_steps']:.3f} wsteps={st['wave_steps']}", flush=True)
