@@ -37,8 +37,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--cubes", type=int, default=10_000, help="create_n_cubes(n): 12 triangles each")
     ap.add_argument("--rays", type=int, default=1_000_000, help="rays per GPU per step")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")

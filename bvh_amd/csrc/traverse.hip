@@ -554,19 +554,34 @@ __global__ __launch_bounds__(256) void k_scan_sums(unsigned long long* __restric
     if (threadIdx.x == 0) *total_out = carry;
 }
 
-template <bool PAIR>
+constexpr uint32_t SCAN_FUSED_MAX_BLOCKS = 2048;   // up to this many blocks every block sums its predecessors itself
+
+// counts → offsets.  PREFIXED: blocksums already hold exclusive prefixes (k_scan_sums ran, large batches); otherwise
+// they are the raw per-block sums of k_scan_reduce and this block adds up its predecessors (one kernel less).
+template <bool PAIR, bool PREFIXED>
 __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__ counts, uint32_t n,
                                                     const unsigned long long* __restrict__ blocksums,
-                                                    const unsigned long long* __restrict__ total,
+                                                    unsigned long long* __restrict__ total,
                                                     uint32_t* __restrict__ offsets) {
     __shared__ uint32_t ws[4];
+    __shared__ unsigned long long wb[4];
     const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+    const int lane = lane_id();
+    unsigned long long before = 0;
+    if (PREFIXED) {
+        before = blocksums[blockIdx.x];
+    } else {
+        unsigned long long part = 0;
+        for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256) part += blocksums[j];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d);
+        if (lane == 0) wb[threadIdx.x >> 6] = part;
+    }
     uint32_t v[SCAN_ITEMS];
     uint32_t s = 0;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) { v[j] = (base + j < n) ? ray_count<PAIR>(counts, base + j) : 0u; s += v[j]; }
     uint32_t inc = s;
-    const int lane = lane_id();
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) {
         uint32_t u = __shfl_up(inc, d);
@@ -574,15 +589,22 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__
     }
     if (lane == WAVE - 1) ws[threadIdx.x >> 6] = inc;
     __syncthreads();
+    if (!PREFIXED) before = wb[0] + wb[1] + wb[2] + wb[3];
     uint32_t wbase = 0;
     for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wbase += ws[w];
-    uint32_t run = (uint32_t)blocksums[blockIdx.x] + wbase + inc - s;
+    uint32_t run = (uint32_t)before + wbase + inc - s;
 #pragma unroll
     for (int j = 0; j < SCAN_ITEMS; j++) {
         if (base + j < n) offsets[base + j] = run;
         run += v[j];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = (uint32_t)(*total);
+    if (PREFIXED) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) offsets[n] = (uint32_t)(*total);
+    } else if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {   // the last block knows the total
+        const unsigned long long t = before + ws[0] + ws[1] + ws[2] + ws[3];
+        offsets[n] = (uint32_t)t;
+        *total = t;
+    }
 }
 
 template <typename T, int NV>
@@ -755,9 +777,14 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
         uint32_t* offs = h->offsets.as<uint32_t>();
         if (split_at) hipLaunchKernelGGL(k_scan_reduce<true>, dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs);
         else hipLaunchKernelGGL(k_scan_reduce<false>, dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, bs, nb, ctr + 3);
-        if (split_at) hipLaunchKernelGGL(k_scan_final<true>, dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs, ctr + 3, offs);
-        else hipLaunchKernelGGL(k_scan_final<false>, dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs, ctr + 3, offs);
+        if (nb > SCAN_FUSED_MAX_BLOCKS) {
+            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, bs, nb, ctr + 3);
+            if (split_at) hipLaunchKernelGGL((k_scan_final<true, true>), dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs, ctr + 3, offs);
+            else hipLaunchKernelGGL((k_scan_final<false, true>), dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs, ctr + 3, offs);
+        } else {
+            if (split_at) hipLaunchKernelGGL((k_scan_final<true, false>), dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs, ctr + 3, offs);
+            else hipLaunchKernelGGL((k_scan_final<false, false>), dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs, ctr + 3, offs);
+        }
         const uint32_t* pair_counts = split_at ? counts : nullptr;
         const int sgrid = (int)std::min<size_t>((cap + 255) / 256, (size_t)ctx->n_cu * 8);
         T* vals = mode == MODE_T_SLICE ? h->tslice.as<T>() : h->isect.as<T>();
