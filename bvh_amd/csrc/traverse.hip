@@ -653,8 +653,13 @@ static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
     const dim3 lgrid((n_waves + lds_threads / WAVE - 1) / (lds_threads / WAVE));
     const uint32_t rpg = (uint32_t)((n_items + lgrid.x - 1) / lgrid.x);   // items per workgroup
     const uint32_t first_slot = t->n >= 2 ? 2u : SLOT_NONE;               // entry 0 is the root's left child (heap number 2)
-    BVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse_lds<T, MODE, STATS>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    static thread_local size_t lds_attr[16] = {};   // per device: dynamic-LDS limit already set for this instantiation
+    size_t& have = lds_attr[ctx->device & 15];
+    if (have < lds_bytes) {
+        BVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_traverse_lds<T, MODE, STATS>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        have = lds_bytes;
+    }
     hipLaunchKernelGGL((k_traverse_lds<T, MODE, STATS>), lgrid, dim3(lds_threads), lds_bytes, st, nodes, n_trav,
                        t->slot_entry.as<uint32_t>(), K, first_slot, split_at, rays_dev, (uint32_t)n_items, rpg, w);
 }
