@@ -639,3 +639,36 @@ def test_parity_1_2m_triangles(eng, orc):
     off, idx, _, st = flat.traverse_batch(_rb(eng, rays), stats=True)
     ooff, oidx, _, ost = orc.traverse_flat(oflat, aabbs, rays, threads=orc.max_threads())
     assert np.array_equal(off, ooff) and np.array_equal(idx, oidx) and st["visited"] == ost["visited"]
+
+
+def test_c_abi_from_plain_c(eng, orc, tmp_path):
+    """tests/c_abi/abi_roundtrip.c — a C11 program that only includes include/bvh_mi355x.h and links
+    libbvh_mi355x.so: FlatBvh::build, Ray::new, traverse, nearest_to; its printout must match the oracle."""
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_roundtrip")
+    libdir = os.path.join(root, "bvh_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi", "abi_roundtrip.c"), "-L", libdir, "-lbvh_mi355x",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    env = dict(os.environ)
+    # the engine must bind to the same HIP runtime the wheel ships (see bvh_amd/_lib.py); for a C program that is
+    # whatever libamdhip64.so.7 the loader finds first: point it at torch's copy, like the Python path does
+    env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.check_output([exe, "5"], env=env, text=True).strip().splitlines()
+    m = 5
+    g = np.stack(np.meshgrid(np.arange(m), np.arange(m), np.arange(m), indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float32) * 2
+    aabbs = np.concatenate([g + np.float32(-0.5), g + np.float32(0.5)], axis=1)
+    ot = orc.build(aabbs)
+    oflat = orc.flatten(ot.nodes)
+    rays = orc.make_rays(np.array([[-5, 0, 0], [-3, -3, -3]], np.float32), np.array([[1, 0, 0], [1, 1, 1]], np.float32))
+    ooff, oidx, _, ost = orc.traverse_flat(oflat, aabbs, rays)
+    assert out[0] == f"shapes {m ** 3} nodes {2 * m ** 3 - 1} flat {3 * m ** 3 - 2} dtype 0"
+    assert out[1] == f"total {len(oidx)} visited {ost['visited']}"
+    for r in range(2):
+        want = " ".join(str(int(i)) for i in oidx[ooff[r]:ooff[r + 1]])
+        assert out[2 + r] == (f"ray {r}: {want}" if want else f"ray {r}:")
+    s, d = orc.nearest(oflat, aabbs, [[2.2, 0.1, 3.9]])
+    assert out[4] == f"nearest {int(s[0])} {d[0]:.6f}"
