@@ -507,7 +507,7 @@ __global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>*
 }
 
 // ---- exclusive scan of per-ray counts ----------------------------------------------------------
-constexpr int SCAN_ITEMS = 16;
+constexpr int SCAN_ITEMS = 4;
 constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;
 
 // PAIR: every ray was walked as two items (k_traverse_lds split): its count is counts[2r] + counts[2r+1]
