@@ -110,6 +110,7 @@ struct bvhgpu_hits {
     bvhgpu::DevBuf blocksums;
     bvhgpu::DevBuf ctr;      // [0] pool count (u64) [1] visited [2] leaf_visits [3] device_steps [4] ray ticket
     size_t pool_cap = 0;
+    bool ctr_clean = false;  // the counters were zeroed behind the previous call's readback
 };
 
 namespace bvhgpu {

@@ -688,7 +688,7 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
     const size_t n_items = split_at ? 2 * n_rays : n_rays;
     h->ctx = ctx; h->dtype = Traits<T>::dtype; h->n_rays = n_rays; h->flags = flags; h->total = 0;
     h->stats = bvhgpu_traverse_stats{0, 0, 0, 0, 0};
-    h->ctr.reserve(8 * sizeof(unsigned long long));
+    { const void* before = h->ctr.p; h->ctr.reserve(8 * sizeof(unsigned long long)); if (h->ctr.p != before) h->ctr_clean = false; }
     unsigned long long* pin = reinterpret_cast<unsigned long long*>(ctx->pinned);
     unsigned long long* ctr = h->ctr.as<unsigned long long>();
 
@@ -734,12 +734,15 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
         h->closest_prim.reserve(std::max<size_t>(n_rays, 1) * 4);
         if (n_rays == 0) return;
         w.closest = h->closest.as<T>(); w.closest_prim = h->closest_prim.as<uint32_t>();
-        BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));
+        if (!h->ctr_clean) BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));
+        h->ctr_clean = false;
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
         DISPATCH_WALK();
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
         BVH_HIP(hipMemcpyAsync(pin, ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));   // for the next call, behind the readback
         BVH_HIP(hipStreamSynchronize(st));
+        h->ctr_clean = true;
         BVH_HIP(hipGetLastError());
         if (ordered && (pin[7] & 0xFFFFFFFFull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
         if (stats) {
@@ -771,7 +774,8 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
             h->pool_t.reserve(h->pool_cap * nv * sizeof(T));
             (mode == MODE_T_SLICE ? h->tslice : h->isect).reserve(h->pool_cap * nv * sizeof(T));
         }
-        BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));
+        if (!h->ctr_clean) BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));
+        h->ctr_clean = false;
         const unsigned long long cap = h->pool_cap;
         w.counts = h->counts.as<uint32_t>(); w.pool = h->pool.as<HitRec>(); w.pool_v = h->pool_t.as<T>(); w.pool_cap = cap;
         uint32_t* counts = w.counts;
@@ -804,7 +808,9 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
                                offs, pair_counts, h->indices.as<uint32_t>(), vals);
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
         BVH_HIP(hipMemcpyAsync(pin, ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));   // for the next call, behind the readback
         BVH_HIP(hipStreamSynchronize(st));
+        h->ctr_clean = true;
         BVH_HIP(hipGetLastError());
         if (ordered && (pin[7] & 0xFFFFFFFFull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
         const unsigned long long used = pin[0];   // pool slots taken (whole chunks)
