@@ -45,6 +45,9 @@ template <typename T> struct MidA {
     static constexpr int HANDOFF = MidB<T>::MAXN;
 };
 template <typename T> struct MidCfg { static constexpr int MAXN = MidA<T>::MAXN; };
+constexpr int STAT_REP = 8;   // global replicas of an item's statistics: tile t adds to replica t % 8, so the ~470 tiles of
+                              // the root do not serialise on 78 addresses (k_bin of level 0: 13.4 -> see profiles); the
+                              // selection merges the replicas
 constexpr int CTR_LEVEL0 = 16;   // u32 pairs (n_items, n_tiles) per level slot
 constexpr size_t ROOTKEY_OFF = 1024;  // byte offset of the 12 root keys inside the ctr buffer
 
@@ -202,7 +205,7 @@ __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, ui
     if (lane < 6) { it->A[lane] = A[lane]; it->C[lane] = C[lane]; }
     if (!is_small && !is_mid && !is_mid2) {
         for (uint32_t j = lane; j < ntile; j += WAVE) a.tile_item[npar][tb + j] = slot;
-        init_stats<T>(&a.stats[npar][slot], lane);
+        for (int r = 0; r < STAT_REP; r++) init_stats<T>(&a.stats[npar][(size_t)slot * STAT_REP + r], lane);
     }
 }
 
@@ -242,7 +245,7 @@ __device__ void push_pair(const BuildArgs<T>& a, int next_level, uint32_t parent
         if (lane < 6) { it->A[lane] = side ? AR[lane] : AL[lane]; it->C[lane] = side ? CR[lane] : CL[lane]; }
         if (kind == 3) {
             for (uint32_t j = lane; j < ntile; j += WAVE) a.tile_item[npar][ctb + j] = cslot;
-            init_stats<T>(&a.stats[npar][cslot], lane);
+            for (int r = 0; r < STAT_REP; r++) init_stats<T>(&a.stats[npar][(size_t)cslot * STAT_REP + r], lane);
         }
     }
 }
@@ -311,7 +314,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_bin(BuildArgs<T> 
             atomicAdd(&sc[rep][bkt], 1u);
         }
         __syncthreads();
-        ItemStats<T>* gs = &a.stats[par][item_id];
+        ItemStats<T>* gs = &a.stats[par][(size_t)item_id * STAT_REP + ((t - it->tile_base) & (STAT_REP - 1))];
         if (threadIdx.x < NUM_BUCKETS) {
             uint32_t c = 0;
 #pragma unroll
@@ -453,7 +456,26 @@ template <typename T> __global__ __launch_bounds__(256) void k_select(BuildArgs<
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t id = wave0; id < nitems; id += nwaves) {
         const Item<T>* it = &a.big[par][id];
-        const ItemStats<T>* st = &a.stats[par][id];
+        // merge the STAT_REP replicas the tiles added to (joins are exact, counts are integers): lane j owns keys j, j+64
+        __shared__ ItemStats<T> s_merged[4];
+        ItemStats<T>* st = &s_merged[threadIdx.x >> 6];
+        {
+            using Key = typename Tr::Key;
+            const ItemStats<T>* rep = &a.stats[par][(size_t)id * STAT_REP];
+            for (int j = lane; j < NUM_BUCKETS * STAT_KEYS; j += WAVE) {
+                const bool mn = key_is_min(j % STAT_KEYS);
+                Key v = rep[0].k[j];
+#pragma unroll
+                for (int r = 1; r < STAT_REP; r++) { const Key u = rep[r].k[j]; v = mn ? (u < v ? u : v) : (u > v ? u : v); }
+                st->k[j] = v;
+            }
+            if (lane < NUM_BUCKETS) {
+                uint32_t c = 0;
+#pragma unroll
+                for (int r = 0; r < STAT_REP; r++) c += rep[r].cnt[lane];
+                st->cnt[lane] = c;
+            }
+        }
         const uint32_t ni = it->ni, parent = it->parent, start = it->start, count = it->count;
         T A[6], C[6];
 #pragma unroll
@@ -1166,7 +1188,7 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     t->bk.reserve(n);
     for (int i = 0; i < 2; i++) {
         t->big[i].reserve(max_big * sizeof(Item<T>));
-        t->stats[i].reserve(max_big * sizeof(ItemStats<T>));
+        t->stats[i].reserve(max_big * STAT_REP * sizeof(ItemStats<T>));
         t->tile_item[i].reserve(max_tiles * 4);
     }
     t->mid.reserve(max_mid * sizeof(Item<T>));
