@@ -672,3 +672,61 @@ def test_c_abi_from_plain_c(eng, orc, tmp_path):
         assert out[2 + r] == (f"ray {r}: {want}" if want else f"ray {r}:")
     s, d = orc.nearest(oflat, aabbs, [[2.2, 0.1, 3.9]])
     assert out[4] == f"nearest {int(s[0])} {d[0]:.6f}"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_all_queries(eng, orc, seed):
+    """in the spirit of the reference's fuzz.rs ("all traversals agree", fuzz.rs:321-324): random scenes of random
+    size and character (spread, clustered, grid-aligned with exact ties, duplicated shapes), random rays and points;
+    every query the engine offers against the oracle, both dtypes alternating."""
+    rng = np.random.default_rng(1000 + seed)
+    dtype = np.float32 if seed % 2 == 0 else np.float64
+    n = int(rng.integers(1, 6000))
+    kind = seed % 4
+    if kind == 0:
+        a = rng.uniform(-50, 50, size=(n, 3))
+    elif kind == 1:
+        c = rng.uniform(-50, 50, size=(max(n // 40, 1), 3))
+        a = c[rng.integers(0, len(c), n)] + rng.normal(scale=0.5, size=(n, 3))
+    elif kind == 2:
+        a = rng.integers(-8, 8, size=(n, 3)).astype(float)
+    else:
+        a = rng.uniform(-50, 50, size=(n, 3)); a[n // 3:] = a[: n - n // 3][rng.integers(0, max(n - n // 3, 1), n - n // 3)]
+    a = a.astype(dtype)
+    tri = np.stack([a, a + rng.uniform(0, 2, size=(n, 3)).astype(dtype), a + rng.uniform(0, 2, size=(n, 3)).astype(dtype)], axis=1)
+    aabbs = np.concatenate([tri.min(axis=1), tri.max(axis=1)], axis=1).astype(dtype)
+    m = 1500
+    o = rng.uniform(-60, 60, size=(m, 3)).astype(dtype)
+    d = (tri[rng.integers(0, n, m)].mean(axis=1) - o).astype(dtype)
+    d[: m // 5] = rng.normal(size=(m // 5, 3))
+    d[m // 5: m // 4] = rng.integers(-1, 2, size=(m // 4 - m // 5, 3)); d[np.all(d == 0, axis=1)] = [1, 0, 0]
+    rays = orc.make_rays(o, d, dtype)
+    bvh = eng.Bvh.from_aabbs(aabbs)
+    ot = orc.build(aabbs)
+    assert bvh.nodes.tobytes() == ot.nodes.tobytes() and np.array_equal(bvh.shape_nodes, ot.shape_node)
+    flat = bvh.flatten()
+    oflat = orc.flatten(ot.nodes)
+    assert flat.nodes.tobytes() == oflat.tobytes()
+    flat.set_triangles(tri)
+    rb = _rb(eng, rays)
+    ooff, oidx, ots, ost = orc.traverse_flat(oflat, aabbs, rays, want_t=True)
+    off, idx, ts, st = flat.traverse_batch(rb, want_t=True, stats=True)
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx) and st["visited"] == ost["visited"]
+    if len(idx):
+        assert np.allclose(ts, ots, rtol=1e-5 if dtype == np.float32 else 1e-12, atol=0)
+    toff, tidx = orc.traverse_tree(ot.nodes, aabbs, rays)               # Bvh::traverse == FlatBvh::traverse
+    assert np.array_equal(toff, ooff) and np.array_equal(tidx, oidx)
+    oisect, oclosest, oprim = orc.triangle_stage(tri, rays, ooff, oidx)
+    _, _, isect, _ = flat.intersect_triangles(rb)
+    cl, prim, _ = flat.closest_hits(rb)
+    assert isect.tobytes() == oisect.tobytes() and cl.tobytes() == oclosest.tobytes() and np.array_equal(prim, oprim)
+    if orc.tree_stats(ot.nodes, aabbs)["max_depth"] < 31:
+        for order, asc in (("nearest", True), ("farthest", False)):
+            noff, nidx, _, _ = flat.traverse_batch(rb, order=order)
+            qoff, qidx = orc.traverse_child_ordered(ot.nodes, aabbs, rays, asc)
+            assert np.array_equal(noff, qoff) and np.array_equal(nidx, qidx)
+    pts = rng.uniform(-60, 60, size=(800, 3)).astype(dtype)
+    for use_tris in (False, True):
+        s_, d_ = flat.nearest_batch(pts, triangles=use_tris)
+        os_, od_ = orc.nearest(oflat, aabbs, pts, tri if use_tris else None)
+        assert np.array_equal(s_, os_) and d_.tobytes() == od_.tobytes()
