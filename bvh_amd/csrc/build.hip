@@ -504,35 +504,8 @@ template <typename T> __global__ __launch_bounds__(256) void k_select(BuildArgs<
         push_pair<T>(a, level + 1, ni, li, start, nl, AL, CL, heap_child(it->heap, 0u), ri, start + nl, count - nl, AR, CR,
                      heap_child(it->heap, 1u), lane);
 
-        // per-tile exclusive offsets for the stable scatter: dest = start + tile_cnt[t][b] + rank
-        uint32_t base[NUM_BUCKETS];
-        uint32_t acc = 0;
-#pragma unroll
-        for (int b = 0; b < NUM_BUCKETS; b++) { base[b] = acc; acc += cnt[b]; }
-        const uint32_t ntile = (count + TILE - 1) / TILE;
-        for (uint32_t c0 = 0; c0 < ntile; c0 += WAVE) {
-            const uint32_t tl = c0 + lane;
-            const bool valid = tl < ntile;
-            uint32_t* tc = a.tile_cnt + (size_t)(it->tile_base + tl) * NUM_BUCKETS;
-            // the six bucket columns are scanned together: one batch of cross-lane moves per step
-            uint32_t v[NUM_BUCKETS], inc[NUM_BUCKETS];
-#pragma unroll
-            for (int b = 0; b < NUM_BUCKETS; b++) { v[b] = valid ? tc[b] : 0u; inc[b] = v[b]; }
-#pragma unroll
-            for (int d = 1; d < WAVE; d <<= 1) {
-                if (c0 + d >= ntile && d >= (int)(ntile - c0)) break;   // no lane of this chunk has a valid lane d below it
-                uint32_t u[NUM_BUCKETS];
-#pragma unroll
-                for (int b = 0; b < NUM_BUCKETS; b++) u[b] = __shfl_up(inc[b], d);
-#pragma unroll
-                for (int b = 0; b < NUM_BUCKETS; b++) inc[b] += lane >= d ? u[b] : 0u;
-            }
-#pragma unroll
-            for (int b = 0; b < NUM_BUCKETS; b++) {
-                if (valid) tc[b] = base[b] + inc[b] - v[b];
-                base[b] += __shfl(inc[b], WAVE - 1);
-            }
-        }
+        // the item's bucket counts for k_scatter (which adds up the counts of the item's earlier tiles itself)
+        if (lane < NUM_BUCKETS) a.stats[par][(size_t)id * STAT_REP].cnt[lane] = cnt[lane];
     }
 }
 
@@ -553,7 +526,37 @@ template <typename T> __global__ __launch_bounds__(256) void k_scatter(BuildArgs
         const uint32_t start = it->start, count = it->count;
         const uint32_t p0 = start + (t - it->tile_base) * TILE;
         const uint32_t pend = min(start + count, p0 + (uint32_t)TILE);
-        if (threadIdx.x < NUM_BUCKETS) run[threadIdx.x] = a.tile_cnt[(size_t)t * NUM_BUCKETS + threadIdx.x];
+        // exclusive offset of (this tile, bucket b) inside the item's slice = shapes of the item in buckets < b
+        // + shapes of bucket b in the item's earlier tiles.  Every workgroup adds those up itself (at most a few
+        // hundred tiles per item) — a serial scan per item in k_select was the longest part of that kernel.
+        {
+            const uint32_t item_id = a.tile_item[par][t];
+            const uint32_t tl = t - it->tile_base;
+            uint32_t part[NUM_BUCKETS];
+#pragma unroll
+            for (int b = 0; b < NUM_BUCKETS; b++) part[b] = 0;
+            const uint32_t* tc = a.tile_cnt + (size_t)it->tile_base * NUM_BUCKETS;
+            for (uint32_t j = threadIdx.x; j < tl; j += 256) {
+#pragma unroll
+                for (int b = 0; b < NUM_BUCKETS; b++) part[b] += tc[(size_t)j * NUM_BUCKETS + b];
+            }
+#pragma unroll
+            for (int b = 0; b < NUM_BUCKETS; b++) {
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) part[b] += __shfl_down(part[b], d);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int b = 0; b < NUM_BUCKETS; b++) wcnt[w][b] = part[b];
+            }
+            __syncthreads();
+            if (threadIdx.x < NUM_BUCKETS) {
+                const uint32_t* ic = a.stats[par][(size_t)item_id * STAT_REP].cnt;
+                uint32_t v = wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+                for (int bb = 0; bb < (int)threadIdx.x; bb++) v += ic[bb];
+                run[threadIdx.x] = v;
+            }
+        }
         __syncthreads();
         for (uint32_t c0 = p0; c0 < pend; c0 += 256) {
             const uint32_t p = c0 + threadIdx.x;
