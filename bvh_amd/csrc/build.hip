@@ -447,13 +447,13 @@ __device__ __forceinline__ uint32_t sah_select(KeyPtr keys, CntPtr cnts, const T
     return nl;
 }
 
-template <typename T> __global__ __launch_bounds__(256) void k_select(BuildArgs<T> a, int level) {
+template <typename T> __device__ void select_role(const BuildArgs<T>& a, int level, uint32_t block, uint32_t nblocks) {
     using Tr = Traits<T>;
     const int slot = lvl_slot(level), par = level & 1;
     const uint32_t nitems = a.ctr[CTR_LEVEL0 + 2 * slot];
     const int lane = lane_id();
-    const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t wave0 = (block * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (nblocks * blockDim.x) >> 6;
     for (uint32_t id = wave0; id < nitems; id += nwaves) {
         const Item<T>* it = &a.big[par][id];
         // merge the STAT_REP replicas the tiles added to (joins are exact, counts are integers): lane j owns keys j, j+64
@@ -504,15 +504,13 @@ template <typename T> __global__ __launch_bounds__(256) void k_select(BuildArgs<
         push_pair<T>(a, level + 1, ni, li, start, nl, AL, CL, heap_child(it->heap, 0u), ri, start + nl, count - nl, AR, CR,
                      heap_child(it->heap, 1u), lane);
 
-        // the item's bucket counts for k_scatter (which adds up the counts of the item's earlier tiles itself)
-        if (lane < NUM_BUCKETS) a.stats[par][(size_t)id * STAT_REP].cnt[lane] = cnt[lane];
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // tier 1 / scatter — stable bucket-major rewrite (bvh_node.rs:250-272)
 // ------------------------------------------------------------------------------------------------
-template <typename T> __global__ __launch_bounds__(256) void k_scatter(BuildArgs<T> a, int level) {
+template <typename T> __device__ void scatter_role(const BuildArgs<T>& a, int level, uint32_t block, uint32_t nblocks) {
     const int slot = lvl_slot(level), par = level & 1;
     const uint32_t ntiles = a.ctr[CTR_LEVEL0 + 2 * slot + 1];
     __shared__ uint32_t run[NUM_BUCKETS];
@@ -521,7 +519,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_scatter(BuildArgs
     const unsigned long long lt = lanemask_lt();
     const uint32_t* src = a.idx[par];
     uint32_t* dst = a.idx[par ^ 1];
-    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (uint32_t t = block; t < ntiles; t += nblocks) {
         const Item<T>* it = &a.big[par][a.tile_item[par][t]];
         const uint32_t start = it->start, count = it->count;
         const uint32_t p0 = start + (t - it->tile_base) * TILE;
@@ -530,32 +528,37 @@ template <typename T> __global__ __launch_bounds__(256) void k_scatter(BuildArgs
         // + shapes of bucket b in the item's earlier tiles.  Every workgroup adds those up itself (at most a few
         // hundred tiles per item) — a serial scan per item in k_select was the longest part of that kernel.
         {
-            const uint32_t item_id = a.tile_item[par][t];
-            const uint32_t tl = t - it->tile_base;
-            uint32_t part[NUM_BUCKETS];
+            const uint32_t tl = t - it->tile_base, ntl = (count + TILE - 1) / TILE;
+            uint32_t before[NUM_BUCKETS], all[NUM_BUCKETS];
 #pragma unroll
-            for (int b = 0; b < NUM_BUCKETS; b++) part[b] = 0;
+            for (int b = 0; b < NUM_BUCKETS; b++) { before[b] = 0; all[b] = 0; }
             const uint32_t* tc = a.tile_cnt + (size_t)it->tile_base * NUM_BUCKETS;
-            for (uint32_t j = threadIdx.x; j < tl; j += 256) {
+            for (uint32_t j = threadIdx.x; j < ntl; j += 256) {
 #pragma unroll
-                for (int b = 0; b < NUM_BUCKETS; b++) part[b] += tc[(size_t)j * NUM_BUCKETS + b];
+                for (int b = 0; b < NUM_BUCKETS; b++) {
+                    const uint32_t v = tc[(size_t)j * NUM_BUCKETS + b];
+                    all[b] += v;
+                    before[b] += j < tl ? v : 0u;
+                }
             }
+            // run[b] = (shapes of the item in buckets < b) + (shapes of bucket b in earlier tiles)
+            uint32_t mine[NUM_BUCKETS];
+            uint32_t acc = 0;
+#pragma unroll
+            for (int b = 0; b < NUM_BUCKETS; b++) { mine[b] = acc + before[b]; acc += all[b]; }
+            // (acc over `all` is a per-thread partial: the sum over threads of (acc_prefix + before) is what we need)
 #pragma unroll
             for (int b = 0; b < NUM_BUCKETS; b++) {
 #pragma unroll
-                for (int d = 32; d > 0; d >>= 1) part[b] += __shfl_down(part[b], d);
+                for (int d = 32; d > 0; d >>= 1) mine[b] += __shfl_down(mine[b], d);
             }
             if (lane == 0) {
 #pragma unroll
-                for (int b = 0; b < NUM_BUCKETS; b++) wcnt[w][b] = part[b];
+                for (int b = 0; b < NUM_BUCKETS; b++) wcnt[w][b] = mine[b];
             }
             __syncthreads();
-            if (threadIdx.x < NUM_BUCKETS) {
-                const uint32_t* ic = a.stats[par][(size_t)item_id * STAT_REP].cnt;
-                uint32_t v = wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
-                for (int bb = 0; bb < (int)threadIdx.x; bb++) v += ic[bb];
-                run[threadIdx.x] = v;
-            }
+            if (threadIdx.x < NUM_BUCKETS)
+                run[threadIdx.x] = wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
         }
         __syncthreads();
         for (uint32_t c0 = p0; c0 < pend; c0 += 256) {
@@ -582,6 +585,14 @@ template <typename T> __global__ __launch_bounds__(256) void k_scatter(BuildArgs
             __syncthreads();
         }
     }
+}
+
+// One launch per level after the binning: the selection (needs the bucket statistics) and the stable scatter (needs
+// only the per-tile bucket counts — NOT the chosen split) are independent, so the first `sel_blocks` workgroups
+// select while the others scatter.
+template <typename T> __global__ __launch_bounds__(256) void k_split(BuildArgs<T> a, int level, uint32_t sel_blocks) {
+    if (blockIdx.x < sel_blocks) select_role<T>(a, level, blockIdx.x, sel_blocks);
+    else scatter_role<T>(a, level, blockIdx.x - sel_blocks, gridDim.x - sel_blocks);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1239,8 +1250,7 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     uint32_t* pin = reinterpret_cast<uint32_t*>(ctx->pinned);
     auto run_level = [&](int L) {
         hipLaunchKernelGGL(k_bin<T>, dim3(tile_grid), dim3(256), 0, st, a, L);
-        hipLaunchKernelGGL(k_select<T>, dim3(sel_grid), dim3(256), 0, st, a, L);
-        hipLaunchKernelGGL(k_scatter<T>, dim3(tile_grid), dim3(256), 0, st, a, L);
+        hipLaunchKernelGGL(k_split<T>, dim3(sel_grid + tile_grid), dim3(256), 0, st, a, L, (uint32_t)sel_grid);
     };
     // Optimistic schedule with no host round trip: enough level-synchronous passes for a balanced
     // tree, then the workgroup tier over everything queued so far, then the wave tier.  ONE readback
