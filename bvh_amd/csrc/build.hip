@@ -27,24 +27,18 @@ namespace bvhgpu {
 
 constexpr int MAXLV = 96;        // counter slots (levels beyond reuse the last two, host-synchronised)
 constexpr int CTR_SMALL = 0;     // u32: number of small items (<= 64 shapes, wave-subtree tier)
-constexpr int CTR_MID = 1;       // u32: number of mid items (65 .. MID_MAX shapes, workgroup tier)
 constexpr int CTR_TICKET = 3;    // u32: k_prep arrival ticket (the last workgroup creates the root item)
 constexpr int CTR_MID2 = 2;      // u32: number of second-mid-tier items (65 .. MidB::MAXN shapes)
-// Workgroup tiers.  A: nodes up to MidA::MAXN shapes, one 512-thread workgroup per node (LDS holds all its
-// AABBs, so one workgroup per CU and only n/MAXN of them): it splits until a child fits tier B and hands it
-// over.  B: nodes up to MidB::MAXN shapes, 256 threads and ~40 KB of LDS, so every CU runs several and the
-// whole chip is busy: it splits down to <= 64-shape children for the wave tier.
+// Workgroup tier: nodes of 65 .. MidB::MAXN shapes, one 256-thread workgroup per node (its AABBs live in ~40 KB of
+// LDS, so every CU runs several): it splits down to <= 64-shape children for the wave tier.  (A second, larger
+// workgroup tier for 1025..4096 shapes existed until the level-synchronous tier got down to ~12 µs per level — below
+// the ~20 µs per level a 4096-shape workgroup needs; see DESIGN.md.)
 template <typename T> struct MidB {
     static constexpr int MAXN = sizeof(T) == 4 ? 1024 : 512;
     static constexpr int THREADS = 256;
     static constexpr int HANDOFF = SMALL_MAX;
 };
-template <typename T> struct MidA {
-    static constexpr int MAXN = sizeof(T) == 4 ? 4096 : 2048;  // shapes one workgroup can hold (LDS: 24/48 B each)
-    static constexpr int THREADS = 512;
-    static constexpr int HANDOFF = MidB<T>::MAXN;
-};
-template <typename T> struct MidCfg { static constexpr int MAXN = MidA<T>::MAXN; };
+template <typename T> struct MidCfg { static constexpr int MAXN = MidB<T>::MAXN; };   // level-tier threshold
 constexpr int STAT_REP = 8;   // global replicas of an item's statistics: tile t adds to replica t % 8, so the ~470 tiles of
                               // the root do not serialise on 78 addresses (k_bin of level 0: 13.4 -> see profiles); the
                               // selection merges the replicas
@@ -72,7 +66,6 @@ template <typename T> struct BuildArgs {
     uint32_t* idx[2];
     uint8_t* bk;
     Item<T>* big[2];
-    Item<T>* mid;
     Item<T>* mid2;
     Item<T>* small;
     ItemStats<T>* stats[2];
@@ -184,12 +177,10 @@ __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, ui
     uint32_t slot = 0, tb = 0;
     const bool is_small = count <= (uint32_t)SMALL_MAX;
     const bool is_mid2 = !is_small && count <= (uint32_t)MidB<T>::MAXN;
-    const bool is_mid = !is_small && !is_mid2 && count <= (uint32_t)MidA<T>::MAXN;
     const uint32_t ntile = (count + TILE - 1) / TILE;
     if (lane == 0) {
         if (is_small) slot = atomicAdd(&a.ctr[CTR_SMALL], 1u);
         else if (is_mid2) slot = atomicAdd(&a.ctr[CTR_MID2], 1u);
-        else if (is_mid) slot = atomicAdd(&a.ctr[CTR_MID], 1u);
         else {
             slot = atomicAdd(&a.ctr[CTR_LEVEL0 + 2 * nslot], 1u);
             tb = atomicAdd(&a.ctr[CTR_LEVEL0 + 2 * nslot + 1], ntile);
@@ -197,13 +188,13 @@ __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, ui
     }
     slot = __shfl(slot, 0);
     tb = __shfl(tb, 0);
-    Item<T>* it = is_small ? &a.small[slot] : (is_mid2 ? &a.mid2[slot] : (is_mid ? &a.mid[slot] : &a.big[npar][slot]));
+    Item<T>* it = is_small ? &a.small[slot] : (is_mid2 ? &a.mid2[slot] : &a.big[npar][slot]);
     if (lane == 0) {
         it->ni = ni; it->parent = parent; it->start = start; it->count = count;
         it->tile_base = tb; it->parity = (uint32_t)npar; it->heap = heap; it->_r1 = 0;
     }
     if (lane < 6) { it->A[lane] = A[lane]; it->C[lane] = C[lane]; }
-    if (!is_small && !is_mid && !is_mid2) {
+    if (!is_small && !is_mid2) {
         for (uint32_t j = lane; j < ntile; j += WAVE) a.tile_item[npar][tb + j] = slot;
         for (int r = 0; r < STAT_REP; r++) init_stats<T>(&a.stats[npar][(size_t)slot * STAT_REP + r], lane);
     }
@@ -219,13 +210,12 @@ __device__ void push_pair(const BuildArgs<T>& a, int next_level, uint32_t parent
     const int nslot = lvl_slot(next_level);
     const int npar = next_level & 1;
     const uint32_t mycount = lane == 0 ? lcount : rcount;
-    const int mykind = mycount <= (uint32_t)SMALL_MAX ? 0 : (mycount <= (uint32_t)MidB<T>::MAXN ? 1 : (mycount <= (uint32_t)MidA<T>::MAXN ? 2 : 3));
+    const int mykind = mycount <= (uint32_t)SMALL_MAX ? 0 : (mycount <= (uint32_t)MidB<T>::MAXN ? 1 : 3);   // wave / workgroup / level tier
     const uint32_t myntile = (mycount + TILE - 1) / TILE;
     uint32_t slot = 0, tb = 0;
     if (lane < 2) {
         if (mykind == 0) slot = atomicAdd(&a.ctr[CTR_SMALL], 1u);
         else if (mykind == 1) slot = atomicAdd(&a.ctr[CTR_MID2], 1u);
-        else if (mykind == 2) slot = atomicAdd(&a.ctr[CTR_MID], 1u);
         else {
             const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(&a.ctr[CTR_LEVEL0 + 2 * nslot]),
                                                      1ull | ((unsigned long long)myntile << 32));
@@ -237,7 +227,7 @@ __device__ void push_pair(const BuildArgs<T>& a, int next_level, uint32_t parent
         const uint32_t cslot = __shfl(slot, side), ctb = __shfl(tb, side);
         const int kind = __shfl(mykind, side);
         const uint32_t ccount = side ? rcount : lcount, ntile = (ccount + TILE - 1) / TILE;
-        Item<T>* it = kind == 0 ? &a.small[cslot] : (kind == 1 ? &a.mid2[cslot] : (kind == 2 ? &a.mid[cslot] : &a.big[npar][cslot]));
+        Item<T>* it = kind == 0 ? &a.small[cslot] : (kind == 1 ? &a.mid2[cslot] : &a.big[npar][cslot]);
         if (lane == 0) {
             it->ni = side ? ri : li; it->parent = parent; it->start = side ? rstart : lstart; it->count = ccount;
             it->tile_base = ctb; it->parity = (uint32_t)npar; it->heap = side ? rheap : lheap; it->_r1 = 0;
@@ -647,13 +637,13 @@ __device__ __forceinline__ uint32_t packed_field(unsigned long long lo, uint32_t
 #ifdef BVH_PROFILE_MID
 __device__ unsigned long long g_mid_prof[8];
 #define MID_T0() long long _t0 = clock64()
-#define MID_T(i) do { long long _t1 = clock64(); if (tid == 0 && blockIdx.x == 0 && TIER_A == (BVH_PROFILE_MID == 1)) { atomicAdd(&g_mid_prof[i], (unsigned long long)(_t1 - _t0)); if (i == 5) atomicAdd(&g_mid_prof[0], 1ull); } _t0 = _t1; } while (0)
+#define MID_T(i) do { long long _t1 = clock64(); if (tid == 0 && blockIdx.x == 0 && true) { atomicAdd(&g_mid_prof[i], (unsigned long long)(_t1 - _t0)); if (i == 5) atomicAdd(&g_mid_prof[0], 1ull); } _t0 = _t1; } while (0)
 #else
 #define MID_T0()
 #define MID_T(i)
 #endif
 
-template <typename T, typename Cfg, bool TIER_A>
+template <typename T, typename Cfg>
 __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t first) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
@@ -671,8 +661,8 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
     __shared__ uint32_t s_whi[MID_THREADS / WAVE];
     __shared__ uint32_t s_nsub;
 
-    const uint32_t n_mid = a.ctr[TIER_A ? CTR_MID : CTR_MID2];
-    const Item<T>* queue = TIER_A ? a.mid : a.mid2;
+    const uint32_t n_mid = a.ctr[CTR_MID2];
+    const Item<T>* queue = a.mid2;
     const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     const unsigned long long lt = lanemask_lt();
 
@@ -1187,7 +1177,6 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
 
     constexpr size_t MID_MAX = (size_t)MidCfg<T>::MAXN;
     const size_t max_big = n / (MID_MAX + 1) + 2;       // simultaneously active nodes with > MID_MAX shapes
-    const size_t max_mid = n / (MidB<T>::MAXN + 1) + 2;  // tier A: nodes with more than MidB::MAXN shapes
     const size_t max_mid2 = n / (SMALL_MAX + 1) + 2;     // tier B: nodes with 65..MidB::MAXN shapes
     const size_t max_tiles = n / TILE + max_big + 2;
     t->aabbs.reserve(n * 6 * sizeof(T));
@@ -1205,7 +1194,6 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
         t->stats[i].reserve(max_big * STAT_REP * sizeof(ItemStats<T>));
         t->tile_item[i].reserve(max_tiles * 4);
     }
-    t->mid.reserve(max_mid * sizeof(Item<T>));
     t->mid2.reserve(max_mid2 * sizeof(Item<T>));
     t->small.reserve((n + 1) * sizeof(Item<T>));
     t->tile_cnt.reserve(max_tiles * NUM_BUCKETS * 4);
@@ -1226,7 +1214,6 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     a.idx[0] = t->idx[0].as<uint32_t>(); a.idx[1] = t->idx[1].as<uint32_t>();
     a.bk = t->bk.as<uint8_t>();
     a.big[0] = t->big[0].as<Item<T>>(); a.big[1] = t->big[1].as<Item<T>>();
-    a.mid = t->mid.as<Item<T>>();
     a.mid2 = t->mid2.as<Item<T>>();
     a.small = t->small.as<Item<T>>();
     a.stats[0] = t->stats[0].as<ItemStats<T>>(); a.stats[1] = t->stats[1].as<ItemStats<T>>();
@@ -1244,7 +1231,6 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
 
     const int tile_grid = (int)std::min<size_t>(max_tiles, 2048);
     const int sel_grid = (int)std::min<size_t>((max_big + 3) / 4, 1024);
-    const int mid_grid = (int)std::min<size_t>(max_mid, (size_t)ctx->n_cu);
     const int mid2_grid = (int)std::min<size_t>(max_mid2, (size_t)ctx->n_cu * 4);
     const int small_grid = (int)std::min<size_t>((n + 3) / 4, (size_t)ctx->n_cu * 8);
     uint32_t* pin = reinterpret_cast<uint32_t*>(ctx->pinned);
@@ -1262,18 +1248,15 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
         if (fixed > MAXLV - 4) fixed = MAXLV - 4;
         for (; level < fixed; level++) run_level(level);
     }
-    uint32_t mid_done = 0, mid2_done = 0, small_done = 0;
+    uint32_t mid2_done = 0, small_done = 0;
     while (true) {
-        if (n > (size_t)MidB<T>::MAXN)
-            hipLaunchKernelGGL((k_mid<T, MidA<T>, true>), dim3(mid_grid), dim3(MidA<T>::THREADS), 0, st, a, mid_done);
         if (n > (size_t)SMALL_MAX)
-            hipLaunchKernelGGL((k_mid<T, MidB<T>, false>), dim3(mid2_grid), dim3(MidB<T>::THREADS), 0, st, a, mid2_done);
+            hipLaunchKernelGGL((k_mid<T, MidB<T>>), dim3(mid2_grid), dim3(MidB<T>::THREADS), 0, st, a, mid2_done);
         hipLaunchKernelGGL(k_small<T>, dim3(small_grid), dim3(256), 0, st, a, small_done);
         if (flatten_after) flatten_tree<T>(t);   // optimistic too: redone if the build turns out to be unfinished
         BVH_HIP(hipMemcpyAsync(pin, a.ctr, ROOTKEY_OFF, hipMemcpyDeviceToHost, st));
         BVH_HIP(hipStreamSynchronize(st));
         BVH_HIP(hipGetLastError());
-        mid_done = pin[CTR_MID];
         mid2_done = pin[CTR_MID2];
         small_done = pin[CTR_SMALL];
         if (n <= (size_t)MID_MAX || pin[CTR_LEVEL0 + 2 * lvl_slot(level)] == 0) break;

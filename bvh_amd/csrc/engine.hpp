@@ -82,8 +82,7 @@ struct bvhgpu_tree {
     bvhgpu::DevBuf idx[2];      // n * u32 ping-pong permutation
     bvhgpu::DevBuf bk;          // n * u8 bucket per position
     bvhgpu::DevBuf big[2];      // Item queues of the level-synchronous tier
-    bvhgpu::DevBuf mid;         // Item queue of workgroup tier A (1025..4096 shapes)
-    bvhgpu::DevBuf mid2;        // Item queue of workgroup tier B (65..1024 shapes)
+    bvhgpu::DevBuf mid2;        // Item queue of the workgroup tier (65..1024 shapes)
     bvhgpu::DevBuf small;       // Item queue of the wave-subtree tier
     bvhgpu::DevBuf stats[2];    // per big item: 6 x (12 keys) + 6 counts
     bvhgpu::DevBuf tile_item[2];
