@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--scene-dist", choices=["bcast", "replicate"], default="bcast",
                     help="N>1: broadcast rank 0's flat scene over RCCL, or rebuild it on every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend for N>1 (nccl == RCCL; gloo only for the one-GPU test of this script)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="test only: every rank uses cuda:0 (needs --backend gloo: RCCL refuses two ranks on one GPU)")
     ap.add_argument("--cpu-sample-rays", type=int, default=1_000_000)
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the traversal kernel from a separate rocprofv3 --pmc pass; default: "
@@ -65,12 +69,19 @@ def main():
     n_gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.one_device:
+        if args.backend != "gloo":
+            raise SystemExit("--one-device needs --backend gloo")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if n_gpus > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
     import bvh_amd
     from bvh_amd import Bvh, Context, FlatBvh, RayBatch, dist as bdist, testbase as tb
@@ -157,6 +168,11 @@ def main():
     # exact visit counters (reference-equivalent loop iterations) for the algorithmic byte count
     stats = tree.traverse_batch(rays, stats=True, fetch=False)[3]
     V, VL, H = stats["visited"], stats["leaf_visits"], stats["hits"]
+    hits_all = H
+    if n_gpus > 1:   # whole-job hit count (untimed): lets a reader check the shards against one process over N*R rays
+        ht = torch.tensor([H], dtype=torch.int64, device=dev)
+        dist.all_reduce(ht, op=dist.ReduceOp.SUM)
+        hits_all = int(ht.item())
     flat_sz = 36 if args.dtype == "f32" else 64
     # per ray  Ray in + V_nav*FlatNode + V_leaf*shape AABB + CSR out 4*(H+1)
     algo_bytes = R * ray_size + (V - VL) * flat_sz + VL * flat_sz + VL * 6 * elem + 4 * (H + R)
@@ -191,6 +207,7 @@ def main():
         },
         "phases_ms": {k: round(v, 4) for k, v in phases.items()},
         "build_levels": bvh.build_levels if builder else None,
+        "hits_all_ranks": int(hits_all),
         "roofline": roofline,
     }
 

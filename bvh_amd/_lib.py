@@ -24,6 +24,11 @@ TRAVERSE_CLOSEST = 8
 TRAVERSE_COHERENT = 16
 TRAVERSE_NEAREST_FIRST = 32
 TRAVERSE_FARTHEST_FIRST = 64
+TRAVERSE_BEST_FIRST = 128
+# `order=` of the batch calls → flags: the child-ordered depth-first iterators and the heap-driven best-first ones
+ORDER_FLAGS = {None: 0, "nearest": TRAVERSE_NEAREST_FIRST, "farthest": TRAVERSE_FARTHEST_FIRST,
+               "nearest_heap": TRAVERSE_NEAREST_FIRST | TRAVERSE_BEST_FIRST,
+               "farthest_heap": TRAVERSE_FARTHEST_FIRST | TRAVERSE_BEST_FIRST}
 
 NODE_F32 = np.dtype([("l_min", "<f4", 3), ("l_max", "<f4", 3), ("r_min", "<f4", 3), ("r_max", "<f4", 3),
                      ("parent", "<u4"), ("l", "<u4"), ("r", "<u4"), ("shape", "<u4")])

@@ -339,7 +339,7 @@ class _TreeBase:
             raise BvhGpuError(_lib.DTYPE_MISMATCH, "ray dtype differs from tree dtype")
         lib = _lib.load()
         flags = (TRAVERSE_T_SLICE if want_t else 0) | (TRAVERSE_STATS if stats else 0) | (TRAVERSE_COHERENT if coherent else 0)
-        flags |= {None: 0, "nearest": TRAVERSE_NEAREST_FIRST, "farthest": TRAVERSE_FARTHEST_FIRST}[order]
+        flags |= _lib.ORDER_FLAGS[order]
         fn = getattr(lib, f"bvhgpu_traverse_{self.sfx}")
         check(fn(self._t, rays._ptr(), rays.n, rays.mem, flags, C.byref(self._hits.h)), self.ctx._h)
         total = C.c_uint64()
@@ -373,7 +373,7 @@ class _TreeBase:
         returns (offsets, indices, isect[total,3] = Intersection{distance,u,v}, stats)"""
         lib = _lib.load()
         flags = TRAVERSE_TRIANGLES | (TRAVERSE_STATS if stats else 0) | (TRAVERSE_COHERENT if coherent else 0)
-        flags |= {None: 0, "nearest": TRAVERSE_NEAREST_FIRST, "farthest": TRAVERSE_FARTHEST_FIRST}[order]
+        flags |= _lib.ORDER_FLAGS[order]
         check(getattr(lib, f"bvhgpu_traverse_{self.sfx}")(self._t, rays._ptr(), rays.n, rays.mem, flags,
                                                            C.byref(self._hits.h)), self.ctx._h)
         total = C.c_uint64()
@@ -395,7 +395,7 @@ class _TreeBase:
         (distance +inf / shape NONE when nothing is hit).  returns (isect[n,3], shape[n], stats)"""
         lib = _lib.load()
         flags = TRAVERSE_CLOSEST | (TRAVERSE_STATS if stats else 0) | (TRAVERSE_COHERENT if coherent else 0)
-        flags |= {None: 0, "nearest": TRAVERSE_NEAREST_FIRST, "farthest": TRAVERSE_FARTHEST_FIRST}[order]
+        flags |= _lib.ORDER_FLAGS[order]
         check(getattr(lib, f"bvhgpu_traverse_{self.sfx}")(self._t, rays._ptr(), rays.n, rays.mem, flags,
                                                            C.byref(self._hits.h)), self.ctx._h)
         st = _lib.TraverseStats()
@@ -427,6 +427,16 @@ class _TreeBase:
         """BoundingHierarchy::nearest_to (bounding_hierarchy.rs:262-336): Option<(&Shape, distance)>."""
         s, d = self.nearest_batch([query], triangles)
         return None if s[0] == NONE else (shapes[int(s[0])], d[0])
+
+    def nearest_traverse(self, ray: "Ray", shapes: Sequence) -> List:
+        """Bvh::nearest_traverse_iterator (bvh_impl.rs:145-151; DistanceTraverseIterator) collected into a list."""
+        _, idx, _, _ = self.traverse_batch(ray._batch, order="nearest_heap")
+        return [shapes[int(i)] for i in idx]
+
+    def farthest_traverse(self, ray: "Ray", shapes: Sequence) -> List:
+        """Bvh::farthest_traverse_iterator (bvh_impl.rs:162-176) collected into a list."""
+        _, idx, _, _ = self.traverse_batch(ray._batch, order="farthest_heap")
+        return [shapes[int(i)] for i in idx]
 
     def nearest_child_traverse(self, ray: "Ray", shapes: Sequence) -> List:
         """Bvh::nearest_child_traverse_iterator (bvh_impl.rs:184-190) collected into a list."""

@@ -114,6 +114,8 @@ int do_traverse(bvhgpu_tree* tree, const typename Traits<T>::Ray* rays, size_t n
             return fail(ctx, BVHGPU_INVALID_ARG, "NEAREST_FIRST and FARTHEST_FIRST are alternatives");
         if (flags & (BVHGPU_TRAVERSE_T_SLICE | BVHGPU_TRAVERSE_STATS))
             return fail(ctx, BVHGPU_INVALID_ARG, "ordered traversal supports the INDICES, TRIANGLES and CLOSEST outputs only");
+    } else if (flags & BVHGPU_TRAVERSE_BEST_FIRST) {
+        return fail(ctx, BVHGPU_INVALID_ARG, "BEST_FIRST needs NEAREST_FIRST or FARTHEST_FIRST");
     }
     if ((flags & BVHGPU_TRAVERSE_TRIANGLES) && (flags & BVHGPU_TRAVERSE_CLOSEST))
         return fail(ctx, BVHGPU_INVALID_ARG, "TRIANGLES and CLOSEST are alternatives");
@@ -697,6 +699,7 @@ void bvhgpu_hits_destroy(bvhgpu_hits* h) {
     h->counts.release(); h->offsets.release(); h->pool.release(); h->pool_t.release();
     h->indices.release(); h->tslice.release(); h->blocksums.release(); h->ctr.release();
     h->isect.release(); h->closest.release(); h->closest_prim.release();
+    h->heap_dist.release(); h->heap_node.release();
     delete h;
 }
 

@@ -108,6 +108,8 @@ struct bvhgpu_hits {
     bvhgpu::DevBuf closest_prim;  // n_rays u32
     bvhgpu::DevBuf blocksums;
     bvhgpu::DevBuf ctr;      // [0] pool count (u64) [1] visited [2] leaf_visits [3] device_steps [4] ray ticket
+    bvhgpu::DevBuf heap_dist, heap_node;  // best-first traversal: the part of the lanes' heaps that does not fit in LDS
+    uint32_t heap_cap = 48;  // ... entries per lane (doubles when a batch overflows it)
     size_t pool_cap = 0;
     bool ctr_clean = false;  // the counters were zeroed behind the previous call's readback
 };

@@ -356,6 +356,138 @@ __global__ __launch_bounds__(256) void k_traverse_ordered(const typename Traits<
 }
 
 // ------------------------------------------------------------------------------------------------
+// Best-first traversal: Bvh::nearest_traverse_iterator / farthest_traverse_iterator (bvh_impl.rs:145-176) =
+// DistanceTraverseIterator<ASCENDING> (bvh/distance_traverse.rs:40-158) collected per ray.  A max-heap of
+// (dist, node) drives the walk: pop the leader; a leaf yields its shape (:151-155); an inner node tests its left,
+// then its right child box with intersection_slice_for_aabb and pushes every hit child with dist = -entry
+// (ascending) or exit (descending) (:99-131).  The heap is Rust's std BinaryHeap and equal distances come out
+// in whatever order ITS sifts leave, so the same sifts run here: push = append + sift_up, pop = move the last
+// element to the root, walk the hole down along the greater child (the right one when left <= right) to the
+// bottom, then sift_up (alloc::collections::binary_heap, sift_down_to_bottom).
+// One ray per lane at a time, workgroups stride over the batch.  A lane's heap: entries [0, HEAP_LDS) in LDS
+// (entry-major: conflict-free), the rest in a global workspace (entry-major over all resident lanes: coalesced
+// when lanes touch the same entry).  The frontier of a best-first walk is small (peak 10 on the 120k-triangle
+// scene, 15 on the atrium stand-in), so the global part is touched only by unusual rays; if even that
+// overflows the host doubles it and replays.
+// ------------------------------------------------------------------------------------------------
+constexpr int HEAP_LDS = 16;
+constexpr uint32_t HEAP_OVERFLOW_BIT = 2u;
+
+template <typename T> struct LaneHeap {
+    T (*sd)[256];
+    uint32_t (*sn)[256];
+    T* gd;
+    uint32_t* gn;
+    size_t G, g;
+    uint32_t tid;
+    __device__ __forceinline__ T dist(uint32_t e) const { return e < HEAP_LDS ? sd[e][tid] : gd[(size_t)(e - HEAP_LDS) * G + g]; }
+    __device__ __forceinline__ uint32_t node(uint32_t e) const { return e < HEAP_LDS ? sn[e][tid] : gn[(size_t)(e - HEAP_LDS) * G + g]; }
+    __device__ __forceinline__ void put(uint32_t e, T d, uint32_t n) {
+        if (e < HEAP_LDS) { sd[e][tid] = d; sn[e][tid] = n; }
+        else { gd[(size_t)(e - HEAP_LDS) * G + g] = d; gn[(size_t)(e - HEAP_LDS) * G + g] = n; }
+    }
+    // BinaryHeap::sift_up(0, pos) with the element held in registers (the std's Hole)
+    __device__ __forceinline__ void sift_up(uint32_t pos, T d, uint32_t n) {
+        while (pos > 0) {
+            const uint32_t parent = (pos - 1) >> 1;
+            const T pd = dist(parent);
+            if (d <= pd) break;
+            put(pos, pd, node(parent));
+            pos = parent;
+        }
+        put(pos, d, n);
+    }
+};
+
+template <typename T, int MODE, bool ASCENDING>
+__global__ __launch_bounds__(256) void k_traverse_heap(const typename Traits<T>::Node* __restrict__ nodes, uint32_t n_nodes,
+                                                       const T* __restrict__ shape_aabbs,
+                                                       const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_rays,
+                                                       WalkOut<T> w, T* __restrict__ heap_dist, uint32_t* __restrict__ heap_node,
+                                                       uint32_t heap_cap, uint32_t* __restrict__ overflow) {
+    __shared__ T s_dist[HEAP_LDS][256];
+    __shared__ uint32_t s_node[HEAP_LDS][256];
+    const int lane = lane_id();
+    const unsigned long long lt = lanemask_lt();
+    LaneHeap<T> hp;
+    hp.sd = s_dist; hp.sn = s_node; hp.gd = heap_dist; hp.gn = heap_node;
+    hp.G = (size_t)gridDim.x * 256; hp.g = (size_t)blockIdx.x * 256 + threadIdx.x; hp.tid = threadIdx.x;
+    const uint32_t cap = HEAP_LDS + heap_cap;
+    PoolCursor pc;
+    bool ovf = false;
+    LaneRay<T, MODE> ray;
+    for (size_t base = (size_t)blockIdx.x * 256; base < n_rays; base += hp.G) {   // workgroup-uniform
+        const size_t r = base + threadIdx.x;
+        const bool active = r < n_rays;
+        ray.clear();
+        if (active) ray.load(rays, (uint32_t)r);
+        uint32_t len = 0;
+        if (active && n_nodes) {   // iter_initially_has_node (iter.rs:164-182), then add_to_heap(T::zero(), 0) (:75-78)
+            bool has_node = true;
+            const uint32_t rs = nodes[0].shape;
+            if (rs != NONE) {
+                const T* sb = shape_aabbs + 6 * (size_t)rs;
+                const T mn[3] = {sb[0], sb[1], sb[2]}, mx[3] = {sb[3], sb[4], sb[5]};
+                T t0, t1;
+                has_node = slab_hit<T>(ray.o, ray.inv, mn, mx, t0, t1);
+            }
+            if (has_node) { hp.put(0, ASCENDING ? -(T)0 : (T)0, 0u); len = 1; }
+        }
+        while (true) {
+            const bool run = len > 0;
+            if (!__any(run)) break;
+            bool rec = false;
+            uint32_t shape = NONE;
+            if (run) {
+                // BinaryHeap::pop
+                len--;
+                const T last_d = hp.dist(len);
+                uint32_t node_index = hp.node(len);
+                if (len > 0) {
+                    const uint32_t last_n = node_index;
+                    node_index = hp.node(0);
+                    uint32_t pos = 0, child = 1;
+                    while (child + 1 < len) {            // child <= end.saturating_sub(2)
+                        T cd = hp.dist(child);
+                        const T cr = hp.dist(child + 1);
+                        if (cd <= cr) { child++; cd = cr; }
+                        hp.put(pos, cd, hp.node(child));
+                        pos = child;
+                        child = 2 * pos + 1;
+                    }
+                    if (child == len - 1) { hp.put(pos, hp.dist(child), hp.node(child)); pos = child; }
+                    hp.sift_up(pos, last_d, last_n);
+                }
+                // unpack_node (:82-97)
+                const typename Traits<T>::Node* nd = nodes + node_index;
+                const uint32_t ns = nd->shape;
+                if (ns != NONE) {
+                    rec = true; shape = ns;
+                } else {
+                    T lmn[3], lmx[3], rmn[3], rmx[3];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { lmn[k] = nd->l_min[k]; lmx[k] = nd->l_max[k]; rmn[k] = nd->r_min[k]; rmx[k] = nd->r_max[k]; }
+                    const uint32_t li = nd->l, ri = nd->r;
+                    T l0, l1, r0, r1;
+                    const bool lh = slab_hit<T>(ray.o, ray.inv, lmn, lmx, l0, l1);   // slice is Some ⇔ hit: (max(tmin,0), tmax)
+                    const bool rh = slab_hit<T>(ray.o, ray.inv, rmn, rmx, r0, r1);
+                    if (len + (lh ? 1u : 0u) + (rh ? 1u : 0u) > cap) {
+                        ovf = true; len = 0;             // the host grows the workspace and replays the batch
+                    } else {
+                        if (lh) { hp.sift_up(len, ASCENDING ? -l0 : l1, li); len++; }   // BinaryHeap::push
+                        if (rh) { hp.sift_up(len, ASCENDING ? -r0 : r1, ri); len++; }
+                    }
+                }
+            }
+            report<T, MODE>(rec, shape, (T)0, (T)0, ray, w, pc, lane, lt);
+        }
+        if (active) ray.retire(w);
+    }
+    if (ovf) atomicOr(overflow, HEAP_OVERFLOW_BIT);
+    walk_epilogue<T, MODE>(w, pc, lane, false, 0, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS-resident top of the tree.  On the 120k-triangle scene 72 % of all box tests touch the first 11
 // levels of the tree (2047 entries) and the vector L1 — one tag lookup per lane per 16-byte load for
 // these scattered reads — is the unit that saturates (measured: ~1 lane-access per clock per CU).  A
@@ -696,10 +828,23 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
     w.counts = nullptr; w.pool = nullptr; w.pool_v = nullptr; w.pool_cap = 0; w.ctr = ctr;
     w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr;
 
-    uint32_t* ovf_flag = reinterpret_cast<uint32_t*>(ctr + 7);   // ordered walk: iterator stack overflow
+    uint32_t* ovf_flag = reinterpret_cast<uint32_t*>(ctr + 7);   // ordered walk: iterator stack (bit 0) / heap workspace (bit 1) overflow
+    const bool best_first = ordered && (flags & BVHGPU_TRAVERSE_BEST_FIRST) != 0;
+    const unsigned heap_grid = (unsigned)std::min<size_t>((n_rays + 255) / 256, (size_t)ctx->n_cu * 4);
     auto launch_ordered = [&](auto mode_tag, auto asc_tag) {
         constexpr int M = decltype(mode_tag)::value;
         constexpr bool A = decltype(asc_tag)::value;
+        if (best_first) {   // DistanceTraverseIterator
+            const size_t lanes = (size_t)heap_grid * 256;
+            if (lanes * h->heap_cap * (sizeof(T) + 4) > ((size_t)16 << 30))
+                throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
+            h->heap_dist.reserve(lanes * h->heap_cap * sizeof(T));
+            h->heap_node.reserve(lanes * h->heap_cap * 4);
+            hipLaunchKernelGGL((k_traverse_heap<T, M, A>), dim3(heap_grid), dim3(256), 0, st,
+                               t->nodes.as<typename Traits<T>::Node>(), (uint32_t)t->n_nodes, t->aabbs.as<T>(), rays_dev,
+                               (uint32_t)n_rays, w, h->heap_dist.as<T>(), h->heap_node.as<uint32_t>(), h->heap_cap, ovf_flag);
+            return;
+        }
         hipLaunchKernelGGL((k_traverse_ordered<T, M, A>), dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st,
                            t->nodes.as<typename Traits<T>::Node>(), (uint32_t)t->n_nodes, t->aabbs.as<T>(), rays_dev,
                            (uint32_t)n_rays, w, ovf_flag);
@@ -734,17 +879,21 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
         h->closest_prim.reserve(std::max<size_t>(n_rays, 1) * 4);
         if (n_rays == 0) return;
         w.closest = h->closest.as<T>(); w.closest_prim = h->closest_prim.as<uint32_t>();
-        if (!h->ctr_clean) BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));
-        h->ctr_clean = false;
-        if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
-        DISPATCH_WALK();
-        if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
-        BVH_HIP(hipMemcpyAsync(pin, ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));   // for the next call, behind the readback
-        BVH_HIP(hipStreamSynchronize(st));
-        h->ctr_clean = true;
-        BVH_HIP(hipGetLastError());
-        if (ordered && (pin[7] & 0xFFFFFFFFull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
+        for (;;) {
+            if (!h->ctr_clean) BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));
+            h->ctr_clean = false;
+            if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
+            DISPATCH_WALK();
+            if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
+            BVH_HIP(hipMemcpyAsync(pin, ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));   // for the next call, behind the readback
+            BVH_HIP(hipStreamSynchronize(st));
+            h->ctr_clean = true;
+            BVH_HIP(hipGetLastError());
+            if (best_first && (pin[7] & HEAP_OVERFLOW_BIT)) { h->heap_cap *= 2; continue; }   // a lane's heap outgrew the workspace
+            break;
+        }
+        if (ordered && (pin[7] & 1ull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
         if (stats) {
             const bool one_to_one = t->unfolded || t->n == 1;
             h->stats.hits = pin[5];
@@ -767,7 +916,7 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
         BVH_HIP(hipStreamSynchronize(st));
         return;
     }
-    for (int attempt = 0; attempt < 2; attempt++) {
+    for (int attempt = 0; attempt < (best_first ? 24 : 2); attempt++) {
         h->pool.reserve(h->pool_cap * sizeof(HitRec));
         h->indices.reserve(h->pool_cap * 4);
         if (nv) {
@@ -812,7 +961,8 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
         BVH_HIP(hipStreamSynchronize(st));
         h->ctr_clean = true;
         BVH_HIP(hipGetLastError());
-        if (ordered && (pin[7] & 0xFFFFFFFFull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
+        if (best_first && (pin[7] & HEAP_OVERFLOW_BIT)) { h->heap_cap *= 2; continue; }   // a lane's heap outgrew the workspace
+        if (ordered && (pin[7] & 1ull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
         const unsigned long long used = pin[0];   // pool slots taken (whole chunks)
         const unsigned long long total = pin[3];  // sum of the per-ray counts = number of hits
         if (used < total) throw HipFail{hipErrorUnknown, "hit pool / count scan mismatch", __LINE__};

@@ -62,6 +62,10 @@ typedef enum { BVHGPU_HOST = 0, BVHGPU_DEVICE = 1 } bvhgpu_mem;
 #define BVHGPU_TRAVERSE_NEAREST_FIRST 32u  /* per-ray order of Bvh::nearest_child_traverse_iterator (bvh_impl.rs:184-190,
                                               child_distance_traverse.rs) instead of flat-array order */
 #define BVHGPU_TRAVERSE_FARTHEST_FIRST 64u /* ... of Bvh::farthest_child_traverse_iterator (bvh_impl.rs:206-212) */
+#define BVHGPU_TRAVERSE_BEST_FIRST 128u     /* with NEAREST_FIRST / FARTHEST_FIRST: the per-ray order of Bvh::nearest_traverse_iterator /
+                                              farthest_traverse_iterator (bvh_impl.rs:145-176) = DistanceTraverseIterator
+                                              (distance_traverse.rs:40-158), a best-first walk driven by a BinaryHeap, instead of
+                                              the child-ordered depth-first iterator */
 #define BVHGPU_TRAVERSE_COHERENT 16u /* hint: neighbouring rays are similar (primary rays): walk one ray per lane in lock-step */
 
 /* ---- POD layouts (little-endian, natural alignment, no packing pragmas) ---- */

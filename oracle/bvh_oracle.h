@@ -106,6 +106,9 @@ void orc_aligned_boxes(float *aabbs /* 21*6 */);
                               const T *points, size_t n, uint32_t *out_shape, T *out_dist);               \
     uint64_t orc_traverse_child_ordered_##S(const NODE *nodes, size_t n_nodes, const T *shape_aabbs, const RAY *rays, \
                                             size_t n_rays, int ascending, uint32_t *offsets, uint32_t *indices, uint64_t cap); \
+    uint64_t orc_traverse_distance_##S(const NODE *nodes, size_t n_nodes, const T *shape_aabbs, const RAY *rays, \
+                                       size_t n_rays, int ascending, uint32_t *offsets, uint32_t *indices, uint64_t cap, \
+                                       uint32_t *heap_peak);                                               \
     void orc_triangle_stage_##S(const T *tris, const RAY *rays, size_t n_rays, const uint32_t *offsets,  \
                                 const uint32_t *indices, T *isect, T *closest, uint32_t *closest_prim);  \
     T orc_surface_area_##S(const T box[6]);                            /* aabb_impl.rs:551-554 */\

@@ -317,6 +317,26 @@ def traverse_child_ordered(nodes, shape_aabbs, rays, ascending: bool = True):
     return offsets, indices
 
 
+def traverse_distance(nodes, shape_aabbs, rays, ascending: bool = True, want_peak: bool = False):
+    """Bvh::nearest_traverse_iterator / farthest_traverse_iterator (DistanceTraverseIterator, BinaryHeap driven)
+    collected per ray → (offsets, indices[, largest heap length])"""
+    s = "f32" if nodes.dtype == NODE_F32 else "f64"
+    ft = _types(s)[0]
+    sa = np.ascontiguousarray(shape_aabbs, dtype=ft).reshape(-1, 6)
+    rays = np.ascontiguousarray(rays)
+    nr = len(rays)
+    offsets = np.zeros(nr + 1, dtype=np.uint32)
+    fn = getattr(lib(), f"orc_traverse_distance_{s}")
+    fn.restype = C.c_uint64
+    peak = C.c_uint32(0)
+    total = fn(_p(nodes), C.c_size_t(len(nodes)), _p(sa), _p(rays), C.c_size_t(nr), C.c_int(int(ascending)), _p(offsets),
+               None, C.c_uint64(0), C.byref(peak))
+    indices = np.zeros(total, dtype=np.uint32)
+    fn(_p(nodes), C.c_size_t(len(nodes)), _p(sa), _p(rays), C.c_size_t(nr), C.c_int(int(ascending)), _p(offsets),
+       _p(indices), C.c_uint64(total), C.byref(peak))
+    return (offsets, indices, int(peak.value)) if want_peak else (offsets, indices)
+
+
 def check_tree(nodes, aabbs) -> int:
     s = "f32" if nodes.dtype == NODE_F32 else "f64"
     ft = _types(s)[0]

@@ -400,3 +400,71 @@ def traverse_child_ordered(nodes, shape_aabbs, ray, ascending=True):
             visit(int(c))
     visit(0)
     return out
+
+
+class RustBinaryHeap:
+    """alloc::collections::BinaryHeap (Rust std) written with swaps instead of the std's moving hole — the two
+    leave the same array behind.  Max-heap on `key`; ties keep whatever the sifts leave (that IS the order
+    DistanceTraverseIterator yields equal-distance nodes in)."""
+
+    def __init__(self):
+        self.d = []
+
+    def __len__(self):
+        return len(self.d)
+
+    def _sift_up(self, pos):
+        d = self.d
+        while pos > 0:
+            parent = (pos - 1) // 2
+            if d[pos][0] <= d[parent][0]:
+                break
+            d[pos], d[parent] = d[parent], d[pos]
+            pos = parent
+
+    def push(self, key, val):
+        self.d.append((key, val))
+        self._sift_up(len(self.d) - 1)
+
+    def pop(self):
+        d = self.d
+        item = d.pop()
+        if not d:
+            return item
+        item, d[0] = d[0], item          # the former last element now sits at the root
+        end, pos = len(d), 0
+        while 2 * pos + 2 < end:         # two children: follow the greater one, the right one on ties
+            child = 2 * pos + 1
+            if d[child][0] <= d[child + 1][0]:
+                child += 1
+            d[pos], d[child] = d[child], d[pos]
+            pos = child
+        if 2 * pos + 1 == end - 1:       # a lone left child at the bottom
+            d[pos], d[end - 1] = d[end - 1], d[pos]
+            pos = end - 1
+        self._sift_up(pos)
+        return item
+
+
+def traverse_distance(nodes, shape_aabbs, ray, ascending=True):
+    """DistanceTraverseIterator (distance_traverse.rs:40-158): best-first over the BvhNode array."""
+    out = []
+    if len(nodes) == 0:
+        return out
+    if nodes[0]["shape"] != 0xFFFFFFFF and not ray_hit(ray, shape_aabbs[nodes[0]["shape"]]):
+        return out
+    ft = np.asarray(ray[0]).dtype.type
+    heap = RustBinaryHeap()
+    heap.push(-ft(0) if ascending else ft(0), 0)
+    while len(heap):
+        _, ni = heap.pop()
+        nd = nodes[ni]
+        if nd["shape"] != 0xFFFFFFFF:
+            out.append(int(nd["shape"]))
+            continue
+        for child, lo, hi in ((nd["l"], nd["l_min"], nd["l_max"]), (nd["r"], nd["r_min"], nd["r_max"])):
+            sl = ray_slice(ray, list(lo) + list(hi))
+            if sl is None:
+                continue
+            heap.push(-sl[0] if ascending else sl[1], int(child))
+    return out

@@ -48,7 +48,8 @@ def test_library_contains_gfx950_code_object(built):
                           f"--input={built.SO_PATH}"], capture_output=True, text=True)
     blob = open(built.SO_PATH, "rb").read()
     assert b"gfx950" in blob
-    for kern in (b"k_traverse", b"k_small", b"k_bin", b"k_select", b"k_scatter", b"k_flatten", b"k_gen_rays"):
+    for kern in (b"k_traverse", b"k_traverse_lds", b"k_traverse_ordered", b"k_traverse_heap", b"k_prep", b"k_bin", b"k_split", b"k_mid",
+                 b"k_small", b"k_flatten", b"k_nearest", b"k_gen_rays"):
         assert kern in blob, kern
 
 

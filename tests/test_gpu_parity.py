@@ -623,6 +623,107 @@ def test_ordered_traversal_matches_iterator_restatement(eng, orc, dtype):
     assert "32" in str(e.value)
 
 
+def test_best_first_traversal_reference_known_answers(eng):
+    """distance_traverse.rs tests on the engine: golden hit sets of the 21 aligned boxes with monotone entry distances
+    (:188-262), the empty tree (:270-281), single-node trees (bvh_impl.rs:667-690), test_overlapping_child_order (:295-322)."""
+    from bvh_amd import testbase as tb
+    shapes = tb.generate_aligned_boxes()
+    flat = eng.Bvh.build(shapes).flatten()
+    for case in GOLD["aligned_boxes"]["rays"]:
+        ray = eng.Ray(case["origin"], case["direction"])
+        near = flat.nearest_traverse(ray, shapes)
+        far = flat.farthest_traverse(ray, shapes)
+        assert sorted(s.id for s in near) == sorted(case["hit_ids"]) == sorted(s.id for s in far)
+        dn = [ray.intersection_slice_for_aabb(s.aabb())[0] for s in near]
+        df = [ray.intersection_slice_for_aabb(s.aabb())[0] for s in far]
+        assert dn == sorted(dn) and df == sorted(df, reverse=True)
+    empty = eng.Bvh.build([]).flatten()
+    assert empty.nearest_traverse(eng.Ray([0, 0, 0], [1, 0, 0]), []) == []
+    assert empty.farthest_traverse(eng.Ray([0, 0, 0], [1, 0, 0]), []) == []
+    one = [tb.UnitBox(0, np.array([0.0, 0.0, 0.0], np.float32))]
+    f1 = eng.Bvh.build(one).flatten()
+    assert f1.nearest_traverse(eng.Ray([0, 2, 0], [1, 0, 0]), one) == []
+    assert len(f1.nearest_traverse(eng.Ray([-5, 0, 0], [1, 0, 0]), one)) == 1
+    ov = np.array([[-0.33333334, -5000.3335, -5000.3335, 1.3333334, 0.33333334, 0.33333334],
+                   [-5000.3335, -5000.3335, -5000.3335, 0.33333334, 0.33333334, -4998.6665],
+                   [-5000.3335, -5000.3335, -5000.3335, 0.33333334, 0.33333334, 5000.3335]], np.float32)
+    fo = eng.Bvh.from_aabbs(ov).flatten()
+    ray = eng.Ray([-5000.0, -5000.0, -5000.0], [1, 0, 0])
+    _, idx, _, _ = fo.traverse_batch(ray._batch, order="nearest_heap")
+    assert sorted(idx.tolist()) == [0, 1, 2]
+    d = [ray.intersection_slice_for_aabb(eng.Aabb(ov[i, :3], ov[i, 3:]))[0] for i in idx]
+    assert d == sorted(d)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_best_first_traversal_matches_iterator_restatement(eng, orc, dtype):
+    """CSR in the order of Bvh::nearest_traverse_iterator / farthest_traverse_iterator (DistanceTraverseIterator: the
+    std BinaryHeap's sifts decide the order of equal distances) against the oracle's restatement: cube scene (more rays
+    than resident lanes: workgroups stride), clustered integer boxes with axis-parallel / in-plane rays (many ties),
+    tiny trees, the triangle stage and the closest hit in that order, and a scene whose frontier (1000+ entries)
+    outgrows the LDS part of the heap AND the first global workspace (grow + replay)."""
+    from bvh_amd import testbase as tb
+    rng = np.random.default_rng(37)
+    tris32, aabbs32 = tb.create_n_cubes(2000)
+    tris, aabbs = tris32.astype(dtype), aabbs32.astype(dtype)
+    centres = tris.reshape(2000, 36, 3).mean(axis=1)
+    n = 300_000
+    o = rng.uniform(-1e5, 1e5, size=(n, 3)).astype(dtype)
+    d = (centres[rng.integers(0, 2000, size=n)] + rng.uniform(-0.6, 0.6, size=(n, 3)) - o).astype(dtype)
+    d[:2000] = rng.normal(size=(2000, 3))
+    rays = orc.make_rays(o, d, dtype)
+    flat = eng.Bvh.from_aabbs(aabbs).flatten()
+    flat.set_triangles(tris)
+    onodes = orc.build(aabbs).nodes
+    foff, fidx, _, _ = flat.traverse_batch(_rb(eng, rays))
+    for order, asc in (("nearest_heap", True), ("farthest_heap", False)):
+        off, idx, _, _ = flat.traverse_batch(_rb(eng, rays), order=order)
+        ooff, oidx = orc.traverse_distance(onodes, aabbs, rays, asc)
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+        assert np.array_equal(off, foff) and not np.array_equal(idx, fidx)      # same sets per ray, another order
+        off2, idx2, isect, _ = flat.intersect_triangles(_rb(eng, rays), order=order)
+        oisect, oclosest, oprim = orc.triangle_stage(tris, rays, ooff, oidx)
+        assert np.array_equal(idx2, oidx) and isect.tobytes() == oisect.tobytes()
+        cl, prim, _ = flat.closest_hits(_rb(eng, rays), order=order)
+        assert cl.tobytes() == oclosest.tobytes() and np.array_equal(prim, oprim)
+    m = 5000
+    lo = rng.integers(-30, 30, size=(m, 3)).astype(dtype); ext = rng.integers(0, 4, size=(m, 3)).astype(dtype)
+    boxes = np.concatenate([lo, lo + ext], axis=1)
+    o2 = np.round(rng.uniform(-35, 35, size=(3000, 3))).astype(dtype)
+    d2 = rng.integers(-1, 2, size=(3000, 3)).astype(dtype); d2[np.all(d2 == 0, axis=1)] = [0, 0, 1]
+    rays2 = orc.make_rays(o2, d2, dtype)
+    for k in (m, 3, 2, 1):
+        b = eng.Bvh.from_aabbs(boxes[:k]).flatten()
+        on = orc.build(boxes[:k]).nodes
+        for order, asc in (("nearest_heap", True), ("farthest_heap", False)):
+            off, idx, _, _ = b.traverse_batch(_rb(eng, rays2), order=order)
+            ooff, oidx = orc.traverse_distance(on, boxes[:k], rays2, asc)
+            assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+    # every box contains the origin: all entry distances tie at 0 and the farthest-first frontier passes 1000 entries
+    q = 3000
+    c = (rng.uniform(-1, 1, size=(q, 3)) * 0.1).astype(dtype)
+    hw = rng.uniform(1, 5, size=(q, 1)).astype(dtype)
+    nest = np.concatenate([c - hw, c + hw], axis=1).astype(dtype)
+    r3 = orc.make_rays(np.zeros((70, 3), dtype), rng.normal(size=(70, 3)).astype(dtype), dtype)
+    nb = eng.Bvh.from_aabbs(nest).flatten()
+    nn = orc.build(nest).nodes
+    for order, asc in (("nearest_heap", True), ("farthest_heap", False)):
+        ooff, oidx, peak = orc.traverse_distance(nn, nest, r3, asc, want_peak=True)
+        off, idx, _, _ = nb.traverse_batch(_rb(eng, r3), order=order)
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+        if not asc:
+            assert peak > 64
+    # the depth that overflows the child iterator's fixed stack is no limit for the heap
+    p = 42
+    x = 8.0 ** np.arange(p, dtype=np.float64)
+    deep = np.stack([x, np.zeros(p), np.zeros(p), x * 1.5, np.ones(p), np.ones(p)], axis=1)
+    along = orc.make_rays(np.array([[-1, 0.25, 0.25]], np.float64), np.array([[1, 0, 0]], np.float64), np.float64)
+    db = eng.Bvh.from_aabbs(deep).flatten()
+    off, idx, _, _ = db.traverse_batch(_rb(eng, along), order="nearest_heap")
+    ooff, oidx = orc.traverse_distance(orc.build(deep).nodes, deep, along, True)
+    assert np.array_equal(idx, oidx) and len(idx) == p
+
+
 def test_parity_1_2m_triangles(eng, orc):
     """ten times the BASELINE scene (create_n_cubes(100 000) = 1.2 M triangles): more level-synchronous passes,
     many tier-A/B items, multi-chunk tile-offset scans — node, flat and CSR arrays byte-identical to the oracle."""
@@ -725,6 +826,10 @@ def test_fuzz_all_queries(eng, orc, seed):
             noff, nidx, _, _ = flat.traverse_batch(rb, order=order)
             qoff, qidx = orc.traverse_child_ordered(ot.nodes, aabbs, rays, asc)
             assert np.array_equal(noff, qoff) and np.array_equal(nidx, qidx)
+    for order, asc in (("nearest_heap", True), ("farthest_heap", False)):
+        noff, nidx, _, _ = flat.traverse_batch(rb, order=order)
+        qoff, qidx = orc.traverse_distance(ot.nodes, aabbs, rays, asc)
+        assert np.array_equal(noff, qoff) and np.array_equal(nidx, qidx)
     pts = rng.uniform(-60, 60, size=(800, 3)).astype(dtype)
     for use_tris in (False, True):
         s_, d_ = flat.nearest_batch(pts, triangles=use_tris)

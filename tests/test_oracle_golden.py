@@ -420,3 +420,68 @@ def test_ordered_iterator_restatements_agree_and_match_golden_sets():
             assert pyref.traverse_child_ordered(tt.nodes, ab, (rays[i]["o"], rays[i]["d"], rays[i]["inv"]), asc) == \
                 idx[off[i]:off[i + 1]].tolist()
             assert sorted(idx[off[i]:off[i + 1]]) == sorted(fidx[foff[i]:foff[i + 1]])
+
+
+def test_distance_iterator_restatements_agree_and_match_reference_tests():
+    """DistanceTraverseIterator (distance_traverse.rs): oracle (C, std BinaryHeap restated with the moving hole) vs
+    pyref (swap-based heap), both directions.  The reference's own tests for it: golden hit sets on the 21 aligned
+    boxes with monotone entry / exit distances (:188-217, rays :224-262), the empty tree (:270-281), the single-node
+    trees (bvh_impl.rs:667-690) and the three overlapping boxes whose nearest order must be sorted (:295-322)."""
+    from oracle import pyref
+    aabbs = orc.aligned_boxes()
+    t = orc.build(aabbs)
+    for case in GOLD["aligned_boxes"]["rays"]:
+        rays = orc.make_rays([case["origin"]], [case["direction"]])
+        r3 = (rays[0]["o"], rays[0]["d"], rays[0]["inv"])
+        for asc in (True, False):
+            off, idx = orc.traverse_distance(t.nodes, aabbs, rays, asc)
+            assert sorted(int(i) - 10 for i in idx) == sorted(case["hit_ids"])
+            d = [orc.ray_slice(rays[0], aabbs[i])[0] for i in idx]       # the test compares ENTRY distances both ways (:199-207)
+            assert d == sorted(d, reverse=not asc)
+            assert pyref.traverse_distance(t.nodes, aabbs, r3, asc) == idx.tolist()
+    # empty tree: both iterators are empty
+    e = orc.build(np.zeros((0, 6), np.float32))
+    rays = orc.make_rays([[0, 0, 0]], [[1, 0, 0]])
+    for asc in (True, False):
+        off, idx = orc.traverse_distance(e.nodes, np.zeros((0, 6), np.float32), rays, asc)
+        assert off.tolist() == [0, 0] and len(idx) == 0
+    # one shape: the root leaf is pre-tested with the shape's AABB (bvh_impl.rs:667-690)
+    one = np.array([[-1, -1, -1, 1, 1, 1]], np.float32) + np.array([0, 0, 0, 0, 0, 0], np.float32)
+    t1 = orc.build(one)
+    miss = orc.make_rays([[0, 2, 0]], [[1, 0, 0]])
+    hit = orc.make_rays([[-5, 0, 0]], [[1, 0, 0]])
+    assert len(orc.traverse_distance(t1.nodes, one, miss)[1]) == 0
+    assert orc.traverse_distance(t1.nodes, one, hit)[1].tolist() == [0]
+    # test_overlapping_child_order (:295-322)
+    ov = np.array([[-0.33333334, -5000.3335, -5000.3335, 1.3333334, 0.33333334, 0.33333334],
+                   [-5000.3335, -5000.3335, -5000.3335, 0.33333334, 0.33333334, -4998.6665],
+                   [-5000.3335, -5000.3335, -5000.3335, 0.33333334, 0.33333334, 5000.3335]], np.float32)
+    to = orc.build(ov)
+    ray = orc.make_rays([[-5000.0, -5000.0, -5000.0]], [[1, 0, 0]])
+    off, idx = orc.traverse_distance(to.nodes, ov, ray, True)
+    assert sorted(idx.tolist()) == [0, 1, 2]
+    d = [orc.ray_slice(ray[0], ov[i])[0] for i in idx]
+    assert d == sorted(d)
+    # random scene, rays aimed at cubes: same sets as FlatBvh::traverse, two restatements agree on the order
+    tris, ab = orc.create_n_cubes(150)
+    tt = orc.build(ab)
+    rng = np.random.default_rng(5)
+    c = tris.reshape(150, 36, 3).mean(axis=1)
+    o = rng.uniform(-1e5, 1e5, size=(200, 3)).astype(np.float32)
+    rays = orc.make_rays(o, (c[rng.integers(0, 150, 200)] - o).astype(np.float32))
+    foff, fidx, _, _ = orc.traverse_flat(orc.flatten(tt.nodes), ab, rays)
+    for asc in (True, False):
+        off, idx, peak = orc.traverse_distance(tt.nodes, ab, rays, asc, want_peak=True)
+        assert np.array_equal(off, foff) and peak >= 2
+        for i in range(len(rays)):
+            got = idx[off[i]:off[i + 1]].tolist()
+            assert pyref.traverse_distance(tt.nodes, ab, (rays[i]["o"], rays[i]["d"], rays[i]["inv"]), asc) == got
+            assert sorted(got) == sorted(fidx[foff[i]:foff[i + 1]])
+    # f64 as well
+    t64 = orc.build(ab.astype(np.float64))
+    r64 = orc.make_rays(rays["o"][:50], rays["d"][:50], np.float64)
+    for asc in (True, False):
+        off, idx = orc.traverse_distance(t64.nodes, ab.astype(np.float64), r64, asc)
+        for i in range(len(r64)):
+            assert pyref.traverse_distance(t64.nodes, ab.astype(np.float64), (r64[i]["o"], r64[i]["d"], r64[i]["inv"]), asc) == \
+                idx[off[i]:off[i + 1]].tolist()
