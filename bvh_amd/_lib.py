@@ -75,6 +75,8 @@ SYMBOLS = [
     ("bvhgpu_rebuild_f64", _i, [_vp, _vp, _sz, _i]),
     ("bvhgpu_build_flat_f32", _i, [_vp, _vp, _sz, _i, _pp]),
     ("bvhgpu_build_flat_f64", _i, [_vp, _vp, _sz, _i, _pp]),
+    ("bvhgpu_refit_f32", _i, [_vp, _vp, _sz, _i]),
+    ("bvhgpu_refit_f64", _i, [_vp, _vp, _sz, _i]),
     ("bvhgpu_rebuild_flat_f32", _i, [_vp, _vp, _sz, _i]),
     ("bvhgpu_rebuild_flat_f64", _i, [_vp, _vp, _sz, _i]),
     ("bvhgpu_tree_destroy", None, [_vp]),

@@ -568,6 +568,21 @@ class Bvh(_TreeBase):
             check(fn(self._t, ptr(a), len(a), HOST), self.ctx._h)
         return self
 
+    def refit(self, aabbs) -> "Bvh":
+        """The shapes moved: same topology, every child AABB recomputed from the new shape AABBs
+        (Bvh::fix_aabbs_ascending, optimization.rs:355-391, applied to the whole tree); a flattened tree is
+        re-flattened.  ~10x cheaper than rebuild(); update_shapes' re-insertion (optimization.rs:337-352) is not
+        reproduced — rebuild() when the topology should follow the motion."""
+        lib = _lib.load()
+        fn = getattr(lib, f"bvhgpu_refit_{self.sfx}")
+        if _is_device_tensor(aabbs):
+            check(fn(self._t, ptr(aabbs.data_ptr()), aabbs.numel() // 6, DEVICE), self.ctx._h)
+        else:
+            ft = np.float32 if self.sfx == "f32" else np.float64
+            a = np.ascontiguousarray(aabbs, dtype=ft).reshape(-1, 6)
+            check(fn(self._t, ptr(a), len(a), HOST), self.ctx._h)
+        return self
+
     @staticmethod
     def build(shapes: Sequence, dtype=np.float32, ctx: Optional[Context] = None) -> "Bvh":
         """Bvh::build (bvh_impl.rs:40-45).  Calls shape.aabb() ONCE per shape (the reference calls it

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libbvh_mi355x.so")
-SOURCES = ["capi.hip", "build.hip", "flatten.hip", "traverse.hip", "obj.cpp"]
+SOURCES = ["capi.hip", "build.hip", "flatten.hip", "traverse.hip", "refit.hip", "obj.cpp"]
 HEADERS = ["common.hpp", "engine.hpp", "obj.cpp", os.path.join("..", "..", "include", "bvh_mi355x.h")]
 # -fno-slp-vectorize: ROCm 7.2's SLP vectoriser + gfx950 instruction selection crash (SIGSEGV in
 # constrainRegClass) on the integer-key min/max folds of sah_select(); packed v_pk_* VALU ops are no

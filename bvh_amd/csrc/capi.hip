@@ -58,7 +58,7 @@ void free_tree_buffers(bvhgpu_tree* t) {
     t->idx[0].release(); t->idx[1].release(); t->bk.release();
     t->big[0].release(); t->big[1].release(); t->mid2.release(); t->small.release();
     t->stats[0].release(); t->stats[1].release();
-    t->tile_item[0].release(); t->tile_item[1].release(); t->tile_cnt.release(); t->ctr.release();
+    t->tile_item[0].release(); t->tile_item[1].release(); t->tile_cnt.release(); t->ctr.release(); t->refit_seg.release();
 }
 
 constexpr size_t MAX_SHAPES = (0xFFFFFFFFull - 1) / 3;  // flat indices are u32 (flat_bvh.rs:136)
@@ -79,6 +79,23 @@ template <typename T> int do_build(bvhgpu_tree* t, const T* aabbs, size_t n, int
     build_tree<T>(t, dev, n, flat);
     if (flat && n == 0) t->flattened = true;
     if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[1], ctx->stream)); ctx->ev_set |= 1u; }
+    return BVHGPU_OK;
+}
+
+// the shapes moved: same topology, boxes recomputed (refit.hip)
+template <typename T> int do_refit(bvhgpu_tree* t, const T* aabbs, size_t n, int mem) {
+    bvhgpu_ctx* ctx = t->ctx;
+    if (!t->built) return fail(ctx, BVHGPU_INVALID_ARG, "refit needs a tree that was built here (imported scenes carry no BvhNode array)");
+    if (n != t->n) return fail(ctx, BVHGPU_INVALID_ARG, "refit: the number of shapes differs from the tree's (build again)");
+    if (n && !aabbs) return fail(ctx, BVHGPU_INVALID_ARG, "aabbs is NULL");
+    if (mem != BVHGPU_HOST && mem != BVHGPU_DEVICE) return fail(ctx, BVHGPU_INVALID_ARG, "bad mem kind");
+    use_device(ctx);
+    const T* dev = aabbs;
+    if (n && mem == BVHGPU_HOST) {  // upload straight into the tree's own copy
+        BVH_HIP(hipMemcpyAsync(t->aabbs.p, aabbs, n * 6 * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+        dev = t->aabbs.as<T>();
+    }
+    refit_tree<T>(t, dev);
     return BVHGPU_OK;
 }
 
@@ -388,6 +405,17 @@ int bvhgpu_rebuild_f64(bvhgpu_tree* t, const double* aabbs, size_t n, int mem) {
     if (!t) return BVHGPU_INVALID_ARG;
     if (t->dtype != BVHGPU_F64) return fail(t->ctx, BVHGPU_DTYPE_MISMATCH, "tree is f32");
     return guarded(t->ctx, [&] { return do_build<double>(t, aabbs, n, mem); });
+}
+
+int bvhgpu_refit_f32(bvhgpu_tree* t, const float* aabbs, size_t n, int mem) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    if (t->dtype != BVHGPU_F32) return fail(t->ctx, BVHGPU_DTYPE_MISMATCH, "tree is f64");
+    return guarded(t->ctx, [&] { return do_refit<float>(t, aabbs, n, mem); });
+}
+int bvhgpu_refit_f64(bvhgpu_tree* t, const double* aabbs, size_t n, int mem) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    if (t->dtype != BVHGPU_F64) return fail(t->ctx, BVHGPU_DTYPE_MISMATCH, "tree is f32");
+    return guarded(t->ctx, [&] { return do_refit<double>(t, aabbs, n, mem); });
 }
 
 // FlatBvh::build (flat_bvh.rs:328-331) = Bvh::build + flatten in one call: one host round trip instead of two

@@ -88,6 +88,7 @@ struct bvhgpu_tree {
     bvhgpu::DevBuf tile_item[2];
     bvhgpu::DevBuf tile_cnt;    // per tile 6 x u32 (counts, then exclusive offsets)
     bvhgpu::DevBuf ctr;         // counters
+    bvhgpu::DevBuf refit_seg;   // refit: complete binary tree of joins over the sorted positions (2 * n_pad boxes)
 };
 
 struct bvhgpu_hits {
@@ -120,6 +121,8 @@ namespace bvhgpu {
 template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after);
 // flatten.hip
 template <typename T> void flatten_tree(bvhgpu_tree* t);
+// refit.hip
+template <typename T> void refit_tree(bvhgpu_tree* t, const T* aabbs_dev);
 // traverse.hip
 template <typename T>
 void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, unsigned flags,

@@ -126,6 +126,16 @@ int bvhgpu_build_flat_f32(bvhgpu_ctx *ctx, const float *aabbs, size_t n, int mem
 int bvhgpu_build_flat_f64(bvhgpu_ctx *ctx, const double *aabbs, size_t n, int mem, bvhgpu_tree **out);
 int bvhgpu_rebuild_flat_f32(bvhgpu_tree *tree, const float *aabbs, size_t n, int mem);
 int bvhgpu_rebuild_flat_f64(bvhgpu_tree *tree, const double *aabbs, size_t n, int mem);
+/* The shapes moved but are the same shapes: keep the topology, recompute every child AABB from the new shape AABBs —
+ * Bvh::fix_aabbs_ascending (optimization.rs:355-391: child boxes = children's get_node_aabb, bvh_node.rs:616-625)
+ * applied to the whole tree.  n must equal the tree's shape count; the tree must have been built here.  If the tree
+ * is flattened its flat / traversal arrays are regenerated.  The result is consistent and tight (the properties
+ * the reference asserts after update_shapes, optimization.rs tests); refit with the AABBs of the build reproduces
+ * the built tree bit for bit.  Bvh::update_shapes itself (optimization.rs:337-352: remove + re-insert, one shape at a
+ * time, topology changes) has no device counterpart: moved shapes are answered by this refit or by a rebuild.
+ * Triangle vertices (bvhgpu_tree_set_triangles) are the caller's to refresh. */
+int bvhgpu_refit_f32(bvhgpu_tree *tree, const float *aabbs, size_t n, int mem);
+int bvhgpu_refit_f64(bvhgpu_tree *tree, const double *aabbs, size_t n, int mem);
 void bvhgpu_tree_destroy(bvhgpu_tree *tree);
 
 int bvhgpu_tree_info(const bvhgpu_tree *tree, int *dtype, size_t *n_shapes, size_t *n_nodes, size_t *n_flat);

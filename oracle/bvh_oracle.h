@@ -106,6 +106,7 @@ void orc_aligned_boxes(float *aabbs /* 21*6 */);
                               const T *points, size_t n, uint32_t *out_shape, T *out_dist);               \
     uint64_t orc_traverse_child_ordered_##S(const NODE *nodes, size_t n_nodes, const T *shape_aabbs, const RAY *rays, \
                                             size_t n_rays, int ascending, uint32_t *offsets, uint32_t *indices, uint64_t cap); \
+    void orc_refit_##S(NODE *nodes, size_t n_nodes, const T *aabbs);   /* optimization.rs:355-391 applied to all nodes */ \
     uint64_t orc_traverse_distance_##S(const NODE *nodes, size_t n_nodes, const T *shape_aabbs, const RAY *rays, \
                                        size_t n_rays, int ascending, uint32_t *offsets, uint32_t *indices, uint64_t cap, \
                                        uint32_t *heap_peak);                                               \

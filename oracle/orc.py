@@ -337,6 +337,18 @@ def traverse_distance(nodes, shape_aabbs, rays, ascending: bool = True, want_pea
     return (offsets, indices, int(peak.value)) if want_peak else (offsets, indices)
 
 
+def refit(nodes, aabbs):
+    """same topology, child AABBs recomputed bottom-up from the (moved) shapes → new node array"""
+    s = "f32" if nodes.dtype == NODE_F32 else "f64"
+    ft = _types(s)[0]
+    a = np.ascontiguousarray(aabbs, dtype=ft).reshape(-1, 6)
+    out = np.ascontiguousarray(nodes).copy()
+    fn = getattr(lib(), f"orc_refit_{s}")
+    fn.restype = None
+    fn(_p(out), C.c_size_t(len(out)), _p(a))
+    return out
+
+
 def check_tree(nodes, aabbs) -> int:
     s = "f32" if nodes.dtype == NODE_F32 else "f64"
     ft = _types(s)[0]

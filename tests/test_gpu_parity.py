@@ -724,6 +724,76 @@ def test_best_first_traversal_matches_iterator_restatement(eng, orc, dtype):
     assert np.array_equal(idx, oidx) and len(idx) == p
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_refit_moved_shapes(eng, orc, dtype):
+    """bvhgpu_refit: the topology stays, every child AABB becomes the exact join of the moved shapes below it
+    (fix_aabbs_ascending, optimization.rs:355-391, applied to the whole tree).  Bit-identical to the oracle's bottom-up
+    recursion; consistent + tight (the reference's assert_consistent / assert_tight, bvh_impl.rs:424-485); refit with the
+    build's own AABBs reproduces the built tree; traversal of the refitted tree == the oracle on the refitted tree and
+    returns the same SET per ray as a fresh build of the moved shapes.  Sizes cover 1..3 segment-tree passes."""
+    from bvh_amd import testbase as tb
+    rng = np.random.default_rng(41)
+    for n_cubes in (1, 40, 420, 9000):
+        tris32, aabbs32 = tb.create_n_cubes(n_cubes)
+        aabbs = aabbs32.astype(dtype)
+        for n in sorted({1, 2, 3, len(aabbs)} if n_cubes == 40 else {len(aabbs)}):
+            a0 = aabbs[:n].copy()
+            bvh = eng.Bvh.from_aabbs(a0)
+            ot = orc.build(a0)
+            flat = bvh.flatten()
+            bvh.refit(a0)                                           # nothing moved: the built tree, bit for bit
+            assert bvh.nodes.tobytes() == ot.nodes.tobytes()
+            assert flat.nodes.tobytes() == orc.flatten(ot.nodes).tobytes()
+            # move every shape (rigidly, by up to a few cube sizes) and give some boxes signed zeros
+            shift = rng.uniform(-3, 3, size=(n, 1, 3)).astype(dtype)
+            a1 = (a0.reshape(n, 2, 3) + shift).reshape(n, 6)
+            a1[::7, 0] = -0.0; a1[::7, 3] = 0.0
+            a1[3::11, 1] = 0.0; a1[3::11, 4] = 0.0
+            bvh.refit(a1)
+            on = orc.refit(ot.nodes, a1)
+            assert bvh.nodes.tobytes() == on.tobytes()
+            assert orc.check_tree(on, a1) == 0
+            oflat = orc.flatten(on)
+            assert flat.nodes.tobytes() == oflat.tobytes()
+            m = 4000
+            o = rng.uniform(-1e5, 1e5, size=(m, 3)).astype(dtype)
+            tgt = a1[rng.integers(0, n, m)].reshape(m, 2, 3).mean(axis=1)
+            rays = orc.make_rays(o, (tgt - o).astype(dtype), dtype)
+            off, idx, _, _ = flat.traverse_batch(_rb(eng, rays))
+            ooff, oidx, _, _ = orc.traverse_flat(oflat, a1, rays)
+            assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+            fresh = orc.build(a1)
+            foff, fidx, _, _ = orc.traverse_flat(orc.flatten(fresh.nodes), a1, rays)
+            assert np.array_equal(foff, ooff)
+            assert all(sorted(idx[off[i]:off[i + 1]]) == sorted(fidx[foff[i]:foff[i + 1]]) for i in range(m))
+            if n >= 2:   # ordered walks read the BvhNode array the refit rewrote
+                noff, nidx, _, _ = flat.traverse_batch(_rb(eng, rays), order="nearest_heap")
+                qoff, qidx = orc.traverse_distance(on, a1, rays, True)
+                assert np.array_equal(noff, qoff) and np.array_equal(nidx, qidx)
+            # a rebuild after the refit is an ordinary build again
+            bvh.rebuild(a1)
+            assert bvh.nodes.tobytes() == fresh.nodes.tobytes()
+    # errors: shape count must match, imported scenes have no BvhNode array
+    bvh = eng.Bvh.from_aabbs(aabbs[:100])
+    with pytest.raises(eng.BvhGpuError):
+        bvh.refit(aabbs[:99])
+
+
+def test_refit_1_2m_triangles_three_passes(eng, orc):
+    """1.2 M shapes: n_pad = 2^21, three segment-tree passes; refit == oracle refit, bit for bit."""
+    from bvh_amd import testbase as tb
+    _, aabbs = tb.create_n_cubes(100_000)
+    bvh = eng.Bvh.from_aabbs(aabbs)
+    nodes0 = bvh.nodes
+    rng = np.random.default_rng(43)
+    n = len(aabbs)
+    a1 = (aabbs.reshape(n, 2, 3) + rng.uniform(-2, 2, size=(n, 1, 3)).astype(np.float32)).reshape(n, 6)
+    bvh.refit(a1)
+    assert bvh.nodes.tobytes() == orc.refit(nodes0, a1).tobytes()
+    bvh.refit(aabbs)
+    assert bvh.nodes.tobytes() == nodes0.tobytes()
+
+
 def test_parity_1_2m_triangles(eng, orc):
     """ten times the BASELINE scene (create_n_cubes(100 000) = 1.2 M triangles): more level-synchronous passes,
     many tier-A/B items, multi-chunk tile-offset scans — node, flat and CSR arrays byte-identical to the oracle."""
