@@ -5,9 +5,12 @@ One STEP = one pass of the hot path over one batch of synthetic input that is al
 HBM: Bvh::build_par (SAH) → Bvh::flatten → FlatBvh::traverse of R rays, results left in HBM as CSR.
 Workload at every N: BASELINE.json configs[1] — create_n_cubes(10 000) = 120 000 triangles f32/3D and
 R = 1 000 000 create_ray rays PER GPU (weak scaling: rank r traverses rays [r*R, (r+1)*R) of the
-seed-0 stream).  N > 1: rank 0 builds + flattens, the traversal array + shape AABBs travel to the
-peers in ONE RCCL broadcast (torch.distributed, backend nccl == RCCL over xGMI), every rank traverses
-its own ray shard; no other collective on the data path.
+seed-0 stream).  N > 1, two plans for the scene (--scene-dist): "bcast" — rank 0 builds + flattens, the
+traversal array + shape AABBs travel to the peers in ONE RCCL broadcast per step (torch.distributed, backend
+nccl == RCCL over xGMI); "replicate" — every rank runs the deterministic build itself, no collective on the
+data path.  The default "auto" times both plans for a few untimed steps and keeps the faster one (at
+120 000 triangles a 0.26 ms build competes with moving 10.6 MB over xGMI); the probe times are reported.
+Every rank traverses its own ray shard; hit lists stay on the GPU that produced them.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
@@ -42,8 +45,9 @@ def parse():
     ap.add_argument("--cubes", type=int, default=10_000, help="create_n_cubes(n): 12 triangles each")
     ap.add_argument("--rays", type=int, default=1_000_000, help="rays per GPU per step")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--scene-dist", choices=["bcast", "replicate"], default="bcast",
-                    help="N>1: broadcast rank 0's flat scene over RCCL, or rebuild it on every rank")
+    ap.add_argument("--scene-dist", choices=["auto", "bcast", "replicate"], default="auto",
+                    help="N>1: broadcast rank 0's flat scene over RCCL each step, or rebuild it on every rank (the build is "
+                         "deterministic); auto times both during warmup and keeps the faster plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N>1 (nccl == RCCL; gloo only for the one-GPU test of this script)")
@@ -107,27 +111,35 @@ def main():
     rays = RayBatch.generate(first, R, bounds, rays_buf, dtype, ctx)
     torch.cuda.synchronize(dev)
 
-    builder = (rank == 0) or args.scene_dist == "replicate" or n_gpus == 1
-    bvh = Bvh.from_aabbs(aabbs, ctx) if builder else None
-    if builder:
+    # N>1, two plans for getting the scene to every GPU each step:
+    #   bcast      rank 0 builds + flattens, ONE RCCL broadcast of the scene blob, peers import it
+    #   replicate  every rank runs the (deterministic) build itself: no collective on the data path
+    # auto probes both before the warmup and keeps the faster one; the probe times go into the JSON line.
+    plans = ["single"] if n_gpus == 1 else (["bcast", "replicate"] if args.scene_dist == "auto" else [args.scene_dist])
+    own_tree = rank == 0 or "replicate" in plans or n_gpus == 1
+    bvh = Bvh.from_aabbs(aabbs, ctx) if own_tree else None
+    if own_tree:
         bvh.flatten_in_place()
     blob = None
     peer = None
-    if n_gpus > 1 and args.scene_dist == "bcast":
+    if "bcast" in plans:
         nbytes = bdist.broadcast_nbytes(bvh.scene_nbytes() if rank == 0 else 0, dev, 0)
         blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    plan = plans[0]
 
     def step():
         nonlocal peer
-        if builder:
-            bvh.rebuild(aabbs, flatten=True)   # Bvh::build_par + Bvh::flatten (FlatBvh::build, flat_bvh.rs:328-331)
-        if blob is not None:
+        if plan == "bcast":
             if rank == 0:
+                bvh.rebuild(aabbs, flatten=True)   # Bvh::build_par + Bvh::flatten (FlatBvh::build, flat_bvh.rs:328-331)
                 bvh.scene_export(blob)
-            bdist.broadcast_scene(blob, 0)  # RCCL over xGMI: traversal array + shape AABBs
+            bdist.broadcast_scene(blob, 0)         # RCCL over xGMI: traversal array + shape AABBs
             if rank != 0:
                 peer = FlatBvh.scene_import(blob, blob.numel(), ctx, reuse=peer)
-        tree = bvh if builder else peer
+            tree = bvh if rank == 0 else peer
+        else:
+            bvh.rebuild(aabbs, flatten=True)
+            tree = bvh
         return tree.traverse_batch(rays, fetch=False)[3]  # FlatBvh::traverse, CSR stays in HBM
 
     def barrier():
@@ -135,24 +147,35 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def timed(k):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if n_gpus > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    probe_ms = {}
+    if len(plans) > 1:          # auto: a short probe of each plan (untimed for the metric), all ranks agree on the max-over-ranks time
+        for pl in plans:
+            plan = pl
+            step(); step()
+            probe_ms[pl] = timed(5) / 5 * 1e3
+        plan = min(plans, key=lambda q: probe_ms[q])
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = step()
-    barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if n_gpus > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = timed(args.steps)
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     value = (n_gpus * R) / (ms_per_step * 1e-3) / 1e6  # Mrays/s, whole job
 
     # ---- per-phase HIP-event times + roofline of the dominant kernel (untimed extra steps) ----
     ctx.enable_timing(True)
+    builder = plan != "bcast" or rank == 0
     tree = bvh if builder else peer
     ph = dict(build_ms=[], flatten_ms=[], traverse_kernel_ms=[], traverse_total_ms=[])
     for _ in range(max(5, min(args.steps, 20))):
@@ -202,12 +225,14 @@ def main():
         "config": {
             "workload": f"configs[1]: create_n_cubes({args.cubes}) = {n_tri} random-cube triangles {args.dtype}/3D, "
                         f"{R} create_ray rays per GPU; step = Bvh::build_par + flatten + FlatBvh::traverse (CSR hit lists in HBM)",
-            "triangles": n_tri, "rays_per_gpu": R, "scene_dist": args.scene_dist if n_gpus > 1 else "single",
-            "parallelism": f"rays sharded x{n_gpus}" + (", flat scene RCCL-broadcast from rank 0" if blob is not None else ""),
+            "triangles": n_tri, "rays_per_gpu": R, "scene_dist": plan,
+            "parallelism": f"rays sharded x{n_gpus}" + {"single": "", "bcast": ", flat scene RCCL-broadcast from rank 0 every step",
+                                                        "replicate": ", every rank rebuilds the scene (deterministic build, no data-path collective)"}[plan],
         },
         "phases_ms": {k: round(v, 4) for k, v in phases.items()},
         "build_levels": bvh.build_levels if builder else None,
         "hits_all_ranks": int(hits_all),
+        "scene_dist_probe_ms_per_step": {k: round(v, 4) for k, v in probe_ms.items()} or None,
         "roofline": roofline,
     }
 

@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("scene_dist", ["bcast", "replicate"])
+@pytest.mark.parametrize("scene_dist", ["bcast", "replicate", "auto"])
 def test_bench_two_ranks_one_gpu(scene_dist):
     import bvh_amd
     if bvh_amd.device_count() <= 0:
@@ -41,6 +41,11 @@ def test_bench_two_ranks_one_gpu(scene_dist):
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
     assert out["config"]["rays_per_gpu"] == R and out["value"] > 0
     assert "roofline" in out and "cpu_baseline" not in out  # the CPU leg is rank 0 at N=1 only
+    if scene_dist == "auto":
+        assert out["config"]["scene_dist"] in ("bcast", "replicate")
+        assert set(out["scene_dist_probe_ms_per_step"]) == {"bcast", "replicate"}
+    else:
+        assert out["config"]["scene_dist"] == scene_dist
 
     # the two shards together == one process over the first 2R rays of the stream (oracle as the checker)
     from bvh_amd import testbase as tb
