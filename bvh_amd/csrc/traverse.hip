@@ -760,6 +760,16 @@ __global__ __launch_bounds__(256) void k_hits_scatter(const HitRec* __restrict__
     }
 }
 
+// The 8 walk / scan counters go to the context's pinned host page and are zeroed for the next call: one 64-thread
+// launch instead of the runtime's copy kernel plus its fill kernel (≈4.5 µs each on the stream).
+__global__ void k_publish_counters(unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ host_page) {
+    if (threadIdx.x < 8) {
+        host_page[threadIdx.x] = ctr[threadIdx.x];
+        ctr[threadIdx.x] = 0;
+    }
+    __threadfence_system();
+}
+
 // ------------------------------------------------------------------------------------------------
 template <typename T, int MODE, bool STATS>
 static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, const WalkOut<T>& w, bool use_lds,
@@ -885,8 +895,7 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
             if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
             DISPATCH_WALK();
             if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
-            BVH_HIP(hipMemcpyAsync(pin, ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-            BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));   // for the next call, behind the readback
+            hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);   // readback + reset for the next call
             BVH_HIP(hipStreamSynchronize(st));
             h->ctr_clean = true;
             BVH_HIP(hipGetLastError());
@@ -956,8 +965,7 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
             hipLaunchKernelGGL((k_hits_scatter<T, 0>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap,
                                offs, pair_counts, h->indices.as<uint32_t>(), vals);
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
-        BVH_HIP(hipMemcpyAsync(pin, ctr, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));   // for the next call, behind the readback
+        hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);   // readback + reset for the next call
         BVH_HIP(hipStreamSynchronize(st));
         h->ctr_clean = true;
         BVH_HIP(hipGetLastError());
