@@ -267,7 +267,11 @@ def main():
                C.c_uint64(0), None, C.byref(st_o), C.c_int(threads))
             return time.perf_counter() - t0
         trav(cores)                                     # first call creates the OpenMP team
-        tt_all = min(trav(cores), trav(cores))
+        tt_all, trav_threads = 1e9, cores               # the box may grant fewer CPUs than it shows: keep the best team size
+        for th in sorted({8, 16, 32, 64, cores} & set(range(1, cores + 1))):
+            dt = min(trav(th), trav(th))
+            if dt < tt_all:
+                tt_all, trav_threads = dt, th
         n1 = max(ns // 16, 1000)
         t0 = time.perf_counter()
         fn(orc._p(of), C.c_size_t(len(of)), orc._p(sa), orc._p(rr), C.c_size_t(n1), orc._p(offs), None,
@@ -276,10 +280,10 @@ def main():
         tbuild = min(tb_par, tb_ser)
         cpu_total = tbuild + tf + tt_all * (R / ns)
         out["cpu_baseline"] = {
-            "value": round(R / cpu_total / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "value": round(R / cpu_total / 1e6, 4), "unit": "Mrays/s", "cores": max(trav_threads, par_threads), "host_cpus_visible": cores, "kind": "port",
             "sample": f"oracle (C restatement, gcc -O2 -ffp-contract=off, OpenMP): full {n_tri}-triangle build "
                       f"(best of task-parallel {tb_par * 1e3:.1f} ms on {par_threads} threads / serial {tb_ser * 1e3:.1f} ms) + serial flatten "
-                      f"{tf * 1e3:.1f} ms + traversal of {ns} of the {R} rays on {cores} threads ({tt_all * 1e3:.1f} ms, count pass only), "
+                      f"{tf * 1e3:.1f} ms + traversal of {ns} of the {R} rays on {trav_threads} threads (best of 8/16/32/64/{cores}: {tt_all * 1e3:.1f} ms, count pass only), "
                       f"scaled to {R} rays; single-thread traversal {tt_1 / n1 * 1e9:.0f} ns/ray "
                       f"(README.md:175 quotes 866 ns/ray on a Ryzen 9 3900X for the Rust crate)",
             "build_ms": round(tbuild * 1e3, 2), "flatten_ms": round(tf * 1e3, 2),
