@@ -49,6 +49,9 @@ def parse():
                     help="N>1: broadcast rank 0's flat scene over RCCL each step, or rebuild it on every rank (the build is "
                          "deterministic); auto times both during warmup and keeps the faster plan")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline-streams", type=int, default=2,
+                    help="N=1 only, reported beside `value` (never as it): the same K steps issued from this many host threads on "
+                         "this many HIP streams, so that the latency-bound build of one step overlaps the traversal of another; 0 = skip")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N>1 (nccl == RCCL; gloo only for the one-GPU test of this script)")
     ap.add_argument("--one-device", action="store_true",
@@ -235,6 +238,49 @@ def main():
         "scene_dist_probe_ms_per_step": {k: round(v, 4) for k, v in probe_ms.items()} or None,
         "roofline": roofline,
     }
+
+    # ---- supplementary: independent steps in flight on several HIP streams (N = 1) ----
+    # `value` above is the time of K steps issued one after the other on ONE stream.  Steps are independent of each other
+    # (each rebuilds the scene from the shape AABBs), and the builder's ~20 small dependent kernels leave most CUs idle, so
+    # a renderer would keep the next frame's build in flight while the current frame traces.  Same K steps, same work:
+    # S host threads, each with its own context / stream / tree / hit buffers, K/S steps each.
+    if n_gpus == 1 and args.pipeline_streams > 1:
+        import threading
+        S = args.pipeline_streams
+        lanes = []
+        for j in range(S):
+            c = Context(local_rank)                       # its own non-blocking HIP stream
+            tr = Bvh.from_aabbs(aabbs, c)
+            tr.flatten_in_place()
+            lanes.append((c, tr))
+
+        def lane_steps(tr, k):
+            for _ in range(k):
+                tr.rebuild(aabbs, flatten=True)
+                tr.traverse_batch(rays, fetch=False)
+
+        per = max(args.steps // S, 1)
+        for c, tr in lanes:
+            lane_steps(tr, 3)
+        torch.cuda.synchronize(dev)
+        threads = [threading.Thread(target=lane_steps, args=(tr, per)) for _, tr in lanes]
+        t0 = time.perf_counter()
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        torch.cuda.synchronize(dev)
+        dtp = time.perf_counter() - t0
+        hits_p = [tr.traverse_batch(rays, stats=True, fetch=False)[3]["hits"] for _, tr in lanes]
+        out["pipelined"] = {
+            "streams": S, "steps": per * S, "value": round(per * S * R / dtp / 1e6, 3), "unit": "Mrays/s",
+            "ms_per_step": round(dtp * 1e3 / (per * S), 4), "hits_per_lane": hits_p,
+            "note": f"the same steps issued from {S} host threads on {S} HIP streams (own context, tree and hit buffers each): "
+                    "the build of one step overlaps the traversal of another; throughput of independent steps, not the latency of one",
+        }
+        for c, tr in lanes:
+            tr.close()
+            c.close()
 
     # ---- CPU baseline: the oracle (C port of the reference algorithm) on this box's host cores ----
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
