@@ -42,7 +42,7 @@ struct bvhgpu_ctx {
     bool own_stream = false;
     std::string err;
     int n_cu = 256;
-    int tune[BVHGPU_TUNE_COUNT] = {2, 32, 1, 16384, 2048, 1024, 1, 0};  // bvhgpu_set_tuning defaults
+    int tune[BVHGPU_TUNE_COUNT] = {2, 32, 1, 16384, 0, 0, 1, 0};  // bvhgpu_set_tuning defaults
     // timing
     bool timing = false;
     hipEvent_t ev[8] = {};
