@@ -785,11 +785,12 @@ static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
     }
     // workgroups of lds_threads that each keep K top-of-tree slots in LDS; as many per CU as 160 KB of LDS
     // and 32 waves allow
-    // 0 = per-type default.  f32: 2048 slots x 32 B and 1024 threads → two workgroups per CU; f64 (56 B per slot): 1400 slots and
-    // 512 threads → two workgroups per CU as well (measured best of a slots x threads sweep, tools/f64_sweep.py)
+    // 0 = per-type default: as many slots as let TWO workgroups share a CU's 160 KB (f32: 2559 x 32 B, f64: 1462 x 56 B) — one
+    // slot more halves the occupancy (0.206 → 0.296 ms on configs[1]); 1024 threads for f32, 512 for f64 (tools/f64_sweep.py)
     const bool wide = sizeof(T) == 8;
+    const int two_per_cu = (int)(((160 * 1024) / 2 - 16) / TopLds<T>::BYTES_PER_SLOT);
     const int want_threads = ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_THREADS] > 0 ? ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_THREADS] : (wide ? 512 : 1024);
-    const int want_slots = ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_SLOTS] > 0 ? ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_SLOTS] : (wide ? 1400 : 2048);
+    const int want_slots = ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_SLOTS] > 0 ? ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_SLOTS] : two_per_cu;
     const uint32_t lds_threads = (uint32_t)std::min(LDS_THREADS, std::max(64, want_threads & ~63));
     const uint32_t K = (uint32_t)std::min<int>((int)TopCfg<T>::SLOTS, std::max(4, want_slots));
     const size_t lds_bytes = 16 + (size_t)K * TopLds<T>::BYTES_PER_SLOT;

@@ -249,7 +249,7 @@ typedef enum {
     BVHGPU_TUNE_RESERVED_1 = 1,
     BVHGPU_TUNE_RESERVED_2 = 2,
     BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS = 3, /* variant 2 is used for batches of at least this many rays (default 16384) */
-    BVHGPU_TUNE_TRAVERSE_LDS_SLOTS = 4,    /* variant 2: top-of-tree entries kept in LDS per workgroup (default 0 = per type: f32 2048 = 11 levels, f64 1400) */
+    BVHGPU_TUNE_TRAVERSE_LDS_SLOTS = 4,    /* variant 2: top-of-tree entries kept in LDS per workgroup (default 0 = as many as let two workgroups share a CU: f32 2559, f64 1462) */
     BVHGPU_TUNE_TRAVERSE_LDS_THREADS = 5,  /* variant 2: workgroup size (default 0 = per type: f32 1024, f64 512) */
     BVHGPU_TUNE_TRAVERSE_SPLIT = 6,        /* variant 2, CSR outputs: walk every ray as two items (left / right subtree of the
                                               root); default 1 */
