@@ -39,7 +39,10 @@ template <typename T> struct MidB {
     static constexpr int HANDOFF = SMALL_MAX;
 };
 template <typename T> struct MidCfg { static constexpr int MAXN = MidB<T>::MAXN; };   // level-tier threshold
-constexpr int STAT_REP = 8;   // global replicas of an item's statistics: tile t adds to replica t % 8, so the ~470 tiles of
+#ifndef BVH_STAT_REP
+#define BVH_STAT_REP 8
+#endif
+constexpr int STAT_REP = BVH_STAT_REP;   // global replicas of an item's statistics: tile t adds to replica t % 8, so the ~470 tiles of
                               // the root do not serialise on 78 addresses (k_bin of level 0: 13.4 -> see profiles); the
                               // selection merges the replicas
 constexpr int CTR_LEVEL0 = 16;   // u32 pairs (n_items, n_tiles) per level slot

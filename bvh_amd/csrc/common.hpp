@@ -21,7 +21,10 @@ constexpr uint32_t NONE = BVHGPU_NONE;
 constexpr int NUM_BUCKETS = 6;        // reference: src/bvh/bucket.rs:5
 constexpr int WAVE = 64;              // gfx950 wavefront
 constexpr int SMALL_MAX = 64;         // segments <= one wave are finished by the wave-subtree kernel
-constexpr int TILE = 512;             // positions per workgroup tile in the level-synchronous tier
+#ifndef BVH_TILE
+#define BVH_TILE 512
+#endif
+constexpr int TILE = BVH_TILE;        // positions per workgroup tile in the level-synchronous tier (256 / 512 / 1024 measured: 512)
 constexpr int STAT_KEYS = 12;         // aabb min3,max3, centroid min3,max3
 
 // ------------------------------------------------------------------------------------------------

@@ -545,7 +545,10 @@ template <> struct TopLds<double> {
 };
 
 constexpr int LDS_THREADS = 1024;
-constexpr int LDS_INNER = 8;   // walk steps between two refill phases
+#ifndef BVH_LDS_INNER
+#define BVH_LDS_INNER 8
+#endif
+constexpr int LDS_INNER = BVH_LDS_INNER;   // walk steps between two refill phases (4 / 6 / 8 / 10 / 12 / 16 measured: 8)
 
 template <typename T, int MODE, bool STATS>
 __global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>* __restrict__ nodes, uint32_t n_trav,
