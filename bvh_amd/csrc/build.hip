@@ -3,24 +3,27 @@
 //
 // The reference recurses node by node (rayon::join).  Node placement is arithmetic (pre-order:
 // left = ni+1, right = ni+1+(2*nl-1), bvh_node.rs:138-142), so any node can be split as soon as
-// its index slice is final, in any order.  Two tiers:
+// its index slice is final, in any order.  Three tiers:
 //
-//  tier 1 — level-synchronous, for nodes with more than 64 shapes.  Per level three kernels over a
-//           queue of work items (one item = one BvhNodeBuildArgs):
-//             bin     : one workgroup per 1024-position tile of an item: bucket id per shape
-//                       (bvh_node.rs:204-222), 6 x (count, AABB, centroid-AABB) reduced with LDS
-//                       integer-key atomics, merged into the item's stats with global atomics
-//                       (min/max are exact → order-free);
-//             select  : one wave per item: 5 candidate splits, strict-< first-wins argmin
-//                       (:231-247), writes the BvhNode, creates the child items, turns per-tile
-//                       bucket counts into exclusive scatter offsets;
-//             scatter : stable bucket-major rewrite of the index slice (:250-272) = one stable
-//                       3-bit counting-sort pass: wave ballot ranks + per-tile offsets.
-//  tier 2 — wave-subtree: every node with <= 64 shapes is finished by ONE wavefront, one shape per
-//           lane, all levels of the subtree at once: segmented ballot ranks for the stable sort,
-//           ds_permute to move shapes, segmented min/max prefix+suffix scans for the L/R bounds
-//           of the 5 candidate splits (plays the role of rayon_executor's sequential cut-off,
-//           bvh_impl.rs:534).
+//  level tier     — nodes with more than MidB::MAXN (1024) shapes, level-synchronous: per level two launches over
+//                   a queue of work items (one item = one BvhNodeBuildArgs).  A launch boundary is the cheapest
+//                   grid-wide synchronisation on this chip (tools/ubench/gridbar.hip).
+//                     k_bin   : one workgroup per 512-position tile of an item: bucket id per shape
+//                               (bvh_node.rs:204-222), 6 x (count, AABB, centroid-AABB) reduced with LDS
+//                               integer-key atomics, merged into one of the item's STAT_REP statistic replicas
+//                               with global atomics (min/max are exact → order-free); per-tile bucket counts;
+//                     k_split : two roles in one launch, because they are independent —
+//                               select  : one wave per item: replicas merged, 5 candidate splits, strict-<
+//                                         first-wins argmin (:231-247), writes the BvhNode, queues the children;
+//                               scatter : stable bucket-major rewrite of the index slice (:250-272) = one stable
+//                                         3-bit counting-sort pass (needs only the per-tile bucket counts, not
+//                                         the chosen split): wave ballot ranks + counts of the earlier tiles.
+//  workgroup tier — k_mid: a node of 65..1024 shapes is finished by ONE workgroup with its index slice and AABBs
+//                   in LDS, level by level, down to <= 64-shape children.
+//  wave tier      — k_small: every node with <= 64 shapes is finished by ONE wavefront, one shape per lane, all
+//                   levels of the subtree at once: segmented ballot ranks for the stable sort, ds_permute to move
+//                   shapes, segmented min/max prefix+suffix scans for the L/R bounds of the 5 candidate splits
+//                   (plays the role of rayon_executor's sequential cut-off, bvh_impl.rs:534).
 #include "engine.hpp"
 
 namespace bvhgpu {
@@ -519,7 +522,7 @@ template <typename T> __device__ void scatter_role(const BuildArgs<T>& a, int le
         const uint32_t pend = min(start + count, p0 + (uint32_t)TILE);
         // exclusive offset of (this tile, bucket b) inside the item's slice = shapes of the item in buckets < b
         // + shapes of bucket b in the item's earlier tiles.  Every workgroup adds those up itself (at most a few
-        // hundred tiles per item) — a serial scan per item in k_select was the longest part of that kernel.
+        // hundred tiles per item) — a serial scan per item in the selection was the longest part of that launch.
         {
             const uint32_t tl = t - it->tile_base, ntl = (count + TILE - 1) / TILE;
             uint32_t before[NUM_BUCKETS], all[NUM_BUCKETS];
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
                     m->nl = nl;
                 }
                 const bool subL = has && cl > (uint32_t)HANDOFF, subR = has && cr > (uint32_t)HANDOFF;
-                // a child that leaves goes to the wave tier (<= 64 shapes) or, from tier A, to tier B
+                // a child that leaves goes to the wave tier (<= 64 shapes); larger ones stay in this workgroup
                 const bool smL = has && !subL && cl <= (uint32_t)SMALL_MAX, smR = has && !subR && cr <= (uint32_t)SMALL_MAX;
                 const bool m2L = has && !subL && !smL, m2R = has && !subR && !smR;
                 const unsigned long long mL = __ballot(subL), mR = __ballot(subR);
@@ -1180,7 +1183,7 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
 
     constexpr size_t MID_MAX = (size_t)MidCfg<T>::MAXN;
     const size_t max_big = n / (MID_MAX + 1) + 2;       // simultaneously active nodes with > MID_MAX shapes
-    const size_t max_mid2 = n / (SMALL_MAX + 1) + 2;     // tier B: nodes with 65..MidB::MAXN shapes
+    const size_t max_mid2 = n / (SMALL_MAX + 1) + 2;     // workgroup tier: nodes with 65..MidB::MAXN shapes
     const size_t max_tiles = n / TILE + max_big + 2;
     t->aabbs.reserve(n * 6 * sizeof(T));
     t->nodes.reserve(t->n_nodes * sizeof(typename Tr::Node));
