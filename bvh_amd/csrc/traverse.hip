@@ -8,12 +8,15 @@
 // reference's order, so each ray's shapes come out in the reference's (DFS, left-first) order.
 // Variable-length output (Vec<&Shape> per ray) becomes CSR in three steps:
 //   1. walk: every reported shape is appended to a pool as (ray, k, shape) with k = the ray's running
-//      hit count (per-wave chunks of the pool: one global atomic per 64 records); counts[ray] = k_end;
-//   2. exclusive scan of counts → offsets (reduce / scan-of-sums / rescan, 3 small kernels);
+//      hit count (per-wave chunks of the pool, 64 records doubling to 8192: one global atomic per chunk);
+//      counts[ray] = k_end;
+//   2. exclusive scan of counts → offsets (reduce + rescan; a scan of the block sums in between for > 2 M rays);
 //   3. indices[offsets[ray] + k] = shape  (+ per-hit values: t-slice or triangle Intersection).
 // If the pool was too small the totals are still exact; the host grows it and replays.
-// Two walk kernels: k_traverse (one ray per lane per launch; small batches) and k_traverse_lds (persistent
-// workgroups, top of the tree resident in LDS, ray refill; large batches).
+// Two walk kernels for the flat-array order: k_traverse (one ray per lane per launch; small or coherent batches) and
+// k_traverse_lds (persistent workgroups, top of the tree resident in LDS, ray refill; large batches).  Over the BvhNode
+// array: k_traverse_ordered (child-ordered iterator, LDS stack) and k_traverse_heap (best-first iterator, BinaryHeap);
+// k_nearest answers nearest_to point queries.
 #include <type_traits>
 
 #include "engine.hpp"
