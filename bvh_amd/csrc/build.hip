@@ -37,7 +37,10 @@ constexpr int CTR_MID2 = 2;      // u32: number of second-mid-tier items (65 .. 
 // workgroup tier for 1025..4096 shapes existed until the level-synchronous tier got down to ~12 µs per level — below
 // the ~20 µs per level a 4096-shape workgroup needs; see DESIGN.md.)
 template <typename T> struct MidB {
-    static constexpr int MAXN = sizeof(T) == 4 ? 1024 : 512;
+#ifndef BVH_MID_MAXN_F64
+#define BVH_MID_MAXN_F64 1024
+#endif
+    static constexpr int MAXN = sizeof(T) == 4 ? 1024 : BVH_MID_MAXN_F64;
     static constexpr int THREADS = 256;
     static constexpr int HANDOFF = SMALL_MAX;
 };
