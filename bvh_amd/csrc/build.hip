@@ -5,7 +5,7 @@
 // left = ni+1, right = ni+1+(2*nl-1), bvh_node.rs:138-142), so any node can be split as soon as
 // its index slice is final, in any order.  Three tiers:
 //
-//  level tier     — nodes with more than MidB::MAXN (1024) shapes, level-synchronous: per level two launches over
+//  level tier     — nodes with more than 768 (small scenes) / 1536 shapes, level-synchronous: per level two launches over
 //                   a queue of work items (one item = one BvhNodeBuildArgs).  A launch boundary is the cheapest
 //                   grid-wide synchronisation on this chip (tools/ubench/gridbar.hip).
 //                     k_bin   : one workgroup per 512-position tile of an item: bucket id per shape
@@ -18,7 +18,7 @@
 //                               scatter : stable bucket-major rewrite of the index slice (:250-272) = one stable
 //                                         3-bit counting-sort pass (needs only the per-tile bucket counts, not
 //                                         the chosen split): wave ballot ranks + counts of the earlier tiles.
-//  workgroup tier — k_mid: a node of 65..1024 shapes is finished by ONE workgroup with its index slice and AABBs
+//  workgroup tier — k_mid: a node of 65..768 (1536) shapes is finished by ONE workgroup with its index slice and AABBs
 //                   in LDS, level by level, down to <= 64-shape children.
 //  wave tier      — k_small: every node with <= 64 shapes is finished by ONE wavefront, one shape per lane, all
 //                   levels of the subtree at once: segmented ballot ranks for the stable sort, ds_permute to move
@@ -31,20 +31,28 @@ namespace bvhgpu {
 constexpr int MAXLV = 96;        // counter slots (levels beyond reuse the last two, host-synchronised)
 constexpr int CTR_SMALL = 0;     // u32: number of small items (<= 64 shapes, wave-subtree tier)
 constexpr int CTR_TICKET = 3;    // u32: k_prep arrival ticket (the last workgroup creates the root item)
-constexpr int CTR_MID2 = 2;      // u32: number of second-mid-tier items (65 .. MidB::MAXN shapes)
-// Workgroup tier: nodes of 65 .. MidB::MAXN shapes, one 256-thread workgroup per node (its AABBs live in ~40 KB of
+constexpr int CTR_MID2 = 2;      // u32: number of workgroup-tier items (65 .. BuildArgs::mid_max shapes)
+// Workgroup tier: nodes of 65 .. mid_max shapes, one workgroup per node (its AABBs live in 30-60 KB of
 // LDS, so every CU runs several): it splits down to <= 64-shape children for the wave tier.  (A second, larger
 // workgroup tier for 1025..4096 shapes existed until the level-synchronous tier got down to ~12 µs per level — below
 // the ~20 µs per level a 4096-shape workgroup needs; see DESIGN.md.)
-template <typename T> struct MidB {
-#ifndef BVH_MID_MAXN_F64
-#define BVH_MID_MAXN_F64 1024
-#endif
-    static constexpr int MAXN = sizeof(T) == 4 ? 1024 : BVH_MID_MAXN_F64;
+// Capacity / workgroup size of that tier, swept on create_n_cubes scenes (build ms, f32):
+//   120 k triangles: 1024/256 0.245, 1024/512 0.239, 768/256 0.237, 768/384 0.232, 512/256 0.238, 1536/256 0.24, 2048/256 0.272
+//   360 k: 768/384 0.424, 1024/256 0.368, 1536/256 0.383      1.2 M: 1.105 / 0.984 / 0.948      12 M: 10.9 / 9.56 / 9.07
+// At 120 k there is about one such node per CU and the tier is a latency chain (more threads per node help); from a few hundred
+// thousand triangles on there are several per CU and it is throughput (fewer, fatter workgroups and one level-tier pass less help).
+// Hence two instantiations, chosen by the shape count at launch (BuildArgs::mid_max is the level tier's hand-over size).
+template <typename T> struct MidSmallScene {   // up to MID_SCENE_SPLIT shapes
+    static constexpr int MAXN = 768;
+    static constexpr int THREADS = 384;
+    static constexpr int HANDOFF = SMALL_MAX;
+};
+template <typename T> struct MidLargeScene {
+    static constexpr int MAXN = sizeof(T) == 4 ? 1536 : 1024;   // f64: 6 x 8 B per shape in LDS
     static constexpr int THREADS = 256;
     static constexpr int HANDOFF = SMALL_MAX;
 };
-template <typename T> struct MidCfg { static constexpr int MAXN = MidB<T>::MAXN; };   // level-tier threshold
+constexpr size_t MID_SCENE_SPLIT = 250000;
 #ifndef BVH_STAT_REP
 #define BVH_STAT_REP 8
 #endif
@@ -63,6 +71,7 @@ template <typename T> struct ItemStats {
 };
 
 template <typename T> struct BuildArgs {
+    uint32_t mid_max;        // nodes with at most this many shapes (and more than 64) go to the workgroup tier
     const T* aabbs;          // the tree's own copy (what every later kernel gathers from)
     const T* src;            // the caller's array: k_prep copies it into `aabbs` while it reduces the bounds
     typename Traits<T>::Node* nodes;
@@ -185,7 +194,7 @@ __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, ui
     const int npar = next_level & 1;
     uint32_t slot = 0, tb = 0;
     const bool is_small = count <= (uint32_t)SMALL_MAX;
-    const bool is_mid2 = !is_small && count <= (uint32_t)MidB<T>::MAXN;
+    const bool is_mid2 = !is_small && count <= a.mid_max;
     const uint32_t ntile = (count + TILE - 1) / TILE;
     if (lane == 0) {
         if (is_small) slot = atomicAdd(&a.ctr[CTR_SMALL], 1u);
@@ -219,7 +228,7 @@ __device__ void push_pair(const BuildArgs<T>& a, int next_level, uint32_t parent
     const int nslot = lvl_slot(next_level);
     const int npar = next_level & 1;
     const uint32_t mycount = lane == 0 ? lcount : rcount;
-    const int mykind = mycount <= (uint32_t)SMALL_MAX ? 0 : (mycount <= (uint32_t)MidB<T>::MAXN ? 1 : 3);   // wave / workgroup / level tier
+    const int mykind = mycount <= (uint32_t)SMALL_MAX ? 0 : (mycount <= a.mid_max ? 1 : 3);   // wave / workgroup / level tier
     const uint32_t myntile = (mycount + TILE - 1) / TILE;
     uint32_t slot = 0, tb = 0;
     if (lane < 2) {
@@ -595,7 +604,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_split(BuildArgs<T
 }
 
 // ------------------------------------------------------------------------------------------------
-// mid tier — one workgroup finishes a whole node of 65 .. MidCfg<T>::MAXN shapes down to <= 64-shape
+// mid tier — one workgroup finishes a whole node of 65 .. Cfg::MAXN shapes down to <= 64-shape
 // sub-nodes, level by level, entirely in LDS: the node's index slice AND its shapes' AABBs are
 // loaded once and then only permuted in LDS.  Same-address LDS atomics were the bottleneck of a
 // first version (13 per shape per level), so statistics are taken AFTER the stable sort, where every
@@ -1184,9 +1193,10 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     t->levels = 0;
     if (n == 0) { t->built = true; return; }
 
-    constexpr size_t MID_MAX = (size_t)MidCfg<T>::MAXN;
+    const bool small_scene = n <= MID_SCENE_SPLIT;
+    const size_t MID_MAX = small_scene ? (size_t)MidSmallScene<T>::MAXN : (size_t)MidLargeScene<T>::MAXN;
     const size_t max_big = n / (MID_MAX + 1) + 2;       // simultaneously active nodes with > MID_MAX shapes
-    const size_t max_mid2 = n / (SMALL_MAX + 1) + 2;     // workgroup tier: nodes with 65..MidB::MAXN shapes
+    const size_t max_mid2 = n / (SMALL_MAX + 1) + 2;     // workgroup tier: nodes with 65..mid_max shapes
     const size_t max_tiles = n / TILE + max_big + 2;
     t->aabbs.reserve(n * 6 * sizeof(T));
     t->nodes.reserve(t->n_nodes * sizeof(typename Tr::Node));
@@ -1231,6 +1241,7 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     a.ctr = t->ctr.as<uint32_t>();
     a.rootkeys = reinterpret_cast<Key*>(reinterpret_cast<char*>(t->ctr.p) + ROOTKEY_OFF);
     a.n = (uint32_t)n;
+    a.mid_max = (uint32_t)MID_MAX;
 
     // counters and root keys were reset at the end of the previous build of this tree (off the critical path)
     if (!t->ctr_ready) hipLaunchKernelGGL(k_init<T>, dim3(1), dim3(256), 0, st, a);
@@ -1260,7 +1271,8 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     uint32_t mid2_done = 0, small_done = 0;
     while (true) {
         if (n > (size_t)SMALL_MAX)
-            hipLaunchKernelGGL((k_mid<T, MidB<T>>), dim3(mid2_grid), dim3(MidB<T>::THREADS), 0, st, a, mid2_done);
+            if (small_scene) hipLaunchKernelGGL((k_mid<T, MidSmallScene<T>>), dim3(mid2_grid), dim3(MidSmallScene<T>::THREADS), 0, st, a, mid2_done);
+            else hipLaunchKernelGGL((k_mid<T, MidLargeScene<T>>), dim3(mid2_grid), dim3(MidLargeScene<T>::THREADS), 0, st, a, mid2_done);
         hipLaunchKernelGGL(k_small<T>, dim3(small_grid), dim3(256), 0, st, a, small_done);
         if (flatten_after) flatten_tree<T>(t);   // optimistic too: redone if the build turns out to be unfinished
         BVH_HIP(hipMemcpyAsync(pin, a.ctr, ROOTKEY_OFF, hipMemcpyDeviceToHost, st));

@@ -133,7 +133,7 @@ def test_parity_config4_f64(eng, orc):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 64, 65, 66, 127, 128, 129, 1000, 1024, 1025, 4099])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 63, 64, 65, 66, 127, 128, 129, 767, 768, 769, 1000, 1024, 1025, 1536, 1537, 4099])
 def test_parity_ragged_sizes(eng, orc, n, dtype):
     """sizes around the wave (64) and tile (1024) boundaries of the two builder tiers."""
     rng = np.random.default_rng(n)
@@ -792,6 +792,28 @@ def test_refit_1_2m_triangles_three_passes(eng, orc):
     assert bvh.nodes.tobytes() == orc.refit(nodes0, a1).tobytes()
     bvh.refit(aabbs)
     assert bvh.nodes.tobytes() == nodes0.tobytes()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_parity_large_scene_tier_geometry(eng, orc, dtype):
+    """above 250 000 shapes the builder hands nodes of up to 1536 (f64: 1024) shapes to 256-thread workgroups instead of
+    768 / 384 (build.hip MidSmallScene / MidLargeScene): 300 000 triangles, nodes / flat / CSR byte-identical to the oracle."""
+    from bvh_amd import testbase as tb
+    _, aabbs = tb.create_n_cubes(25_000)
+    aabbs = aabbs.astype(dtype)
+    bvh = eng.Bvh.from_aabbs(aabbs)
+    ot = orc.build(aabbs, threads=min(8, orc.max_threads()))
+    assert bvh.nodes.tobytes() == ot.nodes.tobytes()
+    assert np.array_equal(bvh.shape_nodes, ot.shape_node)
+    flat = bvh.flatten()
+    oflat = orc.flatten(ot.nodes)
+    assert flat.nodes.tobytes() == oflat.tobytes()
+    rays = orc.create_rays(0, 50_000)
+    if dtype == np.float64:
+        rays = orc.make_rays(rays["o"], rays["d"], np.float64)
+    off, idx, _, _ = flat.traverse_batch(_rb(eng, rays))
+    ooff, oidx, _, _ = orc.traverse_flat(oflat, aabbs, rays, threads=orc.max_threads())
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
 
 
 def test_parity_1_2m_triangles(eng, orc):
