@@ -1246,7 +1246,10 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     // counters and root keys were reset at the end of the previous build of this tree (off the critical path)
     if (!t->ctr_ready) hipLaunchKernelGGL(k_init<T>, dim3(1), dim3(256), 0, st, a);
     t->ctr_ready = false;
-    const int prep_grid = (int)std::min<size_t>((n + 1023) / 1024, 1024);
+#ifndef BVH_PREP_PER_WG
+#define BVH_PREP_PER_WG 1024
+#endif
+    const int prep_grid = (int)std::min<size_t>((n + BVH_PREP_PER_WG - 1) / BVH_PREP_PER_WG, 1024);   // 256 / 512 / 1024 / 2048 shapes per workgroup measured
     hipLaunchKernelGGL(k_prep<T>, dim3(prep_grid), dim3(256), 0, st, a);   // + aabbs copy + root item
 
     const int tile_grid = (int)std::min<size_t>(max_tiles, 2048);
