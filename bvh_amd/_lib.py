@@ -13,7 +13,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("BVH_AMD_SO") or os.path.join(HERE, "libbvh_mi355x.so")  # BVH_AMD_SO: developer profiling builds only
 
-OK, INVALID_ARG, HIP_ERROR, OOM, OVERFLOW, NO_DEVICE, DTYPE_MISMATCH, NOT_FLATTENED = range(8)
+OK, INVALID_ARG, HIP_ERROR, OOM, OVERFLOW, NO_DEVICE, DTYPE_MISMATCH, NOT_FLATTENED, RCCL_ERROR = range(9)
+COMM_ID_BYTES = 128
+BCAST_TRIANGLES = 1
 F32, F64 = 0, 1
 HOST, DEVICE = 0, 1
 NONE = 0xFFFFFFFF
@@ -79,6 +81,12 @@ SYMBOLS = [
     ("bvhgpu_refit_f64", _i, [_vp, _vp, _sz, _i]),
     ("bvhgpu_rebuild_flat_f32", _i, [_vp, _vp, _sz, _i]),
     ("bvhgpu_rebuild_flat_f64", _i, [_vp, _vp, _sz, _i]),
+    ("bvhgpu_rebuild_flat_async_f32", _i, [_vp, _vp, _sz, _i]),
+    ("bvhgpu_rebuild_flat_async_f64", _i, [_vp, _vp, _sz, _i]),
+    ("bvhgpu_tree_wait", _i, [_vp]),
+    ("bvhgpu_traverse_async_f32", _i, [_vp, _vp, _sz, _i, _u, _pp]),
+    ("bvhgpu_traverse_async_f64", _i, [_vp, _vp, _sz, _i, _u, _pp]),
+    ("bvhgpu_hits_wait", _i, [_vp]),
     ("bvhgpu_tree_destroy", None, [_vp]),
     ("bvhgpu_tree_info", _i, [_vp, C.POINTER(_i), C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_sz)]),
     ("bvhgpu_tree_nodes", _i, [_vp, _vp, _i]),
@@ -91,6 +99,13 @@ SYMBOLS = [
     ("bvhgpu_scene_nbytes", _i, [_vp, C.POINTER(_sz)]),
     ("bvhgpu_scene_export", _i, [_vp, _vp, _i]),
     ("bvhgpu_scene_import", _i, [_vp, _vp, _sz, _i, _pp]),
+    ("bvhgpu_comm_unique_id", _i, [_vp]),
+    ("bvhgpu_comm_init_rank", _i, [_vp, _i, _i, _vp, _pp]),
+    ("bvhgpu_comm_init_all", _i, [_pp, _i, _pp]),
+    ("bvhgpu_comm_info", _i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
+    ("bvhgpu_comm_destroy", None, [_vp]),
+    ("bvhgpu_bcast", _i, [_vp, _pp, _i]),
+    ("bvhgpu_bcast_known", _i, [_vp, _pp, _i, _i, _sz, _u]),
     ("bvhgpu_rays_new_f32", _i, [_vp, _vp, _vp, _sz, _i, _vp, _i]),
     ("bvhgpu_rays_new_f64", _i, [_vp, _vp, _vp, _sz, _i, _vp, _i]),
     ("bvhgpu_gen_rays_f32", _i, [_vp, C.c_uint64, _sz, _vp, _vp]),
@@ -122,6 +137,8 @@ SYMBOLS = [
 ]
 TUNE_TRAVERSE_VARIANT = 0
 TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_TRAVERSE_LDS_SLOTS, TUNE_TRAVERSE_LDS_THREADS, TUNE_TRAVERSE_SPLIT = 3, 4, 5, 6
+TUNE_WIDE_ITEMS_LOG4, TUNE_WIDE_STACK_LDS, TUNE_WIDE_WG_PER_CU, TUNE_WIDE_THREADS, TUNE_WIDE_SLOTS = 1, 2, 7, 8, 9
+ABI_VERSION = 2
 
 _lib = None
 
@@ -149,7 +166,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.bvhgpu_abi_version() != 1:
+    if lib.bvhgpu_abi_version() != ABI_VERSION:
         raise ImportError("libbvh_mi355x.so ABI version mismatch")
     _lib = lib
     return lib

@@ -290,6 +290,26 @@ class _Hits:
         self.h = C.c_void_p()
         _live.add(self)
 
+    def wait(self) -> dict:
+        """bvhgpu_hits_wait: complete an asynchronous batch; returns the stats dict of traverse_batch."""
+        lib = _lib.load()
+        check(lib.bvhgpu_hits_wait(self.h), self.ctx._h)
+        total = C.c_uint64()
+        st = _lib.TraverseStats()
+        check(lib.bvhgpu_hits_info(self.h, None, C.byref(total), C.byref(st)), self.ctx._h)
+        return dict(hits=int(st.hits), visited=int(st.visited), leaf_visits=int(st.leaf_visits),
+                    device_steps=int(st.device_steps), wave_steps=int(st.wave_steps), total=int(total.value))
+
+    def fetch(self, n_rays: int):
+        """(offsets, indices) of the completed batch, copied to the host."""
+        lib = _lib.load()
+        total = C.c_uint64()
+        check(lib.bvhgpu_hits_info(self.h, None, C.byref(total), None), self.ctx._h)
+        offsets = np.zeros(n_rays + 1, dtype=np.uint32)
+        indices = np.zeros(total.value, dtype=np.uint32)
+        check(lib.bvhgpu_hits_fetch(self.h, ptr(offsets), ptr(indices), None, HOST), self.ctx._h)
+        return offsets, indices
+
     def close(self):
         if getattr(self, "h", None) and not _closing:
             _lib.load().bvhgpu_hits_destroy(self.h)
@@ -355,6 +375,16 @@ class _TreeBase:
         ts = np.zeros((total.value, 2), dtype=ft) if want_t else None
         check(lib.bvhgpu_hits_fetch(self._hits.h, ptr(offsets), ptr(indices), ptr(ts), HOST), self.ctx._h)
         return offsets, indices, ts, sd
+
+    def traverse_async(self, rays: RayBatch, hits: Optional["_Hits"] = None, flags: int = 0) -> "_Hits":
+        """bvhgpu_traverse_async_*: enqueue the batch (rays resident in HBM) and return at once; the tree may still be
+        building on the same stream.  `hits.wait()` completes it (and returns the stats dict)."""
+        if rays.sfx != self.sfx:
+            raise BvhGpuError(_lib.DTYPE_MISMATCH, "ray dtype differs from tree dtype")
+        hits = hits or self._hits
+        fn = getattr(_lib.load(), f"bvhgpu_traverse_async_{self.sfx}")
+        check(fn(self._t, rays._ptr(), rays.n, rays.mem, flags, C.byref(hits.h)), self.ctx._h)
+        return hits
 
     # ---- triangle stage -------------------------------------------------------------------
     def set_triangles(self, tris) -> None:
@@ -566,6 +596,19 @@ class Bvh(_TreeBase):
             ft = np.float32 if self.sfx == "f32" else np.float64
             a = np.ascontiguousarray(aabbs, dtype=ft).reshape(-1, 6)
             check(fn(self._t, ptr(a), len(a), HOST), self.ctx._h)
+        return self
+
+    def rebuild_async(self, aabbs) -> "Bvh":
+        """bvhgpu_rebuild_flat_async_*: FlatBvh::build enqueued on the context's stream, no wait (`aabbs`: a GPU tensor that
+        stays valid until wait()).  Everything that looks at the tree afterwards completes the build first."""
+        fn = getattr(_lib.load(), f"bvhgpu_rebuild_flat_async_{self.sfx}")
+        if not _is_device_tensor(aabbs):
+            raise BvhGpuError(_lib.INVALID_ARG, "rebuild_async takes shape AABBs that are resident in HBM")
+        check(fn(self._t, ptr(aabbs.data_ptr()), aabbs.numel() // 6, DEVICE), self.ctx._h)
+        return self
+
+    def wait(self) -> "Bvh":
+        check(_lib.load().bvhgpu_tree_wait(self._t), self.ctx._h)
         return self
 
     def refit(self, aabbs) -> "Bvh":

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libbvh_mi355x.so")
-SOURCES = ["capi.hip", "build.hip", "flatten.hip", "traverse.hip", "refit.hip", "obj.cpp"]
+SOURCES = ["capi.hip", "build.hip", "flatten.hip", "traverse.hip", "refit.hip", "comm.hip", "obj.cpp"]
 HEADERS = ["common.hpp", "engine.hpp", "obj.cpp", os.path.join("..", "..", "include", "bvh_mi355x.h")]
 # -fno-slp-vectorize: ROCm 7.2's SLP vectoriser + gfx950 instruction selection crash (SIGSEGV in
 # constrainRegClass) on the integer-key min/max folds of sah_select(); packed v_pk_* VALU ops are no
@@ -41,7 +41,10 @@ def is_stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return OUT
-    cmd = [hipcc()] + FLAGS + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    # librccl: the multi-GPU broadcast of the C ABI (comm.hip).  PyTorch-ROCm bundles its own librccl.so with the same soname
+    # (librccl.so.1): when torch is imported first (bvh_amd/_lib.py does that) the loader reuses that copy, like libamdhip64.
+    rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
+    cmd = [hipcc()] + FLAGS + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES] + [f"-L{rocm_lib}", "-lrccl", f"-Wl,-rpath,{rocm_lib}"]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)

@@ -32,6 +32,12 @@ constexpr int MAXLV = 96;        // counter slots (levels beyond reuse the last 
 constexpr int CTR_SMALL = 0;     // u32: number of small items (<= 64 shapes, wave-subtree tier)
 constexpr int CTR_TICKET = 3;    // u32: k_prep arrival ticket (the last workgroup creates the root item)
 constexpr int CTR_MID2 = 2;      // u32: number of workgroup-tier items (65 .. BuildArgs::mid_max shapes)
+constexpr int CTR_FLAGS = 4;     // u32: BUILD_FLAG_* bits raised by the kernels, read back by the host with the counters
+constexpr uint32_t BUILD_FLAG_NONFINITE = 1u;    // a shape AABB holds NaN / ±inf, or the root centroid extent overflows: the
+                                                 // reference panics there (bvh_node.rs:214-217, `to_usize().unwrap()`); nothing is built
+constexpr uint32_t BUILD_FLAG_EMPTY_SPLIT = 2u;  // some node had no winning SAH candidate (NaN / inf costs): its children carry
+                                                 // Aabb::empty() bounds (bvh_node.rs:225-230), so a child box is NOT the join of its
+                                                 // grandchildren and traversal must test every ancestor (no wide walk)
 // Workgroup tier: nodes of 65 .. mid_max shapes, one workgroup per node (its AABBs live in 30-60 KB of
 // LDS, so every CU runs several): it splits down to <= 64-shape children for the wave tier.  (A second, larger
 // workgroup tier for 1025..4096 shapes existed until the level-synchronous tier got down to ~12 µs per level — below
@@ -117,12 +123,15 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T>
         for (uint32_t i = threadIdx.x; i < a.n_slots; i += blockDim.x) a.slot_entry[i] = NONE;
     const bool copy = a.src != a.aabbs;
     T* own = const_cast<T*>(a.aabbs);
+    bool bad = false;   // input contract: the reference panics on NaN / inf centroids (bvh_node.rs:214-217); a single shape is never bucketed
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x) {
         a.idx[0][i] = i;
         const T* b = a.src + 6 * (size_t)i;
         T bx[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) bx[k] = b[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) bad = bad || !(fabs(bx[k]) < Tr::inf());   // NaN or ±inf (the comparison is false for NaN)
         if (copy) {
 #pragma unroll
             for (int k = 0; k < 6; k++) own[6 * (size_t)i + k] = bx[k];
@@ -154,6 +163,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T>
             }
         }
     }
+    if (a.n > 1 && __any(bad) && lane_id() == 0) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_NONFINITE);
     __syncthreads();
     if (threadIdx.x < STAT_KEYS) {
         int j = threadIdx.x;
@@ -175,7 +185,15 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T>
             A[k] = Tr::unkey(__hip_atomic_load(&a.rootkeys[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             C[k] = Tr::unkey(__hip_atomic_load(&a.rootkeys[6 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
-        push_item<T>(a, 0, 0u, 0u, 0u, a.n, A, C, 1u, (int)threadIdx.x);
+        uint32_t flags = __hip_atomic_load(&a.ctr[CTR_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.n > 1) {   // finite boxes whose centroid extent overflows: (c - cmin) / ext is NaN for some shape → same panic
+            bool ovf = false;
+#pragma unroll
+            for (int k = 0; k < 3; k++) ovf = ovf || !(fabs(C[3 + k] - C[k]) < Tr::inf());
+            if (ovf) { flags |= BUILD_FLAG_NONFINITE; if (threadIdx.x == 0) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_NONFINITE); }
+        }
+        // invalid input: no root item, so every later kernel of the optimistic schedule finds empty queues
+        if (!(flags & BUILD_FLAG_NONFINITE)) push_item<T>(a, 0, 0u, 0u, 0u, a.n, A, C, 1u, (int)threadIdx.x);
     }
 }
 
@@ -370,7 +388,7 @@ template <typename T> __device__ __forceinline__ void box_join(T* a, const T* b)
 // ------------------------------------------------------------------------------------------------
 template <typename T, typename KeyPtr, typename CntPtr>
 __device__ __forceinline__ uint32_t sah_select(KeyPtr keys, CntPtr cnts, const T* A, bool degen, uint32_t* cnt, T* AL,
-                                               T* CL, T* AR, T* CR) {
+                                               T* CL, T* AR, T* CR, bool& no_winner) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
     // Joins are exact, so fold(empty, join) over buckets 0..s / s+1..5 (utils.rs:88-94) equals running
@@ -418,6 +436,7 @@ __device__ __forceinline__ uint32_t sah_select(KeyPtr keys, CntPtr cnts, const T
         bool take = degen ? (s == 0) : (cost < min_cost);       // strict <, first wins (:239)
         if (take) { min_cost = cost; best = s; }
     }
+    no_winner = best < 0;
     if (best < 0) {
         box_empty(AL); box_empty(CL); box_empty(AR); box_empty(CR);
         return cnt[0];
@@ -494,7 +513,9 @@ template <typename T> __device__ void select_role(const BuildArgs<T>& a, int lev
 
         uint32_t cnt[NUM_BUCKETS];
         T AL[6], CL[6], AR[6], CR[6];
-        const uint32_t nl = sah_select<T>(st->k, st->cnt, A, degen, cnt, AL, CL, AR, CR);
+        bool no_winner;
+        const uint32_t nl = sah_select<T>(st->k, st->cnt, A, degen, cnt, AL, CL, AR, CR, no_winner);
+        if (no_winner && lane == 0) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_EMPTY_SPLIT);
         const uint32_t li = ni + 1;                 // :140
         const uint32_t ri = li + (2 * nl - 1);      // :138,142
         if (lane == 0) {
@@ -905,7 +926,9 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
                     uint32_t cin[NUM_BUCKETS];
 #pragma unroll
                     for (int b = 0; b < NUM_BUCKETS; b++) cin[b] = m->base[b + 1] - m->base[b];
-                    nl = sah_select<T>(s_keys + lane * NUM_BUCKETS * STAT_KEYS, cin, m->A, m->degen != 0, cnt, AL, CL, AR, CR);
+                    bool no_winner;
+                    nl = sah_select<T>(s_keys + lane * NUM_BUCKETS * STAT_KEYS, cin, m->A, m->degen != 0, cnt, AL, CL, AR, CR, no_winner);
+                    if (no_winner) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_EMPTY_SPLIT);
                     cl = nl; cr = m->count - nl;
                     const uint32_t ni = m->ni, li = ni + 1, ri = li + (2 * nl - 1);  // bvh_node.rs:138-142
                     typename Tr::Node* nd = &a.nodes[ni];
@@ -1153,6 +1176,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
             for (int k = 0; k < 6; k++) { AL[k] = kl[k]; AR[k] = kr[k]; Cn[k] = left ? kl[6 + k] : kr[6 + k]; }
         }
         if (!taken) { box_empty(AL); box_empty(AR); box_empty(Cn); }
+        if (!done && !taken && lane == lo) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_EMPTY_SPLIT);
         if (!done) {
             const uint32_t li = ni + 1;
             const uint32_t ri = li + (uint32_t)(2 * nl - 1);
@@ -1179,50 +1203,17 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
 }
 
 // ------------------------------------------------------------------------------------------------
-// host driver
+// host driver.  build_enqueue puts the whole optimistic schedule (and the counter readback) on the stream without
+// a host round trip; build_finalize waits for it, validates the input contract and finishes an unbalanced tree level by
+// level.  The synchronous entry points run one after the other; the *_async entry points of the C ABI return after the
+// enqueue and leave the finalize to bvhgpu_tree_wait / bvhgpu_hits_wait.
 // ------------------------------------------------------------------------------------------------
-template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after) {
+template <typename T> static BuildArgs<T> make_args(bvhgpu_tree* t, const T* src) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
-    bvhgpu_ctx* ctx = t->ctx;
-    hipStream_t st = ctx->stream;
-    t->built = false; t->flattened = false;
-    t->n = n; t->n_nodes = n ? 2 * n - 1 : 0;
-    t->n_flat = n >= 2 ? 3 * n - 2 : n;
-    t->n_trav = n >= 2 ? 2 * n - 2 : n;
-    t->levels = 0;
-    if (n == 0) { t->built = true; return; }
-
-    const bool small_scene = n <= MID_SCENE_SPLIT;
-    const size_t MID_MAX = small_scene ? (size_t)MidSmallScene<T>::MAXN : (size_t)MidLargeScene<T>::MAXN;
-    const size_t max_big = n / (MID_MAX + 1) + 2;       // simultaneously active nodes with > MID_MAX shapes
-    const size_t max_mid2 = n / (SMALL_MAX + 1) + 2;     // workgroup tier: nodes with 65..mid_max shapes
-    const size_t max_tiles = n / TILE + max_big + 2;
-    t->aabbs.reserve(n * 6 * sizeof(T));
-    t->nodes.reserve(t->n_nodes * sizeof(typename Tr::Node));
-    t->node_start.reserve(t->n_nodes * 4);
-    t->node_count.reserve(t->n_nodes * 4);
-    t->shape_node.reserve(n * 4);
-    t->node_slot.reserve(t->n_nodes * 2);
-    t->slot_entry.reserve(TopCfg<T>::SLOTS * 4);
-    t->idx[0].reserve(n * 4);
-    t->idx[1].reserve(n * 4);
-    t->bk.reserve(n);
-    for (int i = 0; i < 2; i++) {
-        t->big[i].reserve(max_big * sizeof(Item<T>));
-        t->stats[i].reserve(max_big * STAT_REP * sizeof(ItemStats<T>));
-        t->tile_item[i].reserve(max_tiles * 4);
-    }
-    t->mid2.reserve(max_mid2 * sizeof(Item<T>));
-    t->small.reserve((n + 1) * sizeof(Item<T>));
-    t->tile_cnt.reserve(max_tiles * NUM_BUCKETS * 4);
-    const void* ctr_before = t->ctr.p;
-    t->ctr.reserve(ROOTKEY_OFF + STAT_KEYS * sizeof(Key));
-    if (t->ctr.p != ctr_before) t->ctr_ready = false;   // a fresh buffer has not been zeroed by the previous build
-
     BuildArgs<T> a;
     a.aabbs = t->aabbs.as<T>();
-    a.src = aabbs_dev;
+    a.src = src ? src : t->aabbs.as<T>();
     a.nodes = t->nodes.as<typename Tr::Node>();
     a.node_start = t->node_start.as<uint32_t>();
     a.node_count = t->node_count.as<uint32_t>();
@@ -1240,9 +1231,82 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
     a.tile_cnt = t->tile_cnt.as<uint32_t>();
     a.ctr = t->ctr.as<uint32_t>();
     a.rootkeys = reinterpret_cast<Key*>(reinterpret_cast<char*>(t->ctr.p) + ROOTKEY_OFF);
-    a.n = (uint32_t)n;
-    a.mid_max = (uint32_t)MID_MAX;
+    a.n = (uint32_t)t->n;
+    const bool small_scene = t->n <= MID_SCENE_SPLIT;
+    a.mid_max = (uint32_t)(small_scene ? MidSmallScene<T>::MAXN : MidLargeScene<T>::MAXN);
+    return a;
+}
 
+template <typename T> struct BuildGrid {
+    size_t max_big, max_mid2, max_tiles;
+    int tile_grid, sel_grid, mid2_grid, small_grid;
+    BuildGrid(const bvhgpu_tree* t, size_t mid_max) {
+        const size_t n = t->n;
+        max_big = n / (mid_max + 1) + 2;       // simultaneously active nodes with > mid_max shapes
+        max_mid2 = n / (SMALL_MAX + 1) + 2;    // workgroup tier: nodes with 65..mid_max shapes
+        max_tiles = n / TILE + max_big + 2;
+        tile_grid = (int)std::min<size_t>(max_tiles, 2048);
+        sel_grid = (int)std::min<size_t>((max_big + 3) / 4, 1024);
+        mid2_grid = (int)std::min<size_t>(max_mid2, (size_t)t->ctx->n_cu * 4);
+        small_grid = (int)std::min<size_t>((n + 3) / 4, (size_t)t->ctx->n_cu * 8);
+    }
+};
+
+template <typename T> static void run_level(bvhgpu_tree* t, const BuildArgs<T>& a, const BuildGrid<T>& g, int L) {
+    hipStream_t st = t->ctx->stream;
+    hipLaunchKernelGGL(k_bin<T>, dim3(g.tile_grid), dim3(256), 0, st, a, L);
+    hipLaunchKernelGGL(k_split<T>, dim3(g.sel_grid + g.tile_grid), dim3(256), 0, st, a, L, (uint32_t)g.sel_grid);
+}
+// workgroup tier over the items queued from `mid2_done` on, then the wave tier from `small_done` on
+template <typename T> static void run_lower_tiers(bvhgpu_tree* t, const BuildArgs<T>& a, const BuildGrid<T>& g, uint32_t mid2_done,
+                                                  uint32_t small_done) {
+    hipStream_t st = t->ctx->stream;
+    if (t->n > (size_t)SMALL_MAX) {
+        if (t->n <= MID_SCENE_SPLIT) hipLaunchKernelGGL((k_mid<T, MidSmallScene<T>>), dim3(g.mid2_grid), dim3(MidSmallScene<T>::THREADS), 0, st, a, mid2_done);
+        else hipLaunchKernelGGL((k_mid<T, MidLargeScene<T>>), dim3(g.mid2_grid), dim3(MidLargeScene<T>::THREADS), 0, st, a, mid2_done);
+    }
+    hipLaunchKernelGGL(k_small<T>, dim3(g.small_grid), dim3(256), 0, st, a, small_done);
+}
+
+template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after) {
+    using Tr = Traits<T>;
+    using Key = typename Tr::Key;
+    bvhgpu_ctx* ctx = t->ctx;
+    hipStream_t st = ctx->stream;
+    t->built = false; t->flattened = false; t->pending_build = false; t->exact_only = false;
+    if (n != t->n) t->has_tris = false;   // one triangle per shape: a different shape count invalidates the vertex array
+    t->n = n; t->n_nodes = n ? 2 * n - 1 : 0;
+    t->n_flat = n >= 2 ? 3 * n - 2 : n;
+    t->n_trav = n >= 2 ? 2 * n - 2 : n;
+    t->levels = 0;
+    if (n == 0) { t->built = true; t->flattened = flatten_after; return; }
+
+    const size_t MID_MAX = n <= MID_SCENE_SPLIT ? (size_t)MidSmallScene<T>::MAXN : (size_t)MidLargeScene<T>::MAXN;
+    const BuildGrid<T> g(t, MID_MAX);
+    t->aabbs.reserve(n * 6 * sizeof(T));
+    // the optimistic flatten may run over nodes an unfinished build has not written yet: never-written memory must at least
+    // be harmless (k_flatten also bounds-checks what it reads from a node)
+    if (t->nodes.reserve(t->n_nodes * sizeof(typename Tr::Node))) BVH_HIP(hipMemsetAsync(t->nodes.p, 0, t->nodes.cap, st));
+    if (t->node_start.reserve(t->n_nodes * 4)) BVH_HIP(hipMemsetAsync(t->node_start.p, 0, t->node_start.cap, st));
+    if (t->node_count.reserve(t->n_nodes * 4)) BVH_HIP(hipMemsetAsync(t->node_count.p, 0, t->node_count.cap, st));
+    t->shape_node.reserve(n * 4);
+    if (t->node_slot.reserve(t->n_nodes * 2)) BVH_HIP(hipMemsetAsync(t->node_slot.p, 0xFF, t->node_slot.cap, st));
+    t->slot_entry.reserve(TopCfg<T>::SLOTS * 4);
+    t->idx[0].reserve(n * 4);
+    t->idx[1].reserve(n * 4);
+    t->bk.reserve(n);
+    for (int i = 0; i < 2; i++) {
+        t->big[i].reserve(g.max_big * sizeof(Item<T>));
+        t->stats[i].reserve(g.max_big * STAT_REP * sizeof(ItemStats<T>));
+        t->tile_item[i].reserve(g.max_tiles * 4);
+    }
+    t->mid2.reserve(g.max_mid2 * sizeof(Item<T>));
+    t->small.reserve((n + 1) * sizeof(Item<T>));
+    t->tile_cnt.reserve(g.max_tiles * NUM_BUCKETS * 4);
+    if (t->ctr.reserve(ROOTKEY_OFF + STAT_KEYS * sizeof(Key))) t->ctr_ready = false;   // a fresh buffer has not been zeroed by the previous build
+    if (!t->pin) BVH_HIP(hipHostMalloc(&t->pin, ROOTKEY_OFF, hipHostMallocDefault));
+
+    const BuildArgs<T> a = make_args<T>(t, aabbs_dev);
     // counters and root keys were reset at the end of the previous build of this tree (off the critical path)
     if (!t->ctr_ready) hipLaunchKernelGGL(k_init<T>, dim3(1), dim3(256), 0, st, a);
     t->ctr_ready = false;
@@ -1250,58 +1314,76 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
 #define BVH_PREP_PER_WG 1024
 #endif
     const int prep_grid = (int)std::min<size_t>((n + BVH_PREP_PER_WG - 1) / BVH_PREP_PER_WG, 1024);   // 256 / 512 / 1024 / 2048 shapes per workgroup measured
-    hipLaunchKernelGGL(k_prep<T>, dim3(prep_grid), dim3(256), 0, st, a);   // + aabbs copy + root item
+    hipLaunchKernelGGL(k_prep<T>, dim3(prep_grid), dim3(256), 0, st, a);   // + aabbs copy + input validation + root item
 
-    const int tile_grid = (int)std::min<size_t>(max_tiles, 2048);
-    const int sel_grid = (int)std::min<size_t>((max_big + 3) / 4, 1024);
-    const int mid2_grid = (int)std::min<size_t>(max_mid2, (size_t)ctx->n_cu * 4);
-    const int small_grid = (int)std::min<size_t>((n + 3) / 4, (size_t)ctx->n_cu * 8);
-    uint32_t* pin = reinterpret_cast<uint32_t*>(ctx->pinned);
-    auto run_level = [&](int L) {
-        hipLaunchKernelGGL(k_bin<T>, dim3(tile_grid), dim3(256), 0, st, a, L);
-        hipLaunchKernelGGL(k_split<T>, dim3(sel_grid + tile_grid), dim3(256), 0, st, a, L, (uint32_t)sel_grid);
-    };
     // Optimistic schedule with no host round trip: enough level-synchronous passes for a balanced
     // tree, then the workgroup tier over everything queued so far, then the wave tier.  ONE readback
     // at the end checks that nothing is left in the level queue; unbalanced trees continue from there.
     int level = 0;
     if (n > (size_t)MID_MAX) {
-        int fixed = 1;   // levels of a balanced tree; an unbalanced one continues below, one host round trip per level
+        int fixed = 1;   // levels of a balanced tree; an unbalanced one continues in build_finalize, one host round trip per level
         for (size_t m = n; m > (size_t)MID_MAX; m = (m + 1) / 2) fixed++;
         if (fixed > MAXLV - 4) fixed = MAXLV - 4;
-        for (; level < fixed; level++) run_level(level);
+        for (; level < fixed; level++) run_level<T>(t, a, g, level);
     }
-    uint32_t mid2_done = 0, small_done = 0;
-    while (true) {
-        if (n > (size_t)SMALL_MAX)
-            if (small_scene) hipLaunchKernelGGL((k_mid<T, MidSmallScene<T>>), dim3(mid2_grid), dim3(MidSmallScene<T>::THREADS), 0, st, a, mid2_done);
-            else hipLaunchKernelGGL((k_mid<T, MidLargeScene<T>>), dim3(mid2_grid), dim3(MidLargeScene<T>::THREADS), 0, st, a, mid2_done);
-        hipLaunchKernelGGL(k_small<T>, dim3(small_grid), dim3(256), 0, st, a, small_done);
-        if (flatten_after) flatten_tree<T>(t);   // optimistic too: redone if the build turns out to be unfinished
-        BVH_HIP(hipMemcpyAsync(pin, a.ctr, ROOTKEY_OFF, hipMemcpyDeviceToHost, st));
-        BVH_HIP(hipStreamSynchronize(st));
-        BVH_HIP(hipGetLastError());
-        mid2_done = pin[CTR_MID2];
-        small_done = pin[CTR_SMALL];
-        if (n <= (size_t)MID_MAX || pin[CTR_LEVEL0 + 2 * lvl_slot(level)] == 0) break;
-        // slow path: the level queue is not empty yet — one more level per host round trip
+    run_lower_tiers<T>(t, a, g, 0u, 0u);
+    if (flatten_after) flatten_tree<T>(t);   // optimistic too: redone if the build turns out to be unfinished
+    BVH_HIP(hipMemcpyAsync(t->pin, a.ctr, ROOTKEY_OFF, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_init<T>, dim3(1), dim3(256), 0, st, a);   // reset for the next build of this tree (behind the readback)
+    t->ctr_ready = true;
+    t->pending_build = true; t->pend_level = level; t->pend_flatten = flatten_after;
+}
+
+template <typename T> void build_finalize(bvhgpu_tree* t) {
+    if (!t->pending_build) return;
+    t->pending_build = false;
+    bvhgpu_ctx* ctx = t->ctx;
+    hipStream_t st = ctx->stream;
+    BVH_HIP(hipStreamSynchronize(st));
+    BVH_HIP(hipGetLastError());
+    const size_t n = t->n;
+    const size_t MID_MAX = n <= MID_SCENE_SPLIT ? (size_t)MidSmallScene<T>::MAXN : (size_t)MidLargeScene<T>::MAXN;
+    uint32_t* pin = reinterpret_cast<uint32_t*>(t->pin);
+    if (pin[CTR_FLAGS] & BUILD_FLAG_NONFINITE) { t->flattened = false; throw HipFail{hipErrorInvalidValue, "NONFINITE", __LINE__}; }
+    int level = t->pend_level;
+    if (n > (size_t)MID_MAX && pin[CTR_LEVEL0 + 2 * lvl_slot(level)] != 0) {
+        // slow path: the level queue is not empty yet (unbalanced tree) — one more level per host round trip.  The counters
+        // were zeroed behind the readback: put them back first.
+        const BuildGrid<T> g(t, MID_MAX);
+        const BuildArgs<T> a = make_args<T>(t, nullptr);
+        BVH_HIP(hipMemcpyAsync(a.ctr, t->pin, ROOTKEY_OFF, hipMemcpyHostToDevice, st));
+        t->ctr_ready = false;
+        uint32_t mid2_done = pin[CTR_MID2], small_done = pin[CTR_SMALL];
         while (true) {
             if (level + 1 >= MAXLV - 2)  // recycle the slot the next level will append to
                 BVH_HIP(hipMemsetAsync(a.ctr + CTR_LEVEL0 + 2 * lvl_slot(level + 1), 0, 8, st));
-            run_level(level);
+            run_level<T>(t, a, g, level);
             level++;
-            BVH_HIP(hipMemcpyAsync(pin, a.ctr, ROOTKEY_OFF, hipMemcpyDeviceToHost, st));
+            BVH_HIP(hipMemcpyAsync(t->pin, a.ctr, ROOTKEY_OFF, hipMemcpyDeviceToHost, st));
             BVH_HIP(hipStreamSynchronize(st));
             if (pin[CTR_LEVEL0 + 2 * lvl_slot(level)] == 0) break;
         }
+        run_lower_tiers<T>(t, a, g, mid2_done, small_done);
+        BVH_HIP(hipMemcpyAsync(t->pin, a.ctr, ROOTKEY_OFF, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_init<T>, dim3(1), dim3(256), 0, st, a);
+        t->ctr_ready = true;
+        if (t->pend_flatten) flatten_tree<T>(t);   // the optimistic one ran over an unfinished tree
+        BVH_HIP(hipStreamSynchronize(st));
+        BVH_HIP(hipGetLastError());
+        t->redone = true;   // whoever traversed the optimistic result must do it again
     }
     // diagnostic: number of level-synchronous passes that had work
     int used = level;
     while (used > 0 && used - 1 < MAXLV - 2 && pin[CTR_LEVEL0 + 2 * (used - 1)] == 0) used--;
     t->levels = used;
+    t->exact_only = (pin[CTR_FLAGS] & BUILD_FLAG_EMPTY_SPLIT) != 0;
     t->built = true;
-    hipLaunchKernelGGL(k_init<T>, dim3(1), dim3(256), 0, st, a);   // reset for the next build of this tree
-    t->ctr_ready = true;
+}
+
+template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after) {
+    build_enqueue<T>(t, aabbs_dev, n, flatten_after);
+    build_finalize<T>(t);
+    t->redone = false;
 }
 
 #ifdef BVH_PROFILE_MID
@@ -1314,5 +1396,9 @@ void debug_mid_prof(unsigned long long* out, bool reset) {
 
 template void build_tree<float>(bvhgpu_tree*, const float*, size_t, bool);
 template void build_tree<double>(bvhgpu_tree*, const double*, size_t, bool);
+template void build_enqueue<float>(bvhgpu_tree*, const float*, size_t, bool);
+template void build_enqueue<double>(bvhgpu_tree*, const double*, size_t, bool);
+template void build_finalize<float>(bvhgpu_tree*);
+template void build_finalize<double>(bvhgpu_tree*);
 
 }  // namespace bvhgpu

@@ -24,6 +24,9 @@ template <typename F> int guarded(bvhgpu_ctx* ctx, F&& f) {
         char buf[512];
         snprintf(buf, sizeof buf, "%s failed: %s (line %d)", e.what, hipGetErrorString(e.err), e.line);
         if (e.what && std::strcmp(e.what, "OVERFLOW") == 0) return fail(ctx, BVHGPU_OVERFLOW, "more than 2^32-1 hits in one batch");
+        if (e.what && std::strcmp(e.what, "NONFINITE") == 0)
+            return fail(ctx, BVHGPU_INVALID_ARG, "shape AABBs contain NaN or infinity (or their centroid extent overflows): the reference panics on "
+                                                 "such input (bvh_node.rs:214-217, to_usize().unwrap()); nothing was built");
         if (e.what && std::strcmp(e.what, "ORDERED_DEPTH") == 0)
             return fail(ctx, BVHGPU_OVERFLOW, "tree deeper than the ordered iterator's 32-entry stack (child_distance_traverse.rs:36)");
         if (e.err == hipErrorOutOfMemory) return fail(ctx, BVHGPU_OOM, buf);
@@ -59,16 +62,29 @@ void free_tree_buffers(bvhgpu_tree* t) {
     t->big[0].release(); t->big[1].release(); t->mid2.release(); t->small.release();
     t->stats[0].release(); t->stats[1].release();
     t->tile_item[0].release(); t->tile_item[1].release(); t->tile_cnt.release(); t->ctr.release(); t->refit_seg.release();
+    t->wide.release(); t->wslot_node.release();
+    if (t->pin) { (void)hipHostFree(t->pin); t->pin = nullptr; }
+}
+
+// an asynchronous build may still be in flight: wait for it and finish / validate it (build.hip build_finalize)
+void ensure_built(bvhgpu_tree* t) {
+    if (!t->pending_build) return;
+    if (t->dtype == BVHGPU_F32) build_finalize<float>(t); else build_finalize<double>(t);
+}
+int settle(bvhgpu_tree* t) {   // entry points that look at a tree's state first complete its asynchronous build
+    if (!t->pending_build) return BVHGPU_OK;
+    return guarded(t->ctx, [&] { use_device(t->ctx); ensure_built(t); return (int)BVHGPU_OK; });
 }
 
 constexpr size_t MAX_SHAPES = (0xFFFFFFFFull - 1) / 3;  // flat indices are u32 (flat_bvh.rs:136)
 
-template <typename T> int do_build(bvhgpu_tree* t, const T* aabbs, size_t n, int mem, bool flat = false) {
+template <typename T> int do_build(bvhgpu_tree* t, const T* aabbs, size_t n, int mem, bool flat = false, bool async = false) {
     bvhgpu_ctx* ctx = t->ctx;
     if (n && !aabbs) return fail(ctx, BVHGPU_INVALID_ARG, "aabbs is NULL");
     if (n > MAX_SHAPES) return fail(ctx, BVHGPU_OVERFLOW, "too many shapes for u32 flat indices");
     if (mem != BVHGPU_HOST && mem != BVHGPU_DEVICE) return fail(ctx, BVHGPU_INVALID_ARG, "bad mem kind");
     use_device(ctx);
+    ensure_built(t);   // a previous asynchronous build of this tree
     if (ctx->timing) BVH_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     const T* dev = aabbs;
     if (n && mem == BVHGPU_HOST) {  // upload straight into the tree's own copy
@@ -76,7 +92,8 @@ template <typename T> int do_build(bvhgpu_tree* t, const T* aabbs, size_t n, int
         BVH_HIP(hipMemcpyAsync(t->aabbs.p, aabbs, n * 6 * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
         dev = t->aabbs.as<T>();
     }
-    build_tree<T>(t, dev, n, flat);
+    if (async) build_enqueue<T>(t, dev, n, flat);
+    else build_tree<T>(t, dev, n, flat);
     if (flat && n == 0) t->flattened = true;
     if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[1], ctx->stream)); ctx->ev_set |= 1u; }
     return BVHGPU_OK;
@@ -85,6 +102,7 @@ template <typename T> int do_build(bvhgpu_tree* t, const T* aabbs, size_t n, int
 // the shapes moved: same topology, boxes recomputed (refit.hip)
 template <typename T> int do_refit(bvhgpu_tree* t, const T* aabbs, size_t n, int mem) {
     bvhgpu_ctx* ctx = t->ctx;
+    ensure_built(t);
     if (!t->built) return fail(ctx, BVHGPU_INVALID_ARG, "refit needs a tree that was built here (imported scenes carry no BvhNode array)");
     if (n != t->n) return fail(ctx, BVHGPU_INVALID_ARG, "refit: the number of shapes differs from the tree's (build again)");
     if (n && !aabbs) return fail(ctx, BVHGPU_INVALID_ARG, "aabbs is NULL");
@@ -113,10 +131,13 @@ template <typename T> int new_build(bvhgpu_ctx* ctx, const T* aabbs, size_t n, i
 
 template <typename T>
 int do_traverse(bvhgpu_tree* tree, const typename Traits<T>::Ray* rays, size_t n_rays, int mem, unsigned flags,
-                bvhgpu_hits** hits) {
+                bvhgpu_hits** hits, bool async = false) {
     if (!tree) return BVHGPU_INVALID_ARG;
     bvhgpu_ctx* ctx = tree->ctx;
     if (!hits) return fail(ctx, BVHGPU_INVALID_ARG, "hits is NULL");
+    if (!async) { const int rc = settle(tree); if (rc != BVHGPU_OK) return rc; }
+    else if (mem != BVHGPU_DEVICE) return fail(ctx, BVHGPU_INVALID_ARG, "asynchronous traversal takes rays that are resident in HBM");
+    if (*hits && (*hits)->pend_async) return fail(ctx, BVHGPU_INVALID_ARG, "the result object still holds an asynchronous batch: call bvhgpu_hits_wait first");
     if (tree->dtype != Traits<T>::dtype) return fail(ctx, BVHGPU_DTYPE_MISMATCH, "tree dtype differs from ray dtype");
     if (!tree->flattened) return fail(ctx, BVHGPU_NOT_FLATTENED, "call bvhgpu_flatten first");
     if (n_rays && !rays) return fail(ctx, BVHGPU_INVALID_ARG, "rays is NULL");
@@ -126,7 +147,7 @@ int do_traverse(bvhgpu_tree* tree, const typename Traits<T>::Ray* rays, size_t n
     if ((flags & BVHGPU_TRAVERSE_T_SLICE) && (flags & (BVHGPU_TRAVERSE_TRIANGLES | BVHGPU_TRAVERSE_CLOSEST)))
         return fail(ctx, BVHGPU_INVALID_ARG, "T_SLICE cannot be combined with TRIANGLES / CLOSEST");
     if (flags & (BVHGPU_TRAVERSE_NEAREST_FIRST | BVHGPU_TRAVERSE_FARTHEST_FIRST)) {
-        if (!tree->built) return fail(ctx, BVHGPU_INVALID_ARG, "ordered traversal walks the BvhNode array: the tree must have been built here");
+        if (!tree->built && !tree->pending_build) return fail(ctx, BVHGPU_INVALID_ARG, "ordered traversal walks the BvhNode array: the tree must have been built here");
         if ((flags & BVHGPU_TRAVERSE_NEAREST_FIRST) && (flags & BVHGPU_TRAVERSE_FARTHEST_FIRST))
             return fail(ctx, BVHGPU_INVALID_ARG, "NEAREST_FIRST and FARTHEST_FIRST are alternatives");
         if (flags & (BVHGPU_TRAVERSE_T_SLICE | BVHGPU_TRAVERSE_STATS))
@@ -143,7 +164,13 @@ int do_traverse(bvhgpu_tree* tree, const typename Traits<T>::Ray* rays, size_t n
         *hits = h;
         const auto* dev = static_cast<const typename Traits<T>::Ray*>(
             to_device(ctx, rays, n_rays * sizeof(typename Traits<T>::Ray), mem, ctx->upload));
-        traverse_batch<T>(tree, dev, n_rays, flags, h);
+        if (async) {
+            h->force_binary = false; h->pend_attempts = 0;
+            traverse_enqueue<T>(tree, dev, n_rays, flags, h);
+            h->pend_async = true;
+        } else {
+            traverse_batch<T>(tree, dev, n_rays, flags, h);
+        }
         return (int)BVHGPU_OK;
     });
 }
@@ -225,6 +252,9 @@ int tree_from_flat(bvhgpu_ctx* ctx, const typename Traits<T>::Flat* flat, size_t
             heap[i] = h;
             if (flat[i].entry != NONE) stack.push_back(Frame{i, flat[i].exit, h, 0u});
         }
+        // FlatBvh::flatten only ever emits binary trees; an array that passes the index checks above but is not
+        // binary would leave the LDS slot table empty while traversal still starts at slot 2
+        if (!binary) return fail(ctx, BVHGPU_INVALID_ARG, "flat array is not a flattened binary tree (an entry has more than two children)");
         if (binary) {
             for (size_t i = 0; i < n_flat; i++) {
                 if (heap[i] < SLOTS) slot_entry[heap[i]] = (uint32_t)i;
@@ -286,6 +316,7 @@ template <typename T>
 int do_nearest(bvhgpu_tree* t, const T* points, size_t n, int mem, int kind, uint32_t* out_shape, T* out_dist) {
     if (!t) return BVHGPU_INVALID_ARG;
     bvhgpu_ctx* ctx = t->ctx;
+    { const int rc = settle(t); if (rc != BVHGPU_OK) return rc; }
     if (t->dtype != Traits<T>::dtype) return fail(ctx, BVHGPU_DTYPE_MISMATCH, "tree dtype differs from point dtype");
     if (!t->flattened) return fail(ctx, BVHGPU_NOT_FLATTENED, "call bvhgpu_flatten first");
     if (n && (!points || !out_shape || !out_dist)) return fail(ctx, BVHGPU_INVALID_ARG, "NULL argument");
@@ -341,6 +372,7 @@ const char* bvhgpu_status_string(int s) {
         case BVHGPU_NO_DEVICE: return "no MI355X / HIP device available";
         case BVHGPU_DTYPE_MISMATCH: return "dtype mismatch";
         case BVHGPU_NOT_FLATTENED: return "tree not flattened";
+        case BVHGPU_RCCL_ERROR: return "RCCL error";
         default: return "unknown status";
     }
 }
@@ -436,6 +468,57 @@ int bvhgpu_rebuild_flat_f64(bvhgpu_tree* t, const double* aabbs, size_t n, int m
     return guarded(t->ctx, [&] { return do_build<double>(t, aabbs, n, mem, true); });
 }
 
+// ---- asynchronous step ----
+int bvhgpu_rebuild_flat_async_f32(bvhgpu_tree* t, const float* aabbs, size_t n, int mem) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    if (t->dtype != BVHGPU_F32) return fail(t->ctx, BVHGPU_DTYPE_MISMATCH, "tree is f64");
+    return guarded(t->ctx, [&] { return do_build<float>(t, aabbs, n, mem, true, true); });
+}
+int bvhgpu_rebuild_flat_async_f64(bvhgpu_tree* t, const double* aabbs, size_t n, int mem) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    if (t->dtype != BVHGPU_F64) return fail(t->ctx, BVHGPU_DTYPE_MISMATCH, "tree is f32");
+    return guarded(t->ctx, [&] { return do_build<double>(t, aabbs, n, mem, true, true); });
+}
+int bvhgpu_tree_wait(bvhgpu_tree* t) {
+    if (!t) return BVHGPU_INVALID_ARG;
+    return settle(t);
+}
+int bvhgpu_traverse_async_f32(bvhgpu_tree* tree, const bvhgpu_ray_f32* rays, size_t n_rays, int mem, unsigned flags, bvhgpu_hits** hits) {
+    return do_traverse<float>(tree, rays, n_rays, mem, flags, hits, true);
+}
+int bvhgpu_traverse_async_f64(bvhgpu_tree* tree, const bvhgpu_ray_f64* rays, size_t n_rays, int mem, unsigned flags, bvhgpu_hits** hits) {
+    return do_traverse<double>(tree, rays, n_rays, mem, flags, hits, true);
+}
+// Completes an asynchronous batch: waits for the stream, completes the tree's asynchronous build if there is one (input
+// validation, unbalanced trees) and replays the batch where the optimistic launch was not enough — a tree that was not
+// finished when the walk ran, a tree the wide walk must not be used on, a hit pool / stack / heap that was too small.
+int bvhgpu_hits_wait(bvhgpu_hits* h) {
+    if (!h || !h->ctx) return BVHGPU_INVALID_ARG;
+    if (!h->pend_async) return BVHGPU_OK;
+    bvhgpu_ctx* ctx = h->ctx;
+    return guarded(ctx, [&] {
+        use_device(ctx);
+        h->pend_async = false;
+        bvhgpu_tree* t = h->pend_tree;
+        BVH_HIP(hipStreamSynchronize(ctx->stream));
+        if (!t) return (int)BVHGPU_OK;   // empty batch
+        bool replay = false;
+        if (t->pending_build) {
+            ensure_built(t);
+            replay = t->redone || (h->pend_wide && t->exact_only);
+            t->redone = false;
+        }
+        const void* rays = h->pend_rays;
+        for (;;) {
+            if (!replay && traverse_check(h)) return (int)BVHGPU_OK;
+            replay = false;
+            if (h->dtype == BVHGPU_F32) traverse_enqueue<float>(t, static_cast<const bvhgpu_ray_f32*>(rays), h->n_rays, h->flags, h);
+            else traverse_enqueue<double>(t, static_cast<const bvhgpu_ray_f64*>(rays), h->n_rays, h->flags, h);
+            BVH_HIP(hipStreamSynchronize(ctx->stream));
+        }
+    });
+}
+
 void bvhgpu_tree_destroy(bvhgpu_tree* t) {
     if (!t) return;
     if (t->ctx) { (void)hipSetDevice(t->ctx->device); (void)hipStreamSynchronize(t->ctx->stream); }
@@ -454,6 +537,7 @@ int bvhgpu_tree_info(const bvhgpu_tree* t, int* dtype, size_t* n_shapes, size_t*
 
 int bvhgpu_tree_nodes(bvhgpu_tree* t, void* out, int mem) {
     if (!t) return BVHGPU_INVALID_ARG;
+    { const int rc = settle(t); if (rc != BVHGPU_OK) return rc; }
     if (!t->built) return fail(t->ctx, BVHGPU_INVALID_ARG, "tree has no node array (imported scene)");
     if (t->n_nodes && !out) return fail(t->ctx, BVHGPU_INVALID_ARG, "out is NULL");
     return guarded(t->ctx, [&] {
@@ -466,6 +550,7 @@ int bvhgpu_tree_nodes(bvhgpu_tree* t, void* out, int mem) {
 
 int bvhgpu_tree_shape_nodes(bvhgpu_tree* t, uint32_t* out, int mem) {
     if (!t) return BVHGPU_INVALID_ARG;
+    { const int rc = settle(t); if (rc != BVHGPU_OK) return rc; }
     if (!t->built) return fail(t->ctx, BVHGPU_INVALID_ARG, "tree has no node array (imported scene)");
     if (t->n && !out) return fail(t->ctx, BVHGPU_INVALID_ARG, "out is NULL");
     return guarded(t->ctx, [&] {
@@ -477,12 +562,14 @@ int bvhgpu_tree_shape_nodes(bvhgpu_tree* t, uint32_t* out, int mem) {
 
 int bvhgpu_tree_build_levels(const bvhgpu_tree* t, int* levels) {
     if (!t || !levels) return BVHGPU_INVALID_ARG;
+    if (t->pending_build) { const int rc = settle(const_cast<bvhgpu_tree*>(t)); if (rc != BVHGPU_OK) return rc; }
     *levels = t->levels;
     return BVHGPU_OK;
 }
 
 int bvhgpu_flatten(bvhgpu_tree* t) {
     if (!t) return BVHGPU_INVALID_ARG;
+    { const int rc = settle(t); if (rc != BVHGPU_OK) return rc; }
     if (!t->built) return fail(t->ctx, BVHGPU_INVALID_ARG, "tree has no node array (imported scene)");
     bvhgpu_ctx* ctx = t->ctx;
     return guarded(ctx, [&] {
@@ -496,6 +583,7 @@ int bvhgpu_flatten(bvhgpu_tree* t) {
 
 int bvhgpu_flat_nodes(bvhgpu_tree* t, void* out, int mem) {
     if (!t) return BVHGPU_INVALID_ARG;
+    { const int rc = settle(t); if (rc != BVHGPU_OK) return rc; }
     if (!t->flattened || !t->built) return fail(t->ctx, BVHGPU_NOT_FLATTENED, "call bvhgpu_flatten first");
     if (t->n_flat && !out) return fail(t->ctx, BVHGPU_INVALID_ARG, "out is NULL");
     return guarded(t->ctx, [&] {
@@ -533,6 +621,7 @@ int bvhgpu_scene_nbytes(const bvhgpu_tree* t, size_t* nbytes) {
 
 int bvhgpu_scene_export(bvhgpu_tree* t, void* dst, int mem) {
     if (!t || !dst) return BVHGPU_INVALID_ARG;
+    { const int rc = settle(t); if (rc != BVHGPU_OK) return rc; }
     if (!t->flattened) return fail(t->ctx, BVHGPU_NOT_FLATTENED, "call bvhgpu_flatten first");
     bvhgpu_ctx* ctx = t->ctx;
     return guarded(ctx, [&] {
@@ -573,11 +662,22 @@ int bvhgpu_scene_import(bvhgpu_ctx* ctx, const void* src, size_t nbytes, int mem
         BVH_HIP(hipMemcpyAsync(h, s, 256, mem == BVHGPU_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, ctx->stream));
         BVH_HIP(hipStreamSynchronize(ctx->stream));
         if (h->magic != SCENE_MAGIC || h->dtype > 1) return fail(ctx, BVHGPU_INVALID_ARG, "not a bvhgpu scene blob");
-        if (256 + align256(h->trav_bytes) + align256(h->aabb_bytes) + align256(h->slot_bytes) + align256(h->tri_bytes) > nbytes) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob truncated");
-        if (h->slot_bytes && h->slot_bytes != slot_table_bytes((int)h->dtype)) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob slot table size");
-        t->dtype = (int)h->dtype; t->n = h->n; t->n_trav = h->n_trav; t->n_nodes = 0; t->n_flat = 0;
-        t->unfolded = h->unfolded != 0;
-        const size_t tb = h->trav_bytes, ab = h->aabb_bytes, sb = h->slot_bytes, gb = h->tri_bytes;
+        // the header is untrusted: every section size must be what (n, n_trav, dtype) imply, and the sum must fit the blob
+        const SceneHeader hd = *h;   // (the pinned page is reused below)
+        const uint64_t tsz = hd.dtype == BVHGPU_F32 ? sizeof(TravNode<float>) : sizeof(TravNode<double>);
+        const uint64_t ssz = hd.dtype == BVHGPU_F32 ? 4 : 8;
+        if (hd.n > MAX_SHAPES || hd.n_trav > 3 * (uint64_t)MAX_SHAPES) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob: shape / entry count out of range");
+        if (hd.trav_bytes != hd.n_trav * tsz || hd.aabb_bytes != hd.n * 6 * ssz || (hd.tri_bytes != 0 && hd.tri_bytes != hd.n * 9 * ssz))
+            return fail(ctx, BVHGPU_INVALID_ARG, "scene blob: section sizes do not match the shape / entry counts");
+        if (hd.slot_bytes && hd.slot_bytes != slot_table_bytes((int)hd.dtype)) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob slot table size");
+        if (!hd.unfolded && hd.n_trav != (hd.n >= 2 ? 2 * hd.n - 2 : hd.n)) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob: entry count does not match the shape count");
+        {
+            uint64_t need = 256;   // sizes are < 2^40 after the checks above: the sum cannot wrap
+            for (uint64_t part : {hd.trav_bytes, hd.aabb_bytes, hd.slot_bytes, hd.tri_bytes}) need += align256((size_t)part);
+            if (need > nbytes) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob truncated");
+        }
+        const size_t tb = hd.trav_bytes, ab = hd.aabb_bytes, sb = hd.slot_bytes, gb = hd.tri_bytes;
+        t->flattened = false;   // until the new arrays are in place
         t->trav.reserve(tb + 16);
         t->aabbs.reserve(ab + 16);
         const hipMemcpyKind kd = mem == BVHGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -586,9 +686,14 @@ int bvhgpu_scene_import(bvhgpu_ctx* ctx, const void* src, size_t nbytes, int mem
         if (sb) { t->slot_entry.reserve(sb); BVH_HIP(hipMemcpyAsync(t->slot_entry.p, s + 256 + align256(tb) + align256(ab), sb, kd, ctx->stream)); }
         else t->slot_entry.release();
         if (gb) { t->tris.reserve(gb); BVH_HIP(hipMemcpyAsync(t->tris.p, s + 256 + align256(tb) + align256(ab) + align256(sb), gb, kd, ctx->stream)); }
+        // every copy is enqueued: only now does the tree take the new identity (a failure above leaves a reused tree as it was,
+        // apart from buffers that may have grown)
+        t->dtype = (int)hd.dtype; t->n = hd.n; t->n_trav = hd.n_trav; t->n_nodes = 0; t->n_flat = 0;
+        t->unfolded = hd.unfolded != 0;
         t->has_tris = gb != 0;
+        t->built = false; t->flattened = true; t->exact_only = false;
+        if (t->dtype == BVHGPU_F32) wide_from_trav<float>(t); else wide_from_trav<double>(t);
         if (mem != BVHGPU_DEVICE) BVH_HIP(hipStreamSynchronize(ctx->stream));
-        t->built = false; t->flattened = true;
         return (int)BVHGPU_OK;
     });
     if (rc != BVHGPU_OK) { if (!given) { free_tree_buffers(t); delete t; } return rc; }
@@ -728,6 +833,8 @@ void bvhgpu_hits_destroy(bvhgpu_hits* h) {
     h->indices.release(); h->tslice.release(); h->blocksums.release(); h->ctr.release();
     h->isect.release(); h->closest.release(); h->closest_prim.release();
     h->heap_dist.release(); h->heap_node.release();
+    h->wcounts.release(); h->ray_mask.release(); h->item_cnt.release(); h->wstack.release();
+    if (h->pin) (void)hipHostFree(h->pin);
     delete h;
 }
 

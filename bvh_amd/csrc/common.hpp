@@ -119,6 +119,35 @@ template <> struct TopCfg<double> { static constexpr uint32_t SLOTS = 2880; };  
 static_assert(sizeof(TravNode<float>) == 32, "trav f32");
 static_assert(sizeof(TravNode<double>) == 64, "trav f64");
 
+// ------------------------------------------------------------------------------------------------
+// engine-private WIDE node (DESIGN.md §"Wide walk"): for every inner tree node b, the boxes of its (up to) four
+// GRANDCHILDREN in left-to-right order — slots 0,1 = the children of b's left child, slots 2,3 = those of its right
+// child; a child that is itself a leaf occupies the first slot of its pair (its box IS the shape's AABB) and leaves the
+// second one absent.  SoA over the four slots, one 16-byte chunk per coordinate, so a lane fetches a node with 7 (f32) /
+// 13 (f64) 16-byte loads from one 128- / 256-byte line.  ref: a leaf holds its shape index (< 2^31); an inner grandchild
+// holds WIDE_INNER | its tree node index (it has a wide node of its own); an absent slot holds NONE and a NaN box (which
+// fails every slab test).  Why skipping b's children is exact: see traverse.hip.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct WideNode;
+template <> struct __attribute__((aligned(128))) WideNode<float> {
+    float mn[3][4], mx[3][4];
+    uint32_t ref[4];
+    uint32_t _pad[4];
+};
+template <> struct __attribute__((aligned(256))) WideNode<double> {
+    double mn[3][4], mx[3][4];
+    uint32_t ref[4];
+    uint32_t _pad[12];
+};
+static_assert(sizeof(WideNode<float>) == 128, "wide f32");
+static_assert(sizeof(WideNode<double>) == 256, "wide f64");
+constexpr uint32_t WIDE_INNER = 0x80000000u;
+constexpr uint32_t WIDE_RESIDENT = 0x40000000u;        // walk-private: WIDE_INNER | WIDE_RESIDENT | LDS slot (4-ary heap number)
+constexpr size_t WIDE_MAX_SHAPES = (size_t)1 << 28;    // node indices fit 30 bits, per-ray hit counts fit 28 bits
+constexpr uint32_t WIDE_SLOTS = 1365;                  // 4-ary heap slots of wide levels 0..5 (tree levels 0,2,..,10): the most LDS can hold
+// wide-level k of 4-ary heap slot q (root 0, children 4q+1..4q+4) starts at slot (4^k - 1) / 3
+__host__ __device__ inline uint32_t wide_level_base(int k) { return ((1u << (2 * k)) - 1u) / 3u; }
+
 // work item of the builder: one tree node still to be split (BvhNodeBuildArgs, bvh_node.rs:437-446)
 template <typename T> struct Item {
     uint32_t ni;       // node_index

@@ -13,8 +13,8 @@ namespace bvhgpu {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    void reserve(size_t bytes) {
-        if (bytes <= cap) return;
+    bool reserve(size_t bytes) {   // true: a new (uninitialised) allocation was made
+        if (bytes <= cap) return false;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
@@ -25,6 +25,7 @@ struct DevBuf {
             throw HipFail{e, "hipMalloc", __LINE__};
         }
         cap = want;
+        return true;
     }
     void release() {
         if (p) (void)hipFree(p);
@@ -42,7 +43,7 @@ struct bvhgpu_ctx {
     bool own_stream = false;
     std::string err;
     int n_cu = 256;
-    int tune[BVHGPU_TUNE_COUNT] = {2, 32, 1, 16384, 0, 0, 1, 0};  // bvhgpu_set_tuning defaults
+    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0, 0};  // bvhgpu_set_tuning defaults
     // timing
     bool timing = false;
     hipEvent_t ev[8] = {};
@@ -65,7 +66,14 @@ struct bvhgpu_tree {
     bool flattened = false; // has trav (+ flat if built)
     bool unfolded = false;  // trav mirrors an uploaded FlatBvh 1:1 (nav and leaf entries kept apart)
     bool ctr_ready = false; // build counters / root keys were reset by the previous build
+    bool pending_build = false;  // build_enqueue ran, build_finalize has not (asynchronous entry points)
+    bool pend_flatten = false;   // ... and the flatten was enqueued behind it
+    bool redone = false;         // build_finalize had to finish the tree on the slow path: results enqueued meanwhile are stale
+    bool exact_only = false;     // some split had no SAH winner (empty child bounds): a child box is not the join of its
+                                 // grandchildren, so traversal must test every ancestor (binary walk only)
+    int pend_level = 0;
     int levels = 0;
+    void* pin = nullptr;         // pinned host copy of the build counters (1 KiB), one per tree so that builds can be in flight
     // persistent device arrays
     bvhgpu::DevBuf aabbs;       // n * 6 T
     bvhgpu::DevBuf nodes;       // n_nodes * Node
@@ -74,6 +82,9 @@ struct bvhgpu_tree {
     bvhgpu::DevBuf shape_node;  // n * u32
     bvhgpu::DevBuf flat;        // n_flat * Flat     (reference layout, for export/parity)
     bvhgpu::DevBuf trav;        // n_trav * TravNode (engine layout, what traversal reads)
+    bvhgpu::DevBuf wide;        // n_nodes * WideNode: the four grandchildren of every inner node (wide walk, traverse.hip)
+    bvhgpu::DevBuf wslot_node;  // WideCfg::SLOTS * u32: tree node held in 4-ary heap slot s of the LDS-resident top (NONE = none)
+    bool has_wide = false;
     bvhgpu::DevBuf tris;        // n * 9 T triangle vertices (optional: triangle stage)
     bool has_tris = false;
     bvhgpu::DevBuf slot_entry;  // TopCfg::SLOTS * u32: traversal entry held in LDS slot s (NONE = unused slot)
@@ -113,20 +124,40 @@ struct bvhgpu_hits {
     uint32_t heap_cap = 48;  // ... entries per lane (doubles when a batch overflows it)
     size_t pool_cap = 0;
     bool ctr_clean = false;  // the counters were zeroed behind the previous call's readback
+    // wide walk
+    bvhgpu::DevBuf wcounts;   // n_rays+1 u32: hit count | item mask << 28, all-zero between batches
+    bvhgpu::DevBuf ray_mask;  // n_rays u8: items of the ray that reported hits (valid for rays with hits)
+    bvhgpu::DevBuf item_cnt;  // per item: hits (valid where the ray's mask has the item's bit)
+    bvhgpu::DevBuf wstack;    // the part of the lanes' stacks that does not fit in LDS
+    bool wcounts_clean = false;
+    bool force_binary = false;   // the wide walk overflowed a lane's stack on this batch: replay with the binary walk
+    // the batch in flight (traverse_enqueue → traverse_check): what a replay needs
+    void* pin = nullptr;         // 64 B of pinned host memory: the 8 walk / scan counters of the last batch
+    bvhgpu_tree* pend_tree = nullptr;
+    const void* pend_rays = nullptr;
+    bool pend_wide = false, pend_unfolded = false, pend_async = false;
+    int pend_attempts = 0;
 };
 
 namespace bvhgpu {
 
 // build.hip
 template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after);
+template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after);
+template <typename T> void build_finalize(bvhgpu_tree* t);
 // flatten.hip
 template <typename T> void flatten_tree(bvhgpu_tree* t);
+template <typename T> void wide_from_trav(bvhgpu_tree* t);   // wide nodes + their LDS slot table from trav + slot_entry
 // refit.hip
 template <typename T> void refit_tree(bvhgpu_tree* t, const T* aabbs_dev);
 // traverse.hip
 template <typename T>
 void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, unsigned flags,
                     bvhgpu_hits* h);
+template <typename T>
+void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, unsigned flags,
+                      bvhgpu_hits* h);
+bool traverse_check(bvhgpu_hits* h);   // after a stream synchronise: false = enqueue again
 template <typename T>
 void nearest_batch(bvhgpu_tree* t, const T* points_dev, size_t n, int kind, uint32_t* out_shape_dev, T* out_dist_dev);
 template <typename T>

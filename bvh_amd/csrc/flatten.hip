@@ -9,6 +9,8 @@
 //     leaf i additionally owns flat[nav+1] = {Aabb::empty(), u32::MAX, nav+2, shape}  (:129-141)
 // One thread per tree node; the same thread writes the engine's traversal entry trav[i-1]
 // (folded layout, common.hpp) so both arrays come out of one pass over the nodes.
+#include <algorithm>
+
 #include "engine.hpp"
 
 namespace bvhgpu {
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node*
                                                  const uint32_t* __restrict__ node_count, const T* __restrict__ aabbs,
                                                  const uint16_t* __restrict__ node_slot, uint32_t* __restrict__ slot_entry,
                                                  typename Traits<T>::Flat* __restrict__ flat, TravNode<T>* __restrict__ trav,
-                                                 uint32_t n_nodes) {
+                                                 uint32_t n_nodes, uint32_t n_shapes) {
     using Tr = Traits<T>;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
@@ -54,6 +56,12 @@ __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node*
         return;
     }
     if (i == 0) return;  // the root emits nothing itself (flat_bvh.rs:104-127)
+    // build_flat launches this kernel optimistically, before the host has seen that the builder's queues are drained.
+    // On an unfinished (very unbalanced) tree some nodes are not written yet: nothing read from such a node may turn
+    // into an out-of-range access; the host flattens again once the build is complete.
+    const uint32_t n_flat = 3u * n_shapes - 2u;
+    if (nd.parent >= n_nodes || (nd.shape != NONE && nd.shape >= n_shapes)) return;
+    if ((unsigned long long)(i - 1) + node_start[i] + 1ull >= n_flat || node_count[i] > n_shapes) return;
     const typename Tr::Node pn = nodes[nd.parent];
     const bool is_left = pn.l == i;
     T mn[3], mx[3];
@@ -94,6 +102,93 @@ __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node*
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide nodes (common.hpp WideNode) from the folded traversal array: tree node b (entry b-1; the root has no entry) is
+// inner; its left child is entry b, its right child is the entry the left child exits to; the same step down gives the
+// grandchildren.  Works for trees built here and for imported scenes alike (the array is all it reads).  Threads
+// below WIDE_SLOTS also fill the 4-ary heap slot table of the LDS-resident top of the wide walk: slot q at wide level k
+// is the tree node with binary heap number 4^k + (q - base_k), whose traversal entry the binary slot table holds.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct WideSlot { T mn[3], mx[3]; uint32_t ref; };
+
+template <typename T> __device__ __forceinline__ void wide_slot_from_entry(const TravNode<T>* __restrict__ trav, uint32_t e,
+                                                                           WideSlot<T>& s) {
+    const TravNode<T> g = trav[e];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { s.mn[k] = g.mn[k]; s.mx[k] = g.mx[k]; }
+    s.ref = trav_is_leaf(g.shape) ? g.shape : (WIDE_INNER | (e + 1u));   // entry e belongs to tree node e + 1
+}
+template <typename T> __device__ __forceinline__ void wide_slot_absent(WideSlot<T>& s) {
+    const T nan = __builtin_nan("");
+#pragma unroll
+    for (int k = 0; k < 3; k++) { s.mn[k] = nan; s.mx[k] = nan; }
+    s.ref = NONE;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_wide(const TravNode<T>* __restrict__ trav, uint32_t n_nodes, uint32_t n_trav,
+                                              const uint32_t* __restrict__ slot_entry, uint32_t n_bin_slots,
+                                              WideNode<T>* __restrict__ wide, uint32_t* __restrict__ wslot_node) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < WIDE_SLOTS) {   // slot table of the resident top
+        int k = 0;
+        while (k < 5 && wide_level_base(k + 1) <= b) k++;
+        const uint32_t h = (1u << (2 * k)) + (b - wide_level_base(k));   // binary heap number (root 1)
+        uint32_t node = NONE;
+        if (h == 1u) node = 0u;
+        else if (h < n_bin_slots) {
+            const uint32_t e = slot_entry[h];
+            if (e != NONE && e < n_trav && !trav_is_leaf(trav[e].shape)) node = e + 1u;
+        }
+        wslot_node[b] = node;
+    }
+    if (b >= n_nodes) return;
+    if (b > 0 && trav_is_leaf(trav[b - 1].shape)) return;   // leaves have no wide node
+    WideSlot<T> s[4];
+    // every index read from the array is range-checked: the optimistic flatten of build_flat may run over an unfinished tree
+    // (garbage in, garbage out — the host flattens again — but never out of range)
+    uint32_t child = b < n_trav ? b : n_trav - 1u;   // entry of the left child
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        const TravNode<T> c = trav[child];
+        if (trav_is_leaf(c.shape) || child + 1u >= n_trav) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { s[2 * side].mn[k] = c.mn[k]; s[2 * side].mx[k] = c.mx[k]; }
+            s[2 * side].ref = trav_is_leaf(c.shape) ? c.shape : NONE;
+            wide_slot_absent<T>(s[2 * side + 1]);
+        } else {
+            wide_slot_from_entry<T>(trav, child + 1u, s[2 * side]);
+            const uint32_t g1 = trav[child + 1u].exit;
+            if (g1 < n_trav) wide_slot_from_entry<T>(trav, g1, s[2 * side + 1]); else wide_slot_absent<T>(s[2 * side + 1]);
+        }
+        child = c.exit < n_trav ? c.exit : n_trav - 1u;   // the left child exits to the right child
+    }
+    WideNode<T> w;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { w.mn[k][c] = s[c].mn[k]; w.mx[k][c] = s[c].mx[k]; }
+        w.ref[c] = s[c].ref;
+    }
+    for (int k = 0; k < (int)(sizeof(w._pad) / 4); k++) w._pad[k] = 0;
+    wide[b] = w;
+}
+
+template <typename T> void wide_from_trav(bvhgpu_tree* t) {
+    t->has_wide = false;
+    if (t->n < 2 || t->n >= WIDE_MAX_SHAPES || t->unfolded || !t->slot_entry.p) return;
+    const uint32_t nn = (uint32_t)(t->n_trav + 1);   // tree nodes = entries + the root
+    t->wide.reserve((size_t)nn * sizeof(WideNode<T>));
+    t->wslot_node.reserve(WIDE_SLOTS * 4);
+    hipLaunchKernelGGL(k_wide<T>, dim3((std::max(nn, WIDE_SLOTS) + 255) / 256), dim3(256), 0, t->ctx->stream, t->trav.as<TravNode<T>>(),
+                       nn, (uint32_t)t->n_trav, t->slot_entry.as<uint32_t>(), (uint32_t)TopCfg<T>::SLOTS, t->wide.as<WideNode<T>>(),
+                       t->wslot_node.as<uint32_t>());
+    BVH_HIP(hipGetLastError());
+    t->has_wide = true;
+}
+template void wide_from_trav<float>(bvhgpu_tree*);
+template void wide_from_trav<double>(bvhgpu_tree*);
+
 template <typename T> void flatten_tree(bvhgpu_tree* t) {
     using Tr = Traits<T>;
     if (t->n == 0) { t->flattened = true; return; }
@@ -105,8 +200,9 @@ template <typename T> void flatten_tree(bvhgpu_tree* t) {
                        t->nodes.as<typename Tr::Node>(), t->node_start.as<uint32_t>(), t->node_count.as<uint32_t>(),
                        t->aabbs.as<T>(), t->node_slot.as<uint16_t>(), t->slot_entry.as<uint32_t>(),
                        t->flat.as<typename Tr::Flat>(),
-                       t->trav.as<TravNode<T>>(), nn);
+                       t->trav.as<TravNode<T>>(), nn, (uint32_t)t->n);
     BVH_HIP(hipGetLastError());
+    wide_from_trav<T>(t);
     t->flattened = true;
 }
 

@@ -70,29 +70,41 @@ bool parse_float(Cursor& c, float* out) {
     return true;
 }
 
+// a decimal integer with an optional sign, read inside [c.p, c.end) only — the buffer need not be NUL-terminated, and
+// unlike strtoll no white space (in particular no newline) is skipped in front of it
+bool parse_int(Cursor& c, long long* out) {
+    const char* p = c.p;
+    bool neg = false;
+    if (p < c.end && (*p == '+' || *p == '-')) { neg = *p == '-'; p++; }
+    if (p >= c.end || *p < '0' || *p > '9') return false;
+    long long v = 0;
+    while (p < c.end && *p >= '0' && *p <= '9') {
+        if (v > (0x7FFFFFFFFFFFFFFFll - 9) / 10) return false;   // overflow: not an index any OBJ file can mean
+        v = v * 10 + (*p - '0');
+        p++;
+    }
+    c.p = p;
+    *out = neg ? -v : v;
+    return true;
+}
+
 // one face vertex "p", "p/t", "p//n" or "p/t/n": returns the position index and the kind (bit0: t, bit1: n)
 bool parse_face_vertex(Cursor& c, long long* pos, int* kind) {
     skip_blanks(c);
     if (at_eol(c)) return false;
-    char* endp = nullptr;
-    const long long v = strtoll(c.p, &endp, 10);
-    if (endp == c.p) return false;
-    c.p = endp;
+    long long v = 0, ignored = 0;
+    if (!parse_int(c, &v)) return false;
     *pos = v;
     int k = 0;
     if (c.p < c.end && *c.p == '/') {
         c.p++;
         if (c.p < c.end && *c.p != '/' && !is_space(*c.p) && *c.p != '\n') {
-            (void)strtoll(c.p, &endp, 10);
-            if (endp == c.p) return false;
-            c.p = endp;
+            if (!parse_int(c, &ignored)) return false;
             k |= 1;
         }
         if (c.p < c.end && *c.p == '/') {
             c.p++;
-            (void)strtoll(c.p, &endp, 10);
-            if (endp == c.p) return false;
-            c.p = endp;
+            if (!parse_int(c, &ignored)) return false;
             k |= 2;
         }
     }

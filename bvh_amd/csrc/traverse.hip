@@ -67,6 +67,7 @@ template <typename T> struct WalkOut {
     const T* tris;               // n x 9 vertices (triangle modes)
     T* closest;                  // per ray {distance,u,v} (closest mode)
     uint32_t* closest_prim;      // per ray shape index or NONE
+    uint32_t* item_cnt;          // wide walk with several items per ray: hits of item i, written only when non-zero
 };
 
 // ---- Ray::intersects_triangle (ray_impl.rs:154-213), Möller–Trumbore with back-face culling.  Same
@@ -644,25 +645,256 @@ __global__ __launch_bounds__(LDS_THREADS) void k_traverse_lds(const TravNode<T>*
     walk_epilogue<T, MODE>(w, pc, lane, STATS, steps, leaf_steps, wsteps, cands);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide walk (large incoherent batches, the default): four grandchild boxes per step instead of one child box.
+//
+// Why it returns the reference's list.  FlatBvh::traverse reports shape s iff the slab test passes for every
+// ancestor box of s and for s's own AABB (flat_bvh.rs:408-427), in pre-order.  Every ancestor box is the exact join
+// (component-wise min / max, no rounding) of the AABBs below it, so it contains s's AABB component by component.
+// For a ray whose origin and inverse direction are finite, against finite boxes, no product (b - o) * inv is NaN and
+// each is monotone in b (IEEE subtraction and multiplication by a constant are monotone under round-to-nearest):
+// growing a box can only lower its entry parameter and raise its exit parameter, so
+//        slab(ray, AABB(s)) passes  ⇒  slab(ray, every ancestor box of s) passes.
+// The ancestor tests are therefore redundant for the RESULT, and a walk may skip tree levels as long as it keeps the
+// pre-order: this kernel visits, for an inner node b, the four grandchildren directly (common.hpp WideNode).  On the
+// 120k-triangle scene a ray needs 20 dependent steps instead of 79, for the same 79 box tests.  Rays with a non-finite
+// component (axis-parallel: inv = ±inf) can produce NaN products, which the reference turns into a miss
+// (intersect_default.rs:22-28) and which break the implication above; waves holding such a ray take the exact
+// sequence instead: the skipped child box is rebuilt as the join of its two grandchild boxes (bit-identical to
+// the builder's box up to the sign of a zero, which no product distinguishes) and tested with the reference's
+// NaN-aware slab test before its grandchildren are.  Trees where a child box is NOT the join of its grandchildren
+// (empty bounds after a split with no SAH winner, bvh_node.rs:225-230; uploaded FlatBvh whose shapes moved) and the
+// outputs that need the reference's own visit sequence (STATS, T_SLICE) use the binary walks above.
+//
+// Per lane: `cur` = what to do next (an inner node, a leaf to report, or nothing) and a stack of the other hit
+// grandchildren (at most 3 pushes per step; the first `stack_lds` entries per lane in LDS, entry-major, the rest in
+// a global workspace; overflowing that raises a flag and the host replays the batch with the binary walk).
+// The nodes with the K lowest 4-ary heap numbers (root 0, children 4q+1..4q+4) are copied to LDS by every workgroup
+// (one 16-byte plane per chunk, like TopLds), a lane follows heap numbers while it is inside that set.
+// A ray may be cut into 4 ITEMS, one per grandchild of the root (no ancestor test is owed, see above): item 4r+j walks
+// the root with only slot j enabled; a ray's list is the concatenation of its items' lists.
+// Waves are persistent and draw items from a workgroup cursor exactly like k_traverse_lds.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t CUR_NONE = 0x7FFFFFFFu;   // neither a shape index (< 2^28) nor an inner reference (bit 31)
+#ifndef BVH_WIDE_INNER_STEPS
+#define BVH_WIDE_INNER_STEPS 4
+#endif
+constexpr int WIDE_INNER_STEPS = BVH_WIDE_INNER_STEPS;   // walk steps between two refill phases
+#ifndef BVH_WIDE_MIN_WAVES_F32
+#define BVH_WIDE_MIN_WAVES_F32 8   // __launch_bounds__: waves per SIMD the f32 kernel must allow (8 = two 1024-thread workgroups per CU)
+#endif
+#ifndef BVH_WIDE_MIN_WAVES_F64
+#define BVH_WIDE_MIN_WAVES_F64 4   // f64: two 512-thread workgroups per CU
+#endif
+constexpr uint32_t WIDE_COUNT_BITS = 28;     // per-ray word: hit count | (mask of the items that reported hits) << 28
+
+template <typename T> struct WideRegs { T mn[3][4], mx[3][4]; uint32_t ref[4]; };
+template <typename T> struct WideIo {
+    static constexpr int CHUNKS = (int)(sizeof(WideRegs<T>) / 16);   // 7 (f32) / 13 (f64) 16-byte chunks per node
+    static_assert(sizeof(WideRegs<T>) % 16 == 0, "wide regs");
+    static __device__ __forceinline__ WideRegs<T> from_global(const WideNode<T>* __restrict__ p) {
+        const uint4* q = reinterpret_cast<const uint4*>(p);
+        uint4 c[CHUNKS];
+#pragma unroll
+        for (int j = 0; j < CHUNKS; j++) c[j] = q[j];
+        WideRegs<T> r;
+        __builtin_memcpy(&r, c, sizeof r);
+        return r;
+    }
+    static __device__ __forceinline__ WideRegs<T> from_lds(const uint4* planes, uint32_t K, uint32_t slot) {
+        uint4 c[CHUNKS];
+#pragma unroll
+        for (int j = 0; j < CHUNKS; j++) c[j] = planes[(uint32_t)j * K + slot];
+        WideRegs<T> r;
+        __builtin_memcpy(&r, c, sizeof r);
+        return r;
+    }
+    static __device__ __forceinline__ void to_lds(uint4* planes, uint32_t K, uint32_t slot, const WideNode<T>* __restrict__ g) {
+        const uint4* q = reinterpret_cast<const uint4*>(g);
+#pragma unroll
+        for (int j = 0; j < CHUNKS; j++) planes[(uint32_t)j * K + slot] = q[j];
+    }
+};
+
+// the four slab tests of one wide node → hit bits.  EXACT: the reference's NaN-aware sequence with the skipped child
+// boxes rebuilt and tested first (see the header above).
+template <typename T, bool EXACT>
+__device__ __forceinline__ uint32_t wide_hits(const T o[3], const T inv[3], const WideRegs<T>& nd) {
+    uint32_t m = 0;
+    if (!EXACT) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const T mn[3] = {nd.mn[0][c], nd.mn[1][c], nd.mn[2][c]}, mx[3] = {nd.mx[0][c], nd.mx[1][c], nd.mx[2][c]};
+            m |= slab_hit_finite<T>(o, inv, mn, mx) ? (1u << c) : 0u;
+        }
+        return m;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int c0 = 2 * p, c1 = 2 * p + 1;
+        const T mn0[3] = {nd.mn[0][c0], nd.mn[1][c0], nd.mn[2][c0]}, mx0[3] = {nd.mx[0][c0], nd.mx[1][c0], nd.mx[2][c0]};
+        T t0, t1;
+        if (nd.ref[c1] == NONE) {   // the child is a leaf (or absent): its own box is in slot c0
+            if (nd.ref[c0] != NONE && slab_hit<T>(o, inv, mn0, mx0, t0, t1)) m |= 1u << c0;
+        } else {
+            const T mn1[3] = {nd.mn[0][c1], nd.mn[1][c1], nd.mn[2][c1]}, mx1[3] = {nd.mx[0][c1], nd.mx[1][c1], nd.mx[2][c1]};
+            T jmn[3], jmx[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { jmn[k] = tmin(mn0[k], mn1[k]); jmx[k] = tmax(mx0[k], mx1[k]); }
+            if (slab_hit<T>(o, inv, jmn, jmx, t0, t1)) {
+                if (slab_hit<T>(o, inv, mn0, mx0, t0, t1)) m |= 1u << c0;
+                if (slab_hit<T>(o, inv, mn1, mx1, t0, t1)) m |= 1u << c1;
+            }
+        }
+    }
+    return m;
+}
+
+template <typename T, int MODE, int ITEMS_LOG4, int MAX_THREADS, int MIN_WAVES>
+__global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
+    const WideNode<T>* __restrict__ wide, const uint32_t* __restrict__ wslot_node, uint32_t K, uint32_t stack_lds,
+    const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_items, uint32_t items_per_wg, WalkOut<T> w,
+    uint32_t* __restrict__ gstack, uint32_t gstack_cap, uint32_t* __restrict__ overflow) {
+    constexpr uint32_t ITEMS = 1u << (2 * ITEMS_LOG4);
+    static_assert(ITEMS_LOG4 == 0 || ITEMS_LOG4 == 1, "1 or 4 items per ray");
+    static_assert(MODE != MODE_T_SLICE, "the t-slice output walks the binary array");
+    extern __shared__ __attribute__((aligned(16))) uint4 wsmem[];
+    uint32_t& s_next = *reinterpret_cast<uint32_t*>(wsmem);
+    uint4* planes = wsmem + 1;
+    uint32_t* s_stack = reinterpret_cast<uint32_t*>(planes + (size_t)WideIo<T>::CHUNKS * K);
+    const uint32_t bd = blockDim.x, tid = threadIdx.x;
+    const size_t G = (size_t)gridDim.x * bd, gid = (size_t)blockIdx.x * bd + tid;
+    const unsigned long long g0 = (unsigned long long)blockIdx.x * items_per_wg;
+    const unsigned long long g1 = g0 + items_per_wg;
+    const uint32_t wg_begin = (uint32_t)(g0 < n_items ? g0 : n_items);
+    const uint32_t wg_end = (uint32_t)(g1 < n_items ? g1 : n_items);
+    if (tid == 0) s_next = wg_begin;
+    for (uint32_t q = tid; q < K; q += bd) {
+        const uint32_t node = wslot_node[q];
+        if (node != NONE) WideIo<T>::to_lds(planes, K, q, wide + node);
+    }
+    __syncthreads();
+
+    const int lane = lane_id();
+    const unsigned long long lt = lanemask_lt();
+    LaneRay<T, MODE> ray;
+    ray.clear();
+    uint32_t cur = CUR_NONE, sp = 0, item = NONE, stepmask = 15u;
+    bool exhausted = wg_begin >= wg_end;   // wave-uniform: the workgroup's range has been handed out
+    bool ovf = false;
+    PoolCursor pc;
+    auto push = [&](uint32_t v) {
+        if (sp < stack_lds) s_stack[sp * bd + tid] = v;
+        else if (sp - stack_lds < gstack_cap) gstack[(size_t)(sp - stack_lds) * G + gid] = v;
+        else ovf = true;
+        sp++;
+    };
+    auto pop_or_none = [&]() -> uint32_t {
+        if (sp == 0) return CUR_NONE;
+        sp--;
+        if (sp < stack_lds) return s_stack[sp * bd + tid];
+        return sp - stack_lds < gstack_cap ? gstack[(size_t)(sp - stack_lds) * G + gid] : CUR_NONE;
+    };
+    while (true) {
+        // ---- refill phase
+        bool run = cur != CUR_NONE;
+        const unsigned long long idle = __ballot(!run);
+        if (idle) {
+            if (!run && item != NONE) {   // the item has left the tree: its part of the ray's list is complete
+                if (MODE == MODE_CLOSEST) {
+                    const size_t r = item;
+                    w.closest[3 * r] = ray.best[0]; w.closest[3 * r + 1] = ray.best[1]; w.closest[3 * r + 2] = ray.best[2];
+                    w.closest_prim[r] = ray.best_prim;
+                } else if (ray.cnt) {
+                    if (ITEMS == 1) {
+                        w.counts[item] = ray.cnt | (1u << WIDE_COUNT_BITS);
+                    } else {
+                        atomicAdd(&w.counts[item >> (2 * ITEMS_LOG4)], ray.cnt | (1u << (WIDE_COUNT_BITS + (item & (ITEMS - 1u)))));
+                        w.item_cnt[item] = ray.cnt;
+                    }
+                }
+                item = NONE;
+            }
+            if (!exhausted) {
+                const uint32_t nidle = (uint32_t)__popcll(idle);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_next, nidle);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const uint32_t mine = base + (uint32_t)__popcll(idle & lt);
+                if (!run && base < wg_end && mine < wg_end) {
+                    ray.load(rays, mine >> (2 * ITEMS_LOG4));
+                    ray.r = mine;                          // pool records are per item
+                    item = mine;
+                    cur = WIDE_INNER | WIDE_RESIDENT | 0u;   // the root is heap slot 0 (K >= 1)
+                    sp = 0;
+                    stepmask = ITEMS == 1 ? 15u : (1u << (mine & (ITEMS - 1u)));
+                    run = true;
+                }
+                exhausted = base >= wg_end || (wg_end - base) <= nidle;
+            }
+            if (!__any(run)) break;
+        }
+        const bool fast = !__any(run && !ray.fin);   // wave-uniform
+        for (int s = 0; s < WIDE_INNER_STEPS; s++) {
+            if (cur & WIDE_INNER) {   // (CUR_NONE and shape indices have bit 31 clear)
+                const bool res = (cur & WIDE_RESIDENT) != 0u;
+                const uint32_t id = cur & (WIDE_RESIDENT - 1u);
+                WideRegs<T> nd;
+                if (res) nd = WideIo<T>::from_lds(planes, K, id);
+                else nd = WideIo<T>::from_global(wide + id);
+                uint32_t m = fast ? wide_hits<T, false>(ray.o, ray.inv, nd) : wide_hits<T, true>(ray.o, ray.inv, nd);
+                // slots 1 and 3 may be absent (their NaN boxes fail the test anyway; the mask keeps a stray bit from
+                // ever turning NONE into a node reference); an item's first step enables its own slot only
+                m &= stepmask & (5u | (nd.ref[1] != NONE ? 2u : 0u) | (nd.ref[3] != NONE ? 8u : 0u));
+                stepmask = 15u;
+                const uint32_t cbase = res ? 4u * id + 1u : 0xFFFFFFF0u;   // heap slots of the four grandchildren
+                uint32_t enc[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    enc[c] = ((nd.ref[c] & WIDE_INNER) && cbase + (uint32_t)c < K) ? (WIDE_INNER | WIDE_RESIDENT | (cbase + (uint32_t)c))
+                                                                                   : nd.ref[c];
+                const uint32_t first = m & (0u - m);
+                const uint32_t rest = m ^ first;
+                if (rest & 8u) push(enc[3]);
+                if (rest & 4u) push(enc[2]);
+                if (rest & 2u) push(enc[1]);
+                cur = first == 0u ? pop_or_none() : (first == 1u ? enc[0] : (first == 2u ? enc[1] : (first == 4u ? enc[2] : enc[3])));
+            }
+            const bool rec = cur < CUR_NONE;   // a leaf: report it, take the next pending grandchild
+            const uint32_t shape = cur;
+            if (rec) cur = pop_or_none();
+            report<T, MODE>(rec, shape, (T)0, (T)0, ray, w, pc, lane, lt);
+        }
+        if (ovf) { cur = CUR_NONE; sp = 0; }
+    }
+    if (__any(ovf) && lane == 0) atomicOr(overflow, 4u);
+    walk_epilogue<T, MODE>(w, pc, lane, false, 0, 0, 0, 0);
+}
+
 // ---- exclusive scan of per-ray counts ----------------------------------------------------------
 constexpr int SCAN_ITEMS = 4;
 constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;
 
-// PAIR: every ray was walked as two items (k_traverse_lds split): its count is counts[2r] + counts[2r+1]
-template <bool PAIR> __device__ __forceinline__ uint32_t ray_count(const uint32_t* __restrict__ counts, uint32_t r) {
-    if (!PAIR) return counts[r];
+// KIND 1 (pair): every ray was walked as two items (k_traverse_lds split): its count is counts[2r] + counts[2r+1].
+// KIND 2 (wide walk): counts[r] = hit count | item mask << 28, non-zero only for rays with hits; k_scan_final moves the
+// mask to ray_mask[r] and puts the zero back, so the array is all zero again for the next batch (the walk then stores
+// nothing for the rays — most of them on a sparse scene — that hit nothing).
+constexpr int COUNT_PLAIN = 0, COUNT_PAIR = 1, COUNT_MASKED = 2;
+template <int KIND> __device__ __forceinline__ uint32_t ray_count(const uint32_t* __restrict__ counts, uint32_t r) {
+    if (KIND == COUNT_PLAIN) return counts[r];
+    if (KIND == COUNT_MASKED) return counts[r] & ((1u << WIDE_COUNT_BITS) - 1u);
     const uint2 c = reinterpret_cast<const uint2*>(counts)[r];
     return c.x + c.y;
 }
 
-template <bool PAIR>
+template <int KIND>
 __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict__ counts, uint32_t n,
                                                      unsigned long long* __restrict__ blocksums) {
     __shared__ unsigned long long ws[4];
     const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
     unsigned long long s = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) s += (base + j < n) ? ray_count<PAIR>(counts, base + j) : 0u;
+    for (int j = 0; j < SCAN_ITEMS; j++) s += (base + j < n) ? ray_count<KIND>(counts, base + j) : 0u;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
     if (lane_id() == 0) ws[threadIdx.x >> 6] = s;
@@ -696,11 +928,11 @@ constexpr uint32_t SCAN_FUSED_MAX_BLOCKS = 2048;   // up to this many blocks eve
 
 // counts → offsets.  PREFIXED: blocksums already hold exclusive prefixes (k_scan_sums ran, large batches); otherwise
 // they are the raw per-block sums of k_scan_reduce and this block adds up its predecessors (one kernel less).
-template <bool PAIR, bool PREFIXED>
+template <int KIND, bool PREFIXED>
 __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__ counts, uint32_t n,
                                                     const unsigned long long* __restrict__ blocksums,
                                                     unsigned long long* __restrict__ total,
-                                                    uint32_t* __restrict__ offsets) {
+                                                    uint32_t* __restrict__ offsets, uint8_t* __restrict__ ray_mask) {
     __shared__ uint32_t ws[4];
     __shared__ unsigned long long wb[4];
     const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
@@ -718,7 +950,16 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__
     uint32_t v[SCAN_ITEMS];
     uint32_t s = 0;
 #pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; j++) { v[j] = (base + j < n) ? ray_count<PAIR>(counts, base + j) : 0u; s += v[j]; }
+    for (int j = 0; j < SCAN_ITEMS; j++) { v[j] = (base + j < n) ? ray_count<KIND>(counts, base + j) : 0u; s += v[j]; }
+    if (KIND == COUNT_MASKED) {   // rays with hits: keep the item mask for the scatter, zero the word for the next batch
+#pragma unroll
+        for (int j = 0; j < SCAN_ITEMS; j++) {
+            if (v[j]) {
+                ray_mask[base + j] = (uint8_t)(counts[base + j] >> WIDE_COUNT_BITS);
+                const_cast<uint32_t*>(counts)[base + j] = 0u;
+            }
+        }
+    }
     uint32_t inc = s;
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) {
@@ -760,6 +1001,34 @@ __global__ __launch_bounds__(256) void k_hits_scatter(const HitRec* __restrict__
         // pair_counts: h.ray is an ITEM (2*ray + side); the right item's records follow the left item's
         const uint32_t d = pair_counts ? offsets[h.ray >> 1] + ((h.ray & 1u) ? pair_counts[h.ray - 1] : 0u) + h.k
                                        : offsets[h.ray] + h.k;
+        indices[d] = h.shape;
+#pragma unroll
+        for (int k = 0; k < NV; k++) vals[NV * (size_t)d + k] = pool_v[NV * j + k];
+    }
+}
+
+// wide walk: a record's `ray` is an item (ray << 2*ITEMS_LOG4 | j); the records of item j follow those of the ray's earlier
+// items that reported hits (ray_mask) — item_cnt is only valid for those
+template <typename T, int NV, int ITEMS_LOG4>
+__global__ __launch_bounds__(256) void k_hits_scatter_wide(const HitRec* __restrict__ pool, const T* __restrict__ pool_v,
+                                                           const unsigned long long* __restrict__ ctr,
+                                                           unsigned long long pool_cap, const uint32_t* __restrict__ offsets,
+                                                           const uint32_t* __restrict__ item_cnt, const uint8_t* __restrict__ ray_mask,
+                                                           uint32_t* __restrict__ indices, T* __restrict__ vals) {
+    constexpr uint32_t ITEMS = 1u << (2 * ITEMS_LOG4);
+    const unsigned long long n = ctr[0];
+    if (n > pool_cap) return;  // pool overflowed: the host grows it and replays
+    for (unsigned long long j = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; j < n;
+         j += (unsigned long long)gridDim.x * blockDim.x) {
+        const HitRec h = pool[j];
+        if (h.ray == NONE) continue;   // unused tail of a per-wave chunk
+        const uint32_t ray = h.ray >> (2 * ITEMS_LOG4), it = h.ray & (ITEMS - 1u);
+        uint32_t d = offsets[ray] + h.k;
+        if (ITEMS > 1 && it) {
+            const uint32_t mask = ray_mask[ray];
+            for (uint32_t i = 0; i < it; i++)
+                if (mask & (1u << i)) d += item_cnt[(h.ray - it) + i];
+        }
         indices[d] = h.shape;
 #pragma unroll
         for (int k = 0; k < NV; k++) vals[NV * (size_t)d + k] = pool_v[NV * j + k];
@@ -818,9 +1087,61 @@ static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
                        t->slot_entry.as<uint32_t>(), K, first_slot, split_at, rays_dev, (uint32_t)n_items, rpg, w);
 }
 
+// ---- wide walk launch ------------------------------------------------------------------------
+// Workgroup geometry: `wg_per_cu` workgroups of `threads` share a CU's 160 KB of LDS; each keeps the per-lane stack
+// (stack_lds entries x threads x 4 B) and as many top-of-tree wide nodes as fit in the rest.
+template <typename T> struct WideGeom {
+    uint32_t threads, wg_per_cu, stack_lds, K;
+    size_t lds_bytes;
+    WideGeom(const bvhgpu_ctx* ctx) {
+        const bool f64 = sizeof(T) == 8;
+        const int want_threads = ctx->tune[BVHGPU_TUNE_WIDE_THREADS] > 0 ? ctx->tune[BVHGPU_TUNE_WIDE_THREADS] : (f64 ? 512 : 1024);
+        threads = (uint32_t)std::min(f64 ? 512 : 1024, std::max(64, want_threads & ~63));
+        wg_per_cu = (uint32_t)std::max(1, std::min(ctx->tune[BVHGPU_TUNE_WIDE_WG_PER_CU] > 0 ? ctx->tune[BVHGPU_TUNE_WIDE_WG_PER_CU] : 2,
+                                                   (int)(2048 / threads)));
+        stack_lds = (uint32_t)std::max(0, std::min(ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] >= 0 ? ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] : 8, 32));
+        const size_t budget = (size_t)(160 * 1024) / wg_per_cu;
+        const size_t fixed = 16 + (size_t)stack_lds * threads * 4;
+        const size_t per_slot = (size_t)WideIo<T>::CHUNKS * 16;
+        size_t k = budget > fixed + per_slot ? (budget - fixed) / per_slot : 1;
+        if (ctx->tune[BVHGPU_TUNE_WIDE_SLOTS] > 0) k = std::min<size_t>(k, (size_t)ctx->tune[BVHGPU_TUNE_WIDE_SLOTS]);
+        K = (uint32_t)std::max<size_t>(1, std::min<size_t>(k, WIDE_SLOTS));
+        lds_bytes = 16 + (size_t)K * per_slot + (size_t)stack_lds * threads * 4;
+    }
+};
+constexpr uint32_t WIDE_GSTACK = 24;   // stack entries per lane beyond the LDS part, in HBM (a walk pushes at most 3 per wide level)
+
+template <typename T, int MODE, int ITEMS_LOG4>
+static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, const WalkOut<T>& w, bvhgpu_hits* h,
+                        uint32_t* ovf_flag) {
+    bvhgpu_ctx* ctx = t->ctx;
+    const WideGeom<T> g(ctx);
+    const size_t n_items = n_rays << (2 * ITEMS_LOG4);
+    const size_t full = (n_items + WAVE - 1) / WAVE;
+    const uint32_t wpw = g.threads / WAVE;
+    const uint32_t n_waves = (uint32_t)std::min<size_t>(full, (size_t)ctx->n_cu * g.wg_per_cu * wpw);
+    const dim3 grid((n_waves + wpw - 1) / wpw);
+    const uint32_t ipw = (uint32_t)((n_items + grid.x - 1) / grid.x);   // items per workgroup
+    const size_t lanes = (size_t)grid.x * g.threads;
+    h->wstack.reserve(lanes * WIDE_GSTACK * 4);
+    constexpr int MAXT = sizeof(T) == 8 ? 512 : 1024;
+    constexpr int MINW = sizeof(T) == 8 ? BVH_WIDE_MIN_WAVES_F64 : BVH_WIDE_MIN_WAVES_F32;
+    auto kern = &k_traverse_wide<T, MODE, ITEMS_LOG4, MAXT, MINW>;
+    static thread_local size_t lds_attr[16] = {};   // per device: dynamic-LDS limit already set for this instantiation
+    size_t& have = lds_attr[ctx->device & 15];
+    if (have < g.lds_bytes) {
+        BVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
+        have = g.lds_bytes;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(g.threads), g.lds_bytes, ctx->stream, t->wide.as<WideNode<T>>(), t->wslot_node.as<uint32_t>(),
+                       g.K, g.stack_lds, rays_dev, (uint32_t)n_items, ipw, w, h->wstack.as<uint32_t>(), WIDE_GSTACK, ovf_flag);
+}
+
+// ---- one batch = enqueue (no host round trip) + check (after the stream has been synchronised) --------------------
+// What the enqueue decided is kept in the result object, so that the check — and an asynchronous caller's
+// bvhgpu_hits_wait — can replay the batch when the hit pool, a lane's heap or a lane's stack was too small.
 template <typename T>
-void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, unsigned flags,
-                    bvhgpu_hits* h) {
+void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, unsigned flags, bvhgpu_hits* h) {
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
     const bool stats = (flags & BVHGPU_TRAVERSE_STATS) != 0;
@@ -830,27 +1151,38 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
                    : (flags & BVHGPU_TRAVERSE_TRIANGLES) ? MODE_TRIANGLES
                    : (flags & BVHGPU_TRAVERSE_T_SLICE) ? MODE_T_SLICE : MODE_INDICES;
     const int nv = mode == MODE_T_SLICE ? 2 : (mode == MODE_TRIANGLES ? 3 : 0);
-    // walk kernel: one ray per lane per launch, or persistent workgroups with the top of the tree in LDS
-    const bool use_lds = ctx->tune[BVHGPU_TUNE_TRAVERSE_VARIANT] != 0 && t->slot_entry.p != nullptr && !coherent && !ordered &&
-                         n_rays >= (size_t)ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS];
-    // two items per ray (left / right subtree of the root) for the CSR modes: see k_traverse_lds
+    const int variant = ctx->tune[BVHGPU_TUNE_TRAVERSE_VARIANT];
+    const bool big_batch = !coherent && !ordered && n_rays >= (size_t)ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS];
+    // walk kernel: wide walk (see k_traverse_wide for what it needs), else persistent workgroups over the binary array with
+    // its top in LDS, else one ray per lane per launch
+    const bool use_wide = variant >= 3 && big_batch && t->has_wide && !t->exact_only && !t->unfolded && !stats &&
+                          mode != MODE_T_SLICE && !h->force_binary && t->n >= 2;
+    const bool use_lds = !use_wide && variant != 0 && t->slot_entry.p != nullptr && big_batch;
+    // several items per ray while a resident lane gets fewer than ~4 rays: the tail of the launch dominates there
+    const bool few_rays = n_rays < (size_t)ctx->n_cu * 2048 * 4;
     uint32_t split_at = 0;
-    if (use_lds && mode != MODE_CLOSEST && ctx->tune[BVHGPU_TUNE_TRAVERSE_SPLIT] != 0 && t->n >= 2 && !t->unfolded &&
-        n_rays < (size_t)ctx->n_cu * 2048 * 4) {   // fewer than 4 rays per resident lane: the tail dominates
+    if (use_lds && mode != MODE_CLOSEST && ctx->tune[BVHGPU_TUNE_TRAVERSE_SPLIT] != 0 && t->n >= 2 && !t->unfolded && few_rays)
         split_at = 1;   // the kernel reads the boundary itself: exit index of entry 0 (the root's left child)
+    int items_log4 = 0;
+    if (use_wide && mode != MODE_CLOSEST) {
+        const int want = ctx->tune[BVHGPU_TUNE_WIDE_ITEMS_LOG4];
+        items_log4 = want >= 0 ? std::min(want, 1) : (few_rays ? 1 : 0);
+        if ((n_rays << (2 * items_log4)) >= 0xFFFFFFFFull) items_log4 = 0;
     }
     const size_t n_items = split_at ? 2 * n_rays : n_rays;
     h->ctx = ctx; h->dtype = Traits<T>::dtype; h->n_rays = n_rays; h->flags = flags; h->total = 0;
     h->stats = bvhgpu_traverse_stats{0, 0, 0, 0, 0};
-    { const void* before = h->ctr.p; h->ctr.reserve(8 * sizeof(unsigned long long)); if (h->ctr.p != before) h->ctr_clean = false; }
-    unsigned long long* pin = reinterpret_cast<unsigned long long*>(ctx->pinned);
+    h->pend_tree = t; h->pend_rays = rays_dev; h->pend_wide = use_wide; h->pend_unfolded = t->unfolded || t->n == 1;
+    if (h->ctr.reserve(8 * sizeof(unsigned long long))) h->ctr_clean = false;
+    if (!h->pin) BVH_HIP(hipHostMalloc(&h->pin, 64, hipHostMallocDefault));
+    unsigned long long* pin = reinterpret_cast<unsigned long long*>(h->pin);
     unsigned long long* ctr = h->ctr.as<unsigned long long>();
 
     WalkOut<T> w;
     w.counts = nullptr; w.pool = nullptr; w.pool_v = nullptr; w.pool_cap = 0; w.ctr = ctr;
-    w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr;
+    w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr; w.item_cnt = nullptr;
 
-    uint32_t* ovf_flag = reinterpret_cast<uint32_t*>(ctr + 7);   // ordered walk: iterator stack (bit 0) / heap workspace (bit 1) overflow
+    uint32_t* ovf_flag = reinterpret_cast<uint32_t*>(ctr + 7);   // bit 0 ordered-iterator stack, bit 1 heap workspace, bit 2 wide-walk stack
     const bool best_first = ordered && (flags & BVHGPU_TRAVERSE_BEST_FIRST) != 0;
     const unsigned heap_grid = (unsigned)std::min<size_t>((n_rays + 255) / 256, (size_t)ctx->n_cu * 4);
     auto launch_ordered = [&](auto mode_tag, auto asc_tag) {
@@ -874,6 +1206,11 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
     auto dispatch_ordered = [&](auto mode_tag) {
         if (ordered == 1) launch_ordered(mode_tag, std::true_type{}); else launch_ordered(mode_tag, std::false_type{});
     };
+    auto dispatch_wide = [&](auto mode_tag) {
+        constexpr int M = decltype(mode_tag)::value;
+        if (M != MODE_CLOSEST && items_log4 == 1) launch_wide<T, M, (M == MODE_CLOSEST ? 0 : 1)>(t, rays_dev, n_rays, w, h, ovf_flag);
+        else launch_wide<T, M, 0>(t, rays_dev, n_rays, w, h, ovf_flag);
+    };
 #define DISPATCH_WALK()                                                                              \
     do {                                                                                             \
         if (ordered) {                                                                               \
@@ -881,6 +1218,14 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
                 case MODE_INDICES: dispatch_ordered(std::integral_constant<int, MODE_INDICES>{}); break;     \
                 case MODE_TRIANGLES: dispatch_ordered(std::integral_constant<int, MODE_TRIANGLES>{}); break; \
                 default: dispatch_ordered(std::integral_constant<int, MODE_CLOSEST>{}); break;       \
+            }                                                                                        \
+            break;                                                                                   \
+        }                                                                                            \
+        if (use_wide) {                                                                              \
+            switch (mode) {                                                                          \
+                case MODE_INDICES: dispatch_wide(std::integral_constant<int, MODE_INDICES>{}); break;        \
+                case MODE_TRIANGLES: dispatch_wide(std::integral_constant<int, MODE_TRIANGLES>{}); break;    \
+                default: dispatch_wide(std::integral_constant<int, MODE_CLOSEST>{}); break;          \
             }                                                                                        \
             break;                                                                                   \
         }                                                                                            \
@@ -896,119 +1241,167 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
         }                                                                                            \
     } while (0)
 
+    if (!h->ctr_clean) BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));
+    h->ctr_clean = false;
     if (mode == MODE_CLOSEST) {   // no CSR: one Intersection + shape per ray
         h->closest.reserve(std::max<size_t>(n_rays, 1) * 3 * sizeof(T));
         h->closest_prim.reserve(std::max<size_t>(n_rays, 1) * 4);
-        if (n_rays == 0) return;
+        if (n_rays == 0) { h->pend_tree = nullptr; return; }
         w.closest = h->closest.as<T>(); w.closest_prim = h->closest_prim.as<uint32_t>();
-        for (;;) {
-            if (!h->ctr_clean) BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));
-            h->ctr_clean = false;
-            if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
-            DISPATCH_WALK();
-            if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
-            hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);   // readback + reset for the next call
-            BVH_HIP(hipStreamSynchronize(st));
-            h->ctr_clean = true;
-            BVH_HIP(hipGetLastError());
-            if (best_first && (pin[7] & HEAP_OVERFLOW_BIT)) { h->heap_cap *= 2; continue; }   // a lane's heap outgrew the workspace
-            break;
-        }
-        if (ordered && (pin[7] & 1ull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
-        if (stats) {
-            const bool one_to_one = t->unfolded || t->n == 1;
-            h->stats.hits = pin[5];
-            h->stats.device_steps = pin[1];
-            h->stats.wave_steps = pin[4];
-            h->stats.visited = one_to_one ? pin[1] : pin[1] + pin[5];
-            h->stats.leaf_visits = one_to_one ? pin[2] : pin[5];
-        }
-        if (ctx->timing) ctx->ev_set |= 4u;
+        if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
+        DISPATCH_WALK();
+        if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
+        hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);   // readback + reset for the next call
+        h->ctr_clean = true;
         return;
     }
 
-    h->counts.reserve((n_items + 1) * 4);
     h->offsets.reserve((n_rays + 1) * 4);
     const uint32_t nb = (uint32_t)((n_rays + SCAN_BLOCK - 1) / SCAN_BLOCK);
     h->blocksums.reserve((nb + 1) * sizeof(unsigned long long));
     if (h->pool_cap == 0) h->pool_cap = std::max<size_t>(n_rays, (size_t)1 << 16);
     if (n_rays == 0) {
         BVH_HIP(hipMemsetAsync(h->offsets.p, 0, 4, st));
-        BVH_HIP(hipStreamSynchronize(st));
+        h->pend_tree = nullptr;
         return;
     }
-    for (int attempt = 0; attempt < (best_first ? 24 : 2); attempt++) {
-        h->pool.reserve(h->pool_cap * sizeof(HitRec));
-        h->indices.reserve(h->pool_cap * 4);
-        if (nv) {
-            h->pool_t.reserve(h->pool_cap * nv * sizeof(T));
-            (mode == MODE_T_SLICE ? h->tslice : h->isect).reserve(h->pool_cap * nv * sizeof(T));
-        }
-        if (!h->ctr_clean) BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));
-        h->ctr_clean = false;
-        const unsigned long long cap = h->pool_cap;
-        w.counts = h->counts.as<uint32_t>(); w.pool = h->pool.as<HitRec>(); w.pool_v = h->pool_t.as<T>(); w.pool_cap = cap;
-        uint32_t* counts = w.counts;
-        if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
-        DISPATCH_WALK();
-        if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); }
-        unsigned long long* bs = h->blocksums.as<unsigned long long>();
-        uint32_t* offs = h->offsets.as<uint32_t>();
-        if (split_at) hipLaunchKernelGGL(k_scan_reduce<true>, dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs);
-        else hipLaunchKernelGGL(k_scan_reduce<false>, dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs);
+    h->pool.reserve(h->pool_cap * sizeof(HitRec));
+    h->indices.reserve(h->pool_cap * 4);
+    if (nv) {
+        h->pool_t.reserve(h->pool_cap * nv * sizeof(T));
+        (mode == MODE_T_SLICE ? h->tslice : h->isect).reserve(h->pool_cap * nv * sizeof(T));
+    }
+    const unsigned long long cap = h->pool_cap;
+    uint32_t* counts;
+    if (use_wide) {   // per-ray words kept all-zero between batches (k_scan_final puts the zeros back)
+        if (h->wcounts.reserve((n_rays + 1) * 4)) h->wcounts_clean = false;
+        if (!h->wcounts_clean) BVH_HIP(hipMemsetAsync(h->wcounts.p, 0, h->wcounts.cap, st));
+        h->wcounts_clean = false;
+        h->ray_mask.reserve(n_rays + 1);
+        if (items_log4) h->item_cnt.reserve(((n_rays << (2 * items_log4)) + 1) * 4);
+        counts = h->wcounts.as<uint32_t>();
+        w.item_cnt = h->item_cnt.as<uint32_t>();
+    } else {
+        h->counts.reserve((n_items + 1) * 4);
+        counts = h->counts.as<uint32_t>();
+    }
+    w.counts = counts; w.pool = h->pool.as<HitRec>(); w.pool_v = h->pool_t.as<T>(); w.pool_cap = cap;
+    if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
+    DISPATCH_WALK();
+    if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); }
+    unsigned long long* bs = h->blocksums.as<unsigned long long>();
+    uint32_t* offs = h->offsets.as<uint32_t>();
+    uint8_t* rmask = h->ray_mask.as<uint8_t>();
+    const uint32_t nr = (uint32_t)n_rays;
+    const int kind = use_wide ? COUNT_MASKED : (split_at ? COUNT_PAIR : COUNT_PLAIN);
+    auto scan = [&](auto kind_tag) {
+        constexpr int KD = decltype(kind_tag)::value;
+        hipLaunchKernelGGL(k_scan_reduce<KD>, dim3(nb), dim3(256), 0, st, counts, nr, bs);
         if (nb > SCAN_FUSED_MAX_BLOCKS) {
             hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, bs, nb, ctr + 3);
-            if (split_at) hipLaunchKernelGGL((k_scan_final<true, true>), dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs, ctr + 3, offs);
-            else hipLaunchKernelGGL((k_scan_final<false, true>), dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs, ctr + 3, offs);
+            hipLaunchKernelGGL((k_scan_final<KD, true>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, rmask);
         } else {
-            if (split_at) hipLaunchKernelGGL((k_scan_final<true, false>), dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs, ctr + 3, offs);
-            else hipLaunchKernelGGL((k_scan_final<false, false>), dim3(nb), dim3(256), 0, st, counts, (uint32_t)n_rays, bs, ctr + 3, offs);
+            hipLaunchKernelGGL((k_scan_final<KD, false>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, rmask);
         }
-        const uint32_t* pair_counts = split_at ? counts : nullptr;
-        const int sgrid = (int)std::min<size_t>((cap + 255) / 256, (size_t)ctx->n_cu * 8);
-        T* vals = mode == MODE_T_SLICE ? h->tslice.as<T>() : h->isect.as<T>();
-        if (nv == 2)
-            hipLaunchKernelGGL((k_hits_scatter<T, 2>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap,
-                               offs, pair_counts, h->indices.as<uint32_t>(), vals);
-        else if (nv == 3)
-            hipLaunchKernelGGL((k_hits_scatter<T, 3>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap,
-                               offs, pair_counts, h->indices.as<uint32_t>(), vals);
-        else
-            hipLaunchKernelGGL((k_hits_scatter<T, 0>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap,
-                               offs, pair_counts, h->indices.as<uint32_t>(), vals);
-        if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
-        hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);   // readback + reset for the next call
-        BVH_HIP(hipStreamSynchronize(st));
-        h->ctr_clean = true;
-        BVH_HIP(hipGetLastError());
-        if (best_first && (pin[7] & HEAP_OVERFLOW_BIT)) { h->heap_cap *= 2; continue; }   // a lane's heap outgrew the workspace
-        if (ordered && (pin[7] & 1ull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
-        const unsigned long long used = pin[0];   // pool slots taken (whole chunks)
-        const unsigned long long total = pin[3];  // sum of the per-ray counts = number of hits
-        if (used < total) throw HipFail{hipErrorUnknown, "hit pool / count scan mismatch", __LINE__};
-        if (total > 0xFFFFFFFFull) throw HipFail{hipErrorInvalidValue, "OVERFLOW", __LINE__};
-        if (used > cap) {  // pool too small: grow to the need (deterministic: same chunks on replay) and replay
-            h->pool_cap = (size_t)used + (size_t)used / 8 + 1024;
-            continue;
+    };
+    if (kind == COUNT_MASKED) scan(std::integral_constant<int, COUNT_MASKED>{});
+    else if (kind == COUNT_PAIR) scan(std::integral_constant<int, COUNT_PAIR>{});
+    else scan(std::integral_constant<int, COUNT_PLAIN>{});
+    if (use_wide) h->wcounts_clean = true;   // (stays true only if the check finds that the batch ran to completion)
+    const uint32_t* pair_counts = split_at ? counts : nullptr;
+    const int sgrid = (int)std::min<size_t>((cap + 255) / 256, (size_t)ctx->n_cu * 8);
+    T* vals = mode == MODE_T_SLICE ? h->tslice.as<T>() : h->isect.as<T>();
+    uint32_t* indices = h->indices.as<uint32_t>();
+    if (use_wide) {
+        const uint32_t* icnt = h->item_cnt.as<uint32_t>();
+        if (nv == 3) {
+            if (items_log4) hipLaunchKernelGGL((k_hits_scatter_wide<T, 3, 1>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, icnt, rmask, indices, vals);
+            else hipLaunchKernelGGL((k_hits_scatter_wide<T, 3, 0>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, icnt, rmask, indices, vals);
+        } else {
+            if (items_log4) hipLaunchKernelGGL((k_hits_scatter_wide<T, 0, 1>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, icnt, rmask, indices, vals);
+            else hipLaunchKernelGGL((k_hits_scatter_wide<T, 0, 0>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, icnt, rmask, indices, vals);
         }
-        h->total = total;
-        h->stats.hits = total;
-        if (stats) {
-            h->stats.device_steps = pin[1];
-            h->stats.wave_steps = pin[4];
-            // reference-equivalent loop iterations (flat_bvh.rs:408): in the folded layout every
-            // reported leaf stands for a navigator visit plus a leaf-entry visit
-            const bool one_to_one = t->unfolded || t->n == 1;
-            h->stats.visited = one_to_one ? pin[1] : pin[1] + total;
-            h->stats.leaf_visits = one_to_one ? pin[2] : total;
-        }
-        if (ctx->timing) ctx->ev_set |= 4u;
-        return;
+    } else if (nv == 2) {
+        hipLaunchKernelGGL((k_hits_scatter<T, 2>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, pair_counts, indices, vals);
+    } else if (nv == 3) {
+        hipLaunchKernelGGL((k_hits_scatter<T, 3>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, pair_counts, indices, vals);
+    } else {
+        hipLaunchKernelGGL((k_hits_scatter<T, 0>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, pair_counts, indices, vals);
     }
-    throw HipFail{hipErrorUnknown, "hit pool did not converge", __LINE__};
+    if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
+    hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);   // readback + reset for the next call
+    h->ctr_clean = true;
 #undef DISPATCH_WALK
 }
 
+// After the stream has been synchronised: true = the batch is complete; false = something was too small and has been
+// grown (or the walk switched) — enqueue again.  Throws on the conditions the reference would panic on.
+bool traverse_check(bvhgpu_hits* h) {
+    if (!h->pend_tree) return true;   // nothing was launched (empty batch)
+    bvhgpu_ctx* ctx = h->ctx;
+    const unsigned flags = h->flags;
+    const bool stats = (flags & BVHGPU_TRAVERSE_STATS) != 0;
+    const bool ordered = (flags & (BVHGPU_TRAVERSE_NEAREST_FIRST | BVHGPU_TRAVERSE_FARTHEST_FIRST)) != 0;
+    const bool best_first = ordered && (flags & BVHGPU_TRAVERSE_BEST_FIRST) != 0;
+    const unsigned long long* pin = reinterpret_cast<const unsigned long long*>(h->pin);
+    BVH_HIP(hipGetLastError());
+    if (best_first && (pin[7] & HEAP_OVERFLOW_BIT)) {   // a lane's heap outgrew the workspace
+        if (++h->pend_attempts > 24) throw HipFail{hipErrorUnknown, "best-first heap did not converge", __LINE__};
+        h->heap_cap *= 2; h->wcounts_clean = false; return false;
+    }
+    if (ordered && (pin[7] & 1ull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
+    if (h->pend_wide && (pin[7] & 4ull)) {   // a lane's stack outgrew LDS + workspace: the binary walks need no stack
+        h->force_binary = true; h->wcounts_clean = false; return false;
+    }
+    if (flags & BVHGPU_TRAVERSE_CLOSEST) {
+        if (stats) {
+            h->stats.hits = pin[5];
+            h->stats.device_steps = pin[1];
+            h->stats.wave_steps = pin[4];
+            h->stats.visited = h->pend_unfolded ? pin[1] : pin[1] + pin[5];
+            h->stats.leaf_visits = h->pend_unfolded ? pin[2] : pin[5];
+        }
+        if (ctx->timing) ctx->ev_set |= 4u;
+        h->pend_tree = nullptr;
+        return true;
+    }
+    const unsigned long long used = pin[0];   // pool slots taken (whole chunks)
+    const unsigned long long total = pin[3];  // sum of the per-ray counts = number of hits
+    if (used < total) throw HipFail{hipErrorUnknown, "hit pool / count scan mismatch", __LINE__};
+    if (total > 0xFFFFFFFFull) throw HipFail{hipErrorInvalidValue, "OVERFLOW", __LINE__};
+    if (used > h->pool_cap) {  // pool too small: grow to the need (deterministic: same chunks on replay) and replay
+        if (++h->pend_attempts > 3) throw HipFail{hipErrorUnknown, "hit pool did not converge", __LINE__};
+        h->pool_cap = (size_t)used + (size_t)used / 8 + 1024;
+        return false;
+    }
+    h->total = total;
+    h->stats.hits = total;
+    if (stats) {
+        h->stats.device_steps = pin[1];
+        h->stats.wave_steps = pin[4];
+        // reference-equivalent loop iterations (flat_bvh.rs:408): in the folded layout every
+        // reported leaf stands for a navigator visit plus a leaf-entry visit
+        h->stats.visited = h->pend_unfolded ? pin[1] : pin[1] + total;
+        h->stats.leaf_visits = h->pend_unfolded ? pin[2] : total;
+    }
+    if (ctx->timing) ctx->ev_set |= 4u;
+    h->pend_tree = nullptr;
+    return true;
+}
+
+template <typename T>
+void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, unsigned flags,
+                    bvhgpu_hits* h) {
+    h->force_binary = false; h->pend_attempts = 0;
+    for (;;) {
+        traverse_enqueue<T>(t, rays_dev, n_rays, flags, h);
+        BVH_HIP(hipStreamSynchronize(t->ctx->stream));
+        if (traverse_check(h)) return;
+    }
+}
+
+template void traverse_enqueue<float>(bvhgpu_tree*, const bvhgpu_ray_f32*, size_t, unsigned, bvhgpu_hits*);
+template void traverse_enqueue<double>(bvhgpu_tree*, const bvhgpu_ray_f64*, size_t, unsigned, bvhgpu_hits*);
 template void traverse_batch<float>(bvhgpu_tree*, const bvhgpu_ray_f32*, size_t, unsigned, bvhgpu_hits*);
 template void traverse_batch<double>(bvhgpu_tree*, const bvhgpu_ray_f64*, size_t, unsigned, bvhgpu_hits*);
 

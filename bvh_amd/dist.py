@@ -1,13 +1,21 @@
 """Multi-GPU plumbing of the path: rays shard, the scene is broadcast once.
 
-One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in CPU tests).  The
-path has exactly one exchange step: rank `src` built and flattened the tree; its scene blob
-(bvhgpu_scene_export: traversal array + shape AABBs) goes to every peer in ONE broadcast.  Hit lists
-stay on the GPU that produced them — there is no gather/all-reduce on the data path.
+One process per GPU.  The path has exactly one exchange step: rank `root` built and flattened the tree; its traversal
+array, shape AABBs and LDS slot table go to every peer in RCCL broadcasts issued by the C ABI itself (bvhgpu_bcast /
+bvhgpu_bcast_known, csrc/comm.hip: ncclBroadcast straight from / into the trees' HBM buffers over xGMI).  Hit lists stay
+on the GPU that produced them — there is no gather / all-reduce on the data path.  torch.distributed (or anything else
+that can move 128 bytes) is only the launcher's rendezvous for the RCCL unique id, and the bench's barrier.
+
+The older transport — export a scene blob, broadcast it with torch.distributed, import it on the peers — is kept
+(broadcast_scene) for backends without RCCL (the gloo CPU tests) and as the fallback of bench.py.
 """
 from __future__ import annotations
 
-from typing import Tuple
+import ctypes as C
+from typing import Optional, Tuple
+
+from . import _lib
+from ._lib import check
 
 
 def shard_range(rank: int, world: int, rays_per_gpu: int) -> Tuple[int, int]:
@@ -18,8 +26,85 @@ def shard_range(rank: int, world: int, rays_per_gpu: int) -> Tuple[int, int]:
     return rank * rays_per_gpu, rays_per_gpu
 
 
+def strong_shard(rank: int, world: int, total_rays: int) -> Tuple[int, int]:
+    """Strong-scaling shard (BASELINE.json configs[3]: 100 M rays sharded over the GPUs): rank r owns the contiguous slice
+    [r*T/W, (r+1)*T/W) of the stream — the slices tile [0, T) exactly for any T, W."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    lo = rank * total_rays // world
+    hi = (rank + 1) * total_rays // world
+    return lo, hi - lo
+
+
+class Communicator:
+    """bvhgpu_comm: the RCCL communicator of the C ABI, one rank per process (bvhgpu_comm_init_rank)."""
+
+    def __init__(self, ctx, nranks: int, rank: int, unique_id: bytes):
+        lib = _lib.load()
+        if len(unique_id) != _lib.COMM_ID_BYTES:
+            raise ValueError("RCCL unique id must be 128 bytes")
+        h = C.c_void_p()
+        buf = (C.c_char * _lib.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        check(lib.bvhgpu_comm_init_rank(ctx._h, int(nranks), int(rank), C.cast(buf, C.c_void_p), C.byref(h)), ctx._h)
+        self._h = h
+        self.ctx = ctx
+        self.nranks = int(nranks)
+        self.rank = int(rank)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_char * _lib.COMM_ID_BYTES)()
+        check(_lib.load().bvhgpu_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    @staticmethod
+    def from_torch_distributed(ctx, device=None) -> "Communicator":
+        """Rendezvous through an initialised torch.distributed process group of any backend: rank 0 draws the id and the
+        128 bytes are broadcast as a tensor (on `device` for the nccl backend, on the CPU for gloo)."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(), dist.get_world_size()
+        on = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+        t = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8, device=on)
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(Communicator.unique_id()), dtype=torch.uint8))
+        dist.broadcast(t, 0)
+        return Communicator(ctx, world, rank, bytes(t.cpu().numpy().tobytes()))
+
+    def bcast(self, tree, root: int = 0, dtype: Optional[str] = None, n_shapes: Optional[int] = None, triangles: bool = False):
+        """Collective.  `tree`: on the root the Bvh / FlatBvh to send; on a peer None (a FlatBvh is created) or the FlatBvh an
+        earlier bcast returned (its HBM is reused).  With dtype ("f32"/"f64") and n_shapes known to every rank the broadcast
+        is enqueued without any host round trip (bvhgpu_bcast_known); otherwise a header travels first.  Returns the tree."""
+        from .api import FlatBvh
+        lib = _lib.load()
+        arr = (C.c_void_p * 1)(tree._t if tree is not None else None)
+        if dtype is not None and n_shapes is not None:
+            check(lib.bvhgpu_bcast_known(self._h, arr, int(root), _lib.F32 if dtype == "f32" else _lib.F64, int(n_shapes),
+                                         _lib.BCAST_TRIANGLES if triangles else 0), self.ctx._h)
+        else:
+            check(lib.bvhgpu_bcast(self._h, arr, int(root)), self.ctx._h)
+        if tree is not None:
+            return tree
+        dt = C.c_int()
+        h = C.c_void_p(arr[0])
+        check(lib.bvhgpu_tree_info(h, C.byref(dt), None, None, None), self.ctx._h)
+        return FlatBvh(self.ctx, h, "f32" if dt.value == _lib.F32 else "f64")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().bvhgpu_comm_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def broadcast_scene(blob, src: int = 0):
-    """Broadcast the scene blob tensor in place (uint8 tensor on the GPU for nccl/RCCL, CPU for gloo)."""
+    """Fallback transport: broadcast the scene blob tensor in place with torch.distributed (uint8 tensor on the GPU for
+    nccl/RCCL, CPU for gloo)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.broadcast(blob, src)

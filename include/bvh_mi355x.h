@@ -22,7 +22,11 @@
  *    = 6 (src/bvh/bucket.rs:5), pre-order node placement (src/bvh/bvh_node.rs:138-142), stable
  *    bucket-major index rewrite (:250-272), strict-< first-wins SAH argmin (:239), surface_area =
  *    2*dot(size,size) (src/aabb/aabb_impl.rs:551-554), NaN-in-slab = miss
- *    (src/ray/intersect_default.rs:22-28).  Inputs are assumed NaN-free, as in the reference.
+ *    (src/ray/intersect_default.rs:22-28).
+ *  - Input contract of the builders: the reference panics on a NaN (or infinite) centroid — `to_usize().unwrap()`,
+ *    src/bvh/bvh_node.rs:214-217.  bvhgpu_build_* / rebuild_* detect NaN / ±inf in the shape AABBs (and finite boxes whose
+ *    centroid extent overflows) on the device and return BVHGPU_INVALID_ARG without building anything; a single shape
+ *    is never bucketed and is accepted as in the reference.
  */
 #ifndef BVH_MI355X_H
 #define BVH_MI355X_H
@@ -34,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BVHGPU_ABI_VERSION 1
+#define BVHGPU_ABI_VERSION 2
 #define BVHGPU_NONE 0xFFFFFFFFu /* u32::MAX marker (flat_bvh.rs:51-53, :124, :137) */
 
 typedef enum {
@@ -45,7 +49,8 @@ typedef enum {
     BVHGPU_OVERFLOW = 4,   /* > (2^32-2)/3 shapes (flat_bvh.rs:136 would truncate silently) or > 2^32-1 hits */
     BVHGPU_NO_DEVICE = 5,
     BVHGPU_DTYPE_MISMATCH = 6,
-    BVHGPU_NOT_FLATTENED = 7
+    BVHGPU_NOT_FLATTENED = 7,
+    BVHGPU_RCCL_ERROR = 8  /* an RCCL call of the multi-GPU broadcast failed (bvhgpu_last_error has ncclGetErrorString) */
 } bvhgpu_status;
 
 typedef enum { BVHGPU_F32 = 0, BVHGPU_F64 = 1 } bvhgpu_dtype;
@@ -117,7 +122,9 @@ void *bvhgpu_stream(bvhgpu_ctx *ctx); /* the hipStream_t work is enqueued on */
  * (bvh_impl.rs:57-59).  The caller keeps `aabbs`; the tree owns its own HBM copy. ---- */
 int bvhgpu_build_f32(bvhgpu_ctx *ctx, const float *aabbs, size_t n, int mem, bvhgpu_tree **out);
 int bvhgpu_build_f64(bvhgpu_ctx *ctx, const double *aabbs, size_t n, int mem, bvhgpu_tree **out);
-/* Rebuild in place (same dtype, n <= capacity of the first build): no allocation on the hot loop. */
+/* Rebuild in place (same dtype, n <= capacity of the first build): no allocation on the hot loop.  A different shape count
+ * drops the triangle vertices of bvhgpu_tree_set_triangles (one triangle per shape); with the same count they are kept and
+ * are the caller's to refresh. */
 int bvhgpu_rebuild_f32(bvhgpu_tree *tree, const float *aabbs, size_t n, int mem);
 int bvhgpu_rebuild_f64(bvhgpu_tree *tree, const double *aabbs, size_t n, int mem);
 /* FlatBvh::build (flat_bvh.rs:328-331) = Bvh::build + Bvh::flatten in ONE call (one host round trip): the tree is
@@ -137,6 +144,22 @@ int bvhgpu_rebuild_flat_f64(bvhgpu_tree *tree, const double *aabbs, size_t n, in
 int bvhgpu_refit_f32(bvhgpu_tree *tree, const float *aabbs, size_t n, int mem);
 int bvhgpu_refit_f64(bvhgpu_tree *tree, const double *aabbs, size_t n, int mem);
 void bvhgpu_tree_destroy(bvhgpu_tree *tree);
+
+/* ---- asynchronous step.  The calls above return when their result is complete (one host round trip each).  These
+ * enqueue the same work on the ctx's stream and return at once, so that ONE host thread can keep several steps in flight
+ * (on several ctxs = several streams: the latency-bound build of one step overlaps the traversal of another).
+ *   bvhgpu_rebuild_flat_async_*  = bvhgpu_rebuild_flat_* (Bvh::build_par + Bvh::flatten) without the wait.  `aabbs` must stay
+ *                                  valid until the wait (BVHGPU_HOST: pinned memory, or the copy is synchronous anyway).
+ *   bvhgpu_traverse_async_*      = bvhgpu_traverse_* on rays resident in HBM (mem must be BVHGPU_DEVICE); the tree may
+ *                                  still be building on the same stream.
+ *   bvhgpu_hits_wait             completes the batch: waits for the stream, completes the tree's build (input validation;
+ *                                  an unbalanced tree is finished level by level) and replays the batch if the optimistic
+ *                                  launch was not enough (hit pool too small, tree not finished when the walk ran).  The
+ *                                  statuses the synchronous calls would have returned are returned here.
+ *   bvhgpu_tree_wait             the same for a tree alone.  Every other entry point that looks at a tree waits by itself. */
+int bvhgpu_rebuild_flat_async_f32(bvhgpu_tree *tree, const float *aabbs, size_t n, int mem);
+int bvhgpu_rebuild_flat_async_f64(bvhgpu_tree *tree, const double *aabbs, size_t n, int mem);
+int bvhgpu_tree_wait(bvhgpu_tree *tree);
 
 int bvhgpu_tree_info(const bvhgpu_tree *tree, int *dtype, size_t *n_shapes, size_t *n_nodes, size_t *n_flat);
 /* Vec<BvhNode> (bvh_impl.rs:27-33): 2n-1 entries of bvhgpu_node_f32/_f64. */
@@ -165,6 +188,32 @@ int bvhgpu_tree_from_flat_f64(bvhgpu_ctx *ctx, const bvhgpu_flat_f64 *flat, size
 int bvhgpu_scene_nbytes(const bvhgpu_tree *tree, size_t *nbytes);
 int bvhgpu_scene_export(bvhgpu_tree *tree, void *dst, int mem);
 int bvhgpu_scene_import(bvhgpu_ctx *ctx, const void *src, size_t nbytes, int mem, bvhgpu_tree **out);
+
+/* ---- multi-GPU: rays shard across the GPUs of a node, the tree is read-only after flatten — the path has
+ * exactly ONE exchange step, a broadcast of the root's flattened tree to the peers, done here with RCCL over xGMI
+ * straight out of / into the trees' own HBM buffers (traversal array, shape AABBs, LDS slot table, optionally the
+ * triangle vertices).  Hit lists stay on the GPU that produced them.  The reference has no counterpart (single
+ * address space); this is what replaces sharing `&FlatBvh` between rayon workers.
+ * A communicator is formed either by ONE process over `ndev` ctxs (one per GPU, ncclCommInitAll), or by one process per
+ * GPU: rank 0 calls bvhgpu_comm_unique_id, the launcher carries the 128 bytes to the peers (MPI, a torch.distributed
+ * store, a file …) and every rank calls bvhgpu_comm_init_rank.  `trees` has one entry per LOCAL device of the
+ * communicator (one entry in the process-per-GPU form); the root's entry is the source, a peer's entry is NULL (a tree
+ * is allocated) or the result of an earlier broadcast / scene import on that ctx (its HBM is reused).  Received trees
+ * support traversal and point queries only (no BvhNode array).  The calls are collective: every rank must make them. */
+typedef struct bvhgpu_comm bvhgpu_comm;
+#define BVHGPU_COMM_ID_BYTES 128
+#define BVHGPU_BCAST_TRIANGLES 1u
+int bvhgpu_comm_unique_id(void *id_out /* BVHGPU_COMM_ID_BYTES */);
+int bvhgpu_comm_init_rank(bvhgpu_ctx *ctx, int nranks, int rank, const void *id, bvhgpu_comm **out);
+int bvhgpu_comm_init_all(bvhgpu_ctx *const *ctxs, int ndev, bvhgpu_comm **out);
+int bvhgpu_comm_info(const bvhgpu_comm *comm, int *nranks, int *first_rank, int *n_local);
+void bvhgpu_comm_destroy(bvhgpu_comm *comm);
+/* peers learn type and size from a 64-byte header that travels first (one host round trip per rank) */
+int bvhgpu_bcast(bvhgpu_comm *comm, bvhgpu_tree **trees, int root);
+/* every rank already knows dtype and shape count (a frame loop over a scene of constant size): one group of broadcasts
+ * enqueued on the ctxs' streams, no host round trip; `what`: BVHGPU_BCAST_TRIANGLES to send the vertices too.  The root's
+ * tree must be a tree built (or received) here with exactly that dtype / shape count. */
+int bvhgpu_bcast_known(bvhgpu_comm *comm, bvhgpu_tree **trees, int root, int dtype, size_t n_shapes, unsigned what);
 
 /* ---- rays ---- */
 /* Ray::new (ray_impl.rs:70-80) for a batch: normalise, cache 1/d.  origins/dirs: n x 3. */
@@ -211,6 +260,11 @@ int bvhgpu_traverse_f32(bvhgpu_tree *tree, const bvhgpu_ray_f32 *rays, size_t n_
                         bvhgpu_hits **hits);
 int bvhgpu_traverse_f64(bvhgpu_tree *tree, const bvhgpu_ray_f64 *rays, size_t n_rays, int mem, unsigned flags,
                         bvhgpu_hits **hits);
+int bvhgpu_traverse_async_f32(bvhgpu_tree *tree, const bvhgpu_ray_f32 *rays, size_t n_rays, int mem, unsigned flags,
+                              bvhgpu_hits **hits);
+int bvhgpu_traverse_async_f64(bvhgpu_tree *tree, const bvhgpu_ray_f64 *rays, size_t n_rays, int mem, unsigned flags,
+                              bvhgpu_hits **hits);
+int bvhgpu_hits_wait(bvhgpu_hits *hits);
 /* Triangle vertices of the shapes (n x [a xyz, b xyz, c xyz], the fields of testbase.rs Triangle :316-323) for the
  * TRIANGLES / CLOSEST flags; n must equal the tree's shape count.  The tree keeps its own HBM copy. */
 int bvhgpu_tree_set_triangles_f32(bvhgpu_tree *tree, const float *verts, size_t n, int mem);
@@ -244,16 +298,20 @@ int bvhgpu_triangles_aabbs_f32(const float *tris, size_t n, float *aabbs_out);
 
 /* ---- tuning knobs (performance only; results never change).  Not part of the reference surface. ---- */
 typedef enum {
-    BVHGPU_TUNE_TRAVERSE_VARIANT = 0,      /* 0 one ray per lane per launch; 2 (default) persistent workgroups with ray
-                                              refill and the top of the tree resident in LDS */
-    BVHGPU_TUNE_RESERVED_1 = 1,
-    BVHGPU_TUNE_RESERVED_2 = 2,
+    BVHGPU_TUNE_TRAVERSE_VARIANT = 0,      /* 0 one ray per lane per launch; 2 persistent workgroups over the binary traversal
+                                              array with ray refill and the top of the tree resident in LDS; 3 (default) wide
+                                              walk (four grandchild boxes per step) where its preconditions hold, else 2 */
+    BVHGPU_TUNE_WIDE_ITEMS_LOG4 = 1,       /* variant 3, CSR outputs: walk every ray as 4^v items (0 or 1); default -1 = by batch size */
+    BVHGPU_TUNE_WIDE_STACK_LDS = 2,        /* variant 3: stack entries per lane kept in LDS (default -1 = 8; deeper entries live in HBM) */
     BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS = 3, /* variant 2 is used for batches of at least this many rays (default 16384) */
     BVHGPU_TUNE_TRAVERSE_LDS_SLOTS = 4,    /* variant 2: top-of-tree entries kept in LDS per workgroup (default 0 = as many as let two workgroups share a CU: f32 2559, f64 1462) */
     BVHGPU_TUNE_TRAVERSE_LDS_THREADS = 5,  /* variant 2: workgroup size (default 0 = per type: f32 1024, f64 512) */
     BVHGPU_TUNE_TRAVERSE_SPLIT = 6,        /* variant 2, CSR outputs: walk every ray as two items (left / right subtree of the
                                               root); default 1 */
-    BVHGPU_TUNE_COUNT = 8
+    BVHGPU_TUNE_WIDE_WG_PER_CU = 7,        /* variant 3: workgroups sharing a CU's LDS (default 0 = 2) */
+    BVHGPU_TUNE_WIDE_THREADS = 8,          /* variant 3: workgroup size (default 0 = per type: f32 1024, f64 512) */
+    BVHGPU_TUNE_WIDE_SLOTS = 9,            /* variant 3: cap on the top-of-tree wide nodes kept in LDS (default 0 = what fits) */
+    BVHGPU_TUNE_COUNT = 12
 } bvhgpu_tune;
 int bvhgpu_set_tuning(bvhgpu_ctx *ctx, int knob, int value);
 int bvhgpu_get_tuning(const bvhgpu_ctx *ctx, int knob, int *value);

@@ -49,22 +49,48 @@ def build_library(force: bool = False) -> str:
 
 
 _lib = None
+_native = False
+
+
+def _load(path):
+    l = C.CDLL(path)
+    l.orc_splitmix64.restype = C.c_uint64
+    l.orc_max_threads.restype = C.c_int
+    for s, ct in (("f32", C.c_float), ("f64", C.c_double)):
+        getattr(l, f"orc_surface_area_{s}").restype = ct
+        getattr(l, f"orc_ray_triangle_{s}").restype = ct
+        getattr(l, f"orc_flatten_{s}").restype = C.c_size_t
+        getattr(l, f"orc_traverse_flat_{s}").restype = C.c_uint64
+        getattr(l, f"orc_traverse_tree_{s}").restype = C.c_uint64
+    return l
 
 
 def lib():
     global _lib
     if _lib is None:
         build_library()
-        _lib = C.CDLL(_SO)
-        _lib.orc_splitmix64.restype = C.c_uint64
-        _lib.orc_max_threads.restype = C.c_int
-        for s, ct in (("f32", C.c_float), ("f64", C.c_double)):
-            getattr(_lib, f"orc_surface_area_{s}").restype = ct
-            getattr(_lib, f"orc_ray_triangle_{s}").restype = ct
-            getattr(_lib, f"orc_flatten_{s}").restype = C.c_size_t
-            getattr(_lib, f"orc_traverse_flat_{s}").restype = C.c_uint64
-            getattr(_lib, f"orc_traverse_tree_{s}").restype = C.c_uint64
+        _lib = _load(_SO)
     return _lib
+
+
+def use_native() -> bool:
+    """bench.py's cpu_baseline leg only: rebuild the oracle ON THIS BOX with -O3 -march=native (still
+    -ffp-contract=off, so results do not change) and route every call of this module through it.  False (and the portable
+    -O2 build stays in use) if the box has no compiler."""
+    global _lib, _native
+    so = os.path.join(_HERE, "liboracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle_native.so"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+        _lib = _load(so)
+        _native = True
+    except Exception:
+        _native = False
+    return _native
+
+
+def is_native() -> bool:
+    return _native
 
 
 def _p(a):

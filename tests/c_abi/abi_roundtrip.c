@@ -51,6 +51,27 @@ int main(int argc, char** argv) {
     uint32_t ns_; float nd_;
     CHECK(bvhgpu_nearest_f32(tree, q, 1, BVHGPU_HOST, 0, &ns_, &nd_));
     printf("nearest %u %.6f\n", ns_, nd_);
+    /* the multi-GPU exchange step with the one device this box has: a one-rank RCCL communicator (ncclCommInitAll),
+     * the broadcast of the flattened tree (in place on the root), both forms; then the same two rays on the result */
+    bvhgpu_comm* comm = NULL;
+    bvhgpu_ctx* ctxs[1] = {ctx};
+    CHECK(bvhgpu_comm_init_all(ctxs, 1, &comm));
+    int nranks = -1, first = -1, nlocal = -1;
+    CHECK(bvhgpu_comm_info(comm, &nranks, &first, &nlocal));
+    bvhgpu_tree* trees[1] = {tree};
+    CHECK(bvhgpu_bcast(comm, trees, 0));
+    CHECK(bvhgpu_bcast_known(comm, trees, 0, BVHGPU_F32, n, 0u));
+    CHECK(bvhgpu_traverse_f32(trees[0], rays, 2, BVHGPU_HOST, 0u, &hits));
+    uint64_t total2;
+    CHECK(bvhgpu_hits_info(hits, &nr, &total2, NULL));
+    printf("comm ranks %d first %d local %d; after bcast total %llu\n", nranks, first, nlocal, (unsigned long long)total2);
+    bvhgpu_comm_destroy(comm);
+    /* the process-per-GPU form with one rank */
+    unsigned char id[BVHGPU_COMM_ID_BYTES];
+    CHECK(bvhgpu_comm_unique_id(id));
+    CHECK(bvhgpu_comm_init_rank(ctx, 1, 0, id, &comm));
+    CHECK(bvhgpu_bcast(comm, trees, 0));
+    bvhgpu_comm_destroy(comm);
     bvhgpu_hits_destroy(hits);
     bvhgpu_tree_destroy(tree);
     bvhgpu_destroy(ctx);

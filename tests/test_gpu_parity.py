@@ -48,6 +48,9 @@ def _full_parity(eng, orc, aabbs, rays, t_rtol):
     if len(idx):
         assert np.allclose(ts, ots, rtol=t_rtol, atol=0)
     assert st["hits"] == ost["hits"] and st["visited"] == ost["visited"] and st["leaf_visits"] == ost["leaf_visits"]
+    # the same batch without STATS / T_SLICE: the default walk for large batches (the wide walk) must give the same CSR
+    off2, idx2, _, _ = flat.traverse_batch(_rb(eng, rays))
+    assert np.array_equal(off2, ooff) and np.array_equal(idx2, oidx)
     return bvh, flat, ot, oflat
 
 
@@ -116,18 +119,19 @@ def test_parity_config0_1200_triangles(eng, orc):
 
 
 def test_parity_config1_120k_triangles(eng, orc):
-    """BASELINE.json configs[1] geometry at full size; rays: a 250 k prefix of the 1 M stream
-    (the full stream is covered by test_full_size_properties)."""
+    """BASELINE.json configs[1] at full size: 120 k triangles, ALL 1 M rays of the seed-0 stream — nodes, flat array,
+    CSR (order included), t-slices and visit counters against the oracle (which needs < 1 s for it, multi-threaded)."""
     from bvh_amd import testbase as tb
     _, aabbs = tb.create_n_cubes(10_000)
-    bvh, flat, ot, oflat = _full_parity(eng, orc, aabbs, orc.create_rays(0, 250_000), 1e-5)
+    bvh, flat, ot, oflat = _full_parity(eng, orc, aabbs, orc.create_rays(0, 1_000_000), 1e-5)
     assert orc.check_tree(bvh.nodes, aabbs) == 0  # assert_consistent + assert_tight + coverage on the GPU tree
 
 
 def test_parity_config4_f64(eng, orc):
+    """BASELINE.json configs[4] at full size: the same scene and ALL 1 M rays in f64 (t-values within 1e-12 relative)."""
     from bvh_amd import testbase as tb
     _, aabbs = tb.create_n_cubes(10_000)
-    r32 = orc.create_rays(0, 50_000)
+    r32 = orc.create_rays(0, 1_000_000)
     rays = orc.make_rays(r32["o"].astype(np.float64), r32["d"].astype(np.float64), np.float64)
     _full_parity(eng, orc, aabbs.astype(np.float64), rays, 1e-12)
 
@@ -322,6 +326,32 @@ def test_traversal_variants_same_result(eng, orc, variant, slots, threads, dtype
     if variant == 2:
         ctx.set_tuning(TUNE_TRAVERSE_LDS_SLOTS, slots)
         ctx.set_tuning(TUNE_TRAVERSE_LDS_THREADS, threads)
+    _variant_suite(eng, orc, ctx, dtype)
+
+
+@pytest.mark.parametrize("items,stack_lds,wg_per_cu,threads,slots", [(-1, -1, 0, 0, 0), (0, 8, 2, 1024, 0), (1, 8, 2, 1024, 0),
+                                                                      (1, 0, 2, 512, 0), (1, 2, 1, 1024, 0), (0, 3, 4, 256, 1),
+                                                                      (1, 32, 1, 64, 5), (1, 6, 2, 512, 341)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_wide_walk_same_result(eng, orc, items, stack_lds, wg_per_cu, threads, slots, dtype):
+    """The wide walk (four grandchild boxes per step, k_traverse_wide) under every geometry knob: 1 / 4 items per ray,
+    the per-lane stack entirely in LDS / entirely in HBM / split, 1..4 workgroups per CU, 1..341 resident top nodes.
+    Same scenes as the other variants: the CSR must equal the oracle's, order included."""
+    from bvh_amd import Context
+    from bvh_amd._lib import (TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_TRAVERSE_VARIANT, TUNE_WIDE_ITEMS_LOG4, TUNE_WIDE_SLOTS,
+                              TUNE_WIDE_STACK_LDS, TUNE_WIDE_THREADS, TUNE_WIDE_WG_PER_CU)
+    ctx = Context(0)
+    ctx.set_tuning(TUNE_TRAVERSE_VARIANT, 3)
+    ctx.set_tuning(TUNE_TRAVERSE_LDS_MIN_RAYS, 0)
+    ctx.set_tuning(TUNE_WIDE_ITEMS_LOG4, items)
+    ctx.set_tuning(TUNE_WIDE_STACK_LDS, stack_lds)
+    ctx.set_tuning(TUNE_WIDE_WG_PER_CU, wg_per_cu)
+    ctx.set_tuning(TUNE_WIDE_THREADS, threads)
+    ctx.set_tuning(TUNE_WIDE_SLOTS, slots)
+    _variant_suite(eng, orc, ctx, dtype, deep=True)
+
+
+def _variant_suite(eng, orc, ctx, dtype, deep=False):
     rtol = 1e-5 if dtype == np.float32 else 1e-12
     rng = np.random.default_rng(77)
 
@@ -370,6 +400,24 @@ def test_traversal_variants_same_result(eng, orc, variant, slots, threads, dtype
     oflat = orc.flatten(orc.build(small).nodes)
     moved = small.copy(); moved[::3, [0, 3]] += dtype(0.75)
     check(small, orc.make_rays(o[:4000], d[:4000], dtype), flat_upload=(oflat, moved))
+    if deep:
+        # a very unbalanced tree (SAH peels a few hundred shapes per level) with rays through ALL boxes: the per-lane stack of
+        # the wide walk leaves LDS, then its HBM part; beyond that the batch must be replayed with the stackless binary walk
+        nd = 6000
+        xs = dtype(1.004) ** np.arange(nd, dtype=dtype)
+        lo3 = np.stack([xs, np.zeros(nd, dtype), np.zeros(nd, dtype)], axis=1)
+        chain = np.concatenate([lo3, lo3 + dtype(0.5)], axis=1)
+        o3 = np.zeros((300, 3), dtype); o3[:, 0] = -1; o3[:, 1] = np.linspace(0.01, 0.49, 300); o3[:, 2] = 0.25
+        d3 = np.tile(np.array([1, 0, 0], dtype), (300, 1)); d3[::7] = [1, 0.001, 0]
+        check(chain, orc.make_rays(o3, d3, dtype))
+        # splits with no SAH winner: boxes so far apart that every surface area overflows to inf make every cost NaN, so
+        # min_bucket stays 0 and both children get EMPTY bounds (bvh_node.rs:225-230) — a child box is then not the join of
+        # its grandchildren and the engine must keep to the walk that tests every ancestor
+        big = dtype(1e19 if dtype == np.float32 else 1e154)
+        lo4 = (rng.uniform(-1, 1, size=(500, 3)) * big).astype(dtype)
+        far = np.concatenate([lo4, lo4 + big * dtype(0.01)], axis=1)
+        o4 = (rng.uniform(-1, 1, size=(600, 3)) * big).astype(dtype)
+        check(far, orc.make_rays(o4, d[:600], dtype))
 
 
 # ------------------------------------------------------------------ triangle stage
@@ -865,6 +913,8 @@ def test_c_abi_from_plain_c(eng, orc, tmp_path):
         assert out[2 + r] == (f"ray {r}: {want}" if want else f"ray {r}:")
     s, d = orc.nearest(oflat, aabbs, [[2.2, 0.1, 3.9]])
     assert out[4] == f"nearest {int(s[0])} {d[0]:.6f}"
+    # the RCCL exchange step through the C ABI (one-rank communicator on this one-GPU box): the tree survives a broadcast
+    assert out[5] == f"comm ranks 1 first 0 local 1; after bcast total {len(oidx)}"
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BVH_FUZZ_SEEDS", "12"))))   # BVH_FUZZ_SEEDS=400 for a long soak
