@@ -1,29 +1,38 @@
 #!/usr/bin/env python3
 """bench.py — BASELINE.json's metric on MI355X: Mrays/s for build + flatten + traverse.
 
-One STEP = one pass of the hot path over one batch of synthetic input that is already resident in
-HBM: Bvh::build_par (SAH) → Bvh::flatten → FlatBvh::traverse of R rays, results left in HBM as CSR.
-Workload at every N: BASELINE.json configs[1] — create_n_cubes(10 000) = 120 000 triangles f32/3D and
-R = 1 000 000 create_ray rays PER GPU (weak scaling: rank r traverses rays [r*R, (r+1)*R) of the
-seed-0 stream).  N > 1, two plans for the scene (--scene-dist): "bcast" — rank 0 builds + flattens, the
-traversal array + shape AABBs travel to the peers in ONE RCCL broadcast per step (torch.distributed, backend
-nccl == RCCL over xGMI); "replicate" — every rank runs the deterministic build itself, no collective on the
-data path.  The default "auto" times both plans for a few untimed steps and keeps the faster one (at
-120 000 triangles a 0.26 ms build competes with moving 10.6 MB over xGMI); the probe times are reported.
-Every rank traverses its own ray shard; hit lists stay on the GPU that produced them.
+One STEP = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+Bvh::build_par (SAH) → Bvh::flatten → FlatBvh::traverse of R rays, results left in HBM as CSR.
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — the dominant kernel (k_traverse) against the HBM roofline: ALGORITHMIC bytes per
-                 launch (from exact visit counters) / HIP-event kernel time.
-  cpu_baseline — the oracle (a C port of the reference algorithm, kind "port") timed on this box's
-                 host cores on a bounded sample of the same workload; rank 0, N = 1 only.
+Headline workload (`value`): BASELINE.json configs[1] — create_n_cubes(10 000) = 120 000 triangles f32/3D and
+R = 1 000 000 create_ray rays PER GPU (weak scaling: rank r traverses rays [r*R, (r+1)*R) of the seed-0 stream).
+The same JSON line also carries, under "extra_configs", driver-observed figures for the other BASELINE configs:
+  configs[2]  stand-in scene (media/sponza.obj is not in the reference checkout), 10 M coherent primary rays   (N = 1)
+  configs[3]  stand-in scene, 100 M incoherent create_ray rays STRONG-sharded over the N GPUs (N = 1: the 12.5 M-ray
+              shard one GPU of eight owns), the scene built on rank 0 and RCCL-broadcast
+  configs[4]  the configs[1] scene and rays in f64                                                            (N = 1)
+`--workload` / `--dtype` / `--scaling` make any of them the headline of a run instead.
+
+N > 1: one process per GPU.  The one exchange step of the path — rank 0's flattened tree to the peers — is an RCCL
+broadcast issued by the C ABI itself (bvhgpu_bcast_known, csrc/comm.hip: straight out of / into the trees' HBM buffers
+over xGMI); torch.distributed only carries the 128-byte RCCL id, the barrier and the max-over-ranks time.  The
+alternative plan "replicate" (the build is deterministic: every rank runs it, no collective on the data path) is probed
+next to it and the faster one is kept (`--scene-dist`); both probe times are reported.
+
+The JSON line (rank 0) follows the task contract, plus:
+  parity       — in-process diff of the GPU result against the CPU oracle on ALL rays of the headline batch
+  roofline     — the dominant kernel against its BINDING resource (PMC-derived, profiles/*_bound.json) + the builder
+  cpu_baseline — the oracle (C restatement of the reference, kind "port"), rebuilt on this box with -O3 -march=native,
+                 timed on this box's host cores; rank 0, N = 1 only
+  pipelined    — the same steps kept in flight on two streams by ONE host thread through the asynchronous C ABI
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
 import sys
@@ -34,7 +43,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+N_CU, N_SIMD, CLK = 256, 1024, 2.4e9
+VALU_PEAK = N_SIMD * CLK / 2  # wave64 VALU instructions per second: one per 2 cycles per SIMD-32
+LDS_PEAK = N_CU * CLK         # LDS-array cycles per second
 
 
 def parse():
@@ -42,27 +54,315 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--cubes", type=int, default=10_000, help="create_n_cubes(n): 12 triangles each")
-    ap.add_argument("--rays", type=int, default=1_000_000, help="rays per GPU per step")
+    ap.add_argument("--workload", choices=["cubes120k", "standin-primary", "standin-incoherent"], default="cubes120k")
+    ap.add_argument("--cubes", type=int, default=10_000, help="cubes120k: create_n_cubes(n), 12 triangles each")
+    ap.add_argument("--rays", type=int, default=None, help="rays per GPU per step (weak) / in total (strong); default per workload")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--scene-dist", choices=["auto", "bcast", "replicate"], default="auto",
-                    help="N>1: broadcast rank 0's flat scene over RCCL each step, or rebuild it on every rank (the build is "
-                         "deterministic); auto times both during warmup and keeps the faster plan")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="weak: --rays per GPU; strong: --rays in total, sharded over the GPUs (default for standin-incoherent)")
+    ap.add_argument("--scene-dist", choices=["auto", "bcast", "replicate", "bcast-torch"], default="auto",
+                    help="N>1: RCCL-broadcast rank 0's flattened tree through the C ABI each step, or rebuild it on every rank; "
+                         "auto times both before the warmup and keeps the faster plan; bcast-torch = scene blob over torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs sub-runs")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--pipeline-streams", type=int, default=2,
-                    help="N=1 only, reported beside `value` (never as it): the same K steps issued from this many host threads on "
-                         "this many HIP streams, so that the latency-bound build of one step overlaps the traversal of another; 0 = skip")
+                    help="N=1, reported beside `value`: the same K steps kept in flight on this many HIP streams by ONE host "
+                         "thread (bvhgpu_*_async); 0 = skip")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend for N>1 (nccl == RCCL; gloo only for the one-GPU test of this script)")
     ap.add_argument("--one-device", action="store_true",
                     help="test only: every rank uses cuda:0 (needs --backend gloo: RCCL refuses two ranks on one GPU)")
     ap.add_argument("--cpu-sample-rays", type=int, default=1_000_000)
-    ap.add_argument("--pmc-traffic", type=float, default=None,
-                    help="HBM bytes per launch of the traversal kernel from a separate rocprofv3 --pmc pass; default: "
-                         "the newest profiles/*_traffic.json (written by tools/profile_round.sh on this command)")
+    ap.add_argument("--standin-detail", type=int, default=16)
     return ap.parse_args()
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """scene + ray stream of one BASELINE config, resident in HBM; also what the CPU checker needs to redo it"""
+
+    def __init__(self, name, args, dtype_name, rank, n_gpus, dev, ctx, scaling=None, rays=None):
+        import torch
+        from bvh_amd import RayBatch, dist as bdist, scene, testbase as tb
+        from bvh_amd._lib import RAY_F32, RAY_F64
+        from bvh_amd.api import camera
+        self.name, self.dtype_name = name, dtype_name
+        self.np_dtype = np.float32 if dtype_name == "f32" else np.float64
+        self.coherent = False
+        self.cam = None
+        if name == "cubes120k":
+            self.bounds = tb.default_bounds()
+            _, self.aabbs_np = tb.create_n_cubes(args.cubes, self.bounds)
+            self.config_id, per = 1 if dtype_name == "f32" else 4, rays or 1_000_000
+            self.scaling = scaling or "weak"
+            self.label = f"create_n_cubes({args.cubes}) = {len(self.aabbs_np)} random-cube triangles"
+        else:
+            _, self.aabbs_np, self.bounds = scene.parse_obj(scene.make_atrium_obj(args.standin_detail))
+            self.label = (f"procedural atrium STAND-IN for media/sponza.obj (absent from the reference checkout), "
+                          f"{len(self.aabbs_np)} triangles through the OBJ loader")
+            if name == "standin-primary":
+                self.config_id, per, self.coherent = 2, rays or 10_000_000, True
+                self.scaling = scaling or "weak"
+                c = (self.bounds[:3] + self.bounds[3:]) * 0.5   # pinhole at the scene-bounds centre (SURVEY §8d)
+                self.cam = camera(c, c + np.array([1.0, -0.15, 0.25]), fov_y_deg=70.0, aspect=4000 / 2500)
+                self.W, self.H = 4000, 2500
+            else:
+                self.config_id, per = 3, rays or 100_000_000
+                self.scaling = scaling or "strong"
+        self.n_tri = len(self.aabbs_np)
+        if self.scaling == "strong":
+            self.total_rays = per
+            self.first, self.R = bdist.strong_shard(rank, n_gpus, per)
+        else:
+            self.first, self.R = bdist.shard_range(rank, n_gpus, per)
+            self.total_rays = per * n_gpus
+        ray_size = (RAY_F32 if dtype_name == "f32" else RAY_F64).itemsize
+        self.ray_size = ray_size
+        self.aabbs = torch.from_numpy(self.aabbs_np.astype(self.np_dtype)).to(dev)
+        self.rays_buf = torch.empty(max(self.R, 1) * ray_size, dtype=torch.uint8, device=dev)
+        if self.cam is not None:
+            self.rays = RayBatch.primary(self.cam, self.W, self.H, self.first, self.R, self.rays_buf, self.np_dtype, ctx)
+        else:
+            self.rays = RayBatch.generate(self.first, self.R, self.bounds, self.rays_buf, self.np_dtype, ctx)
+
+    def oracle_rays(self, orc, first, n):
+        """the same rays from the oracle's restatement of the generators (f32 stream, widened for f64 like the device does)"""
+        r = orc.primary_rays(self.cam, self.W, self.H, first, n) if self.cam is not None else orc.create_rays(first, n, self.bounds)
+        if self.dtype_name == "f64":
+            r = orc.make_rays(r["o"].astype(np.float64), r["d"].astype(np.float64), np.float64)
+        return r
+
+    def describe(self):
+        kind = "coherent primary rays (4000x2500 pinhole)" if self.coherent else "create_ray rays (seed-0 stream)"
+        return (f"configs[{self.config_id}]: {self.label}, {self.dtype_name}/3D; {self.total_rays} {kind} "
+                f"{'in total, sharded over the GPUs' if self.scaling == 'strong' else 'per GPU'}; "
+                "step = Bvh::build_par + flatten + FlatBvh::traverse (CSR hit lists in HBM)")
+
+
+def newest_bound(kernel_prefix):
+    """profiles/*_bound.json of the newest profile round that holds PMC counters for this kernel"""
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bound.json")), key=os.path.getmtime, reverse=True)
+    for f in found:
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        for k in j.get("kernels", []):
+            if k.get("kernel", "").startswith(kernel_prefix):
+                return k, os.path.relpath(f, ROOT)
+    return None, None
+
+
+def bound_fractions(c, seconds):
+    """PMC counters per launch (profiles/*_bound.json) against the time of one launch → fraction of each resource's peak"""
+    out = {}
+    if c.get("hbm_bytes") is not None:
+        out["hbm"] = c["hbm_bytes"] / seconds / (HBM_PEAK_GBS * 1e9)
+    if c.get("SQ_INSTS_VALU") is not None:
+        out["valu"] = c["SQ_INSTS_VALU"] / seconds / VALU_PEAK
+    if c.get("SQ_INSTS_LDS") is not None:
+        out["lds"] = (c["SQ_INSTS_LDS"] * 4 + c.get("SQ_LDS_BANK_CONFLICT", 0)) / seconds / LDS_PEAK
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def run_workload(wl, args, env, steps, warmup, detailed):
+    """K timed steps of one workload on this rank's GPU (all ranks call it together) → result dict"""
+    import torch
+    import torch.distributed as dist
+    from bvh_amd import Bvh, FlatBvh, dist as bdist
+    rank, n_gpus, dev, ctx, comm = env["rank"], env["n_gpus"], env["dev"], env["ctx"], env["comm"]
+    R, aabbs, rays = wl.R, wl.aabbs, wl.rays
+
+    if n_gpus == 1:
+        plans = ["single"]
+    elif args.scene_dist == "auto":
+        plans = (["bcast"] if comm is not None else ["bcast-torch"]) + ["replicate"]
+    else:
+        plans = ["bcast-torch" if (args.scene_dist == "bcast" and comm is None) else args.scene_dist]
+    own_tree = rank == 0 or "replicate" in plans or n_gpus == 1
+    bvh = Bvh.from_aabbs(aabbs, ctx) if own_tree else None
+    if own_tree:
+        bvh.flatten_in_place()
+    blob, peer = None, None
+    if "bcast-torch" in plans:
+        nbytes = bdist.broadcast_nbytes(bvh.scene_nbytes() if rank == 0 else 0, dev, 0)
+        blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    state = {"plan": plans[0], "peer": None}
+
+    def step():
+        plan = state["plan"]
+        if plan == "bcast":            # Bvh::build_par + flatten on rank 0, ONE group of RCCL broadcasts out of the C ABI
+            if rank == 0:
+                bvh.rebuild(aabbs, flatten=True)
+                comm.bcast(bvh, 0, wl.dtype_name, wl.n_tri)
+                tree = bvh
+            else:
+                state["peer"] = tree = comm.bcast(state["peer"], 0, wl.dtype_name, wl.n_tri)
+        elif plan == "bcast-torch":    # fallback transport: scene blob over torch.distributed
+            if rank == 0:
+                bvh.rebuild(aabbs, flatten=True)
+                bvh.scene_export(blob)
+            bdist.broadcast_scene(blob, 0)
+            if rank != 0:
+                state["peer"] = FlatBvh.scene_import(blob, blob.numel(), ctx, reuse=state["peer"])
+            tree = bvh if rank == 0 else state["peer"]
+        else:
+            bvh.rebuild(aabbs, flatten=True)   # FlatBvh::build (flat_bvh.rs:328-331)
+            tree = bvh
+        return tree.traverse_batch(rays, fetch=False, coherent=wl.coherent)[3]   # FlatBvh::traverse, CSR stays in HBM
+
+    def barrier():
+        if n_gpus > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def timed(k):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if n_gpus > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    probe_ms = {}
+    if len(plans) > 1:          # auto: a short probe of each plan (untimed for the metric), all ranks agree on the max-over-ranks time
+        for pl in plans:
+            state["plan"] = pl
+            step(); step()
+            probe_ms[pl] = timed(5) / 5 * 1e3
+        state["plan"] = min(plans, key=lambda q: probe_ms[q])
+    for _ in range(warmup):
+        step()
+    elapsed = timed(steps)
+    ms_per_step = elapsed * 1e3 / max(steps, 1)
+    value = wl.total_rays / (ms_per_step * 1e-3) / 1e6   # Mrays/s, whole job (weak: N*R, strong: T)
+    plan = state["plan"]
+
+    # ---- per-phase HIP-event times (untimed extra steps) ----
+    ctx.enable_timing(True)
+    builder = plan not in ("bcast", "bcast-torch") or rank == 0
+    tree = bvh if builder else state["peer"]
+    ph = dict(build_ms=[], flatten_ms=[], traverse_kernel_ms=[], traverse_total_ms=[])
+    for _ in range(max(5, min(steps, 20))):
+        if builder:
+            bvh.rebuild(aabbs)
+            bvh.flatten_in_place()
+        tree.traverse_batch(rays, fetch=False, coherent=wl.coherent)
+        t = ctx.last_timings()
+        for k in ph:
+            ph[k].append(t[k])
+    ctx.enable_timing(False)
+    phases = {k: float(np.mean(v)) for k, v in ph.items()}
+    # exact visit counters (reference-equivalent loop iterations, from the binary walk) for the algorithmic byte count
+    stats = tree.traverse_batch(rays, stats=True, fetch=False, coherent=wl.coherent)[3]
+    V, VL, H = stats["visited"], stats["leaf_visits"], stats["hits"]
+    hits_all = H
+    if n_gpus > 1:   # whole-job hit count (untimed): lets a reader check the shards against one process over all rays
+        ht = torch.tensor([H], dtype=torch.int64, device=dev)
+        dist.all_reduce(ht, op=dist.ReduceOp.SUM)
+        hits_all = int(ht.item())
+    out = {
+        "workload": wl.name, "config": wl.config_id, "dtype": wl.dtype_name, "value": round(value, 3), "unit": "Mrays/s",
+        "ms_per_step": round(ms_per_step, 4), "steps": steps, "scaling": wl.scaling, "triangles": wl.n_tri,
+        "rays_this_rank": R, "rays_total": wl.total_rays, "scene_dist": plan,
+        "phases_ms": {k: round(v, 4) for k, v in phases.items()},
+        "hits_all_ranks": int(hits_all), "visited_per_ray": round(V / max(R, 1), 2),
+        "scene_dist_probe_ms_per_step": {k: round(v, 4) for k, v in probe_ms.items()} or None,
+        "describe": wl.describe(),
+    }
+    env["last"] = dict(bvh=bvh, tree=tree, stats=stats, phases=phases, builder=builder)
+    if not detailed:
+        return out
+
+    # ---- roofline of the dominant kernel against its BINDING resource, and of the builder ----
+    elem = 4 if wl.dtype_name == "f32" else 8
+    flat_sz = 36 if wl.dtype_name == "f32" else 64
+    # SURVEY §8d: per ray  Ray in + V*FlatNode + V_leaf*shape AABB + CSR out 4*(H+1)
+    algo_bytes = R * wl.ray_size + V * flat_sz + VL * 6 * elem + 4 * (H + R)
+    kern_s = phases["traverse_kernel_ms"] * 1e-3
+    big = R >= 16384 and not wl.coherent
+    kern_name = "bvhgpu::k_traverse_wide" if big else "bvhgpu::k_traverse<"
+    pmc, src = newest_bound(kern_name)
+    roof = {
+        "kernel": kern_name.rstrip("<"), "kernel_ms": round(phases["traverse_kernel_ms"], 4),
+        "algorithmic_bytes_per_launch": int(algo_bytes),
+        "algorithmic_gbs": round(algo_bytes / kern_s / 1e9, 1),
+        "algorithmic_note": "reference-algorithm bytes (SURVEY §8d) / kernel time; the working set is LDS- and cache-resident, so this "
+                            "exceeds what HBM delivers and is NOT the roofline fraction — `frac` is",
+        "slab_tests_per_s": round(V / kern_s, 1), "visited": int(V), "leaf_visits": int(VL), "hits": int(H),
+    }
+    if pmc is not None:
+        fr = bound_fractions(pmc, kern_s)
+        bound = max(fr, key=fr.get)
+        peak, unit, ach = {"hbm": (HBM_PEAK_GBS, "GB/s", pmc.get("hbm_bytes", 0) / kern_s / 1e9),
+                           "valu": (VALU_PEAK / 1e9, "G wave-instr/s", pmc.get("SQ_INSTS_VALU", 0) / kern_s / 1e9),
+                           "lds": (LDS_PEAK / 1e9, "G LDS-cycles/s", (pmc.get("SQ_INSTS_LDS", 0) * 4 + pmc.get("SQ_LDS_BANK_CONFLICT", 0)) / kern_s / 1e9)}[bound]
+        roof.update({
+            "bound": bound, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": unit, "frac": round(fr[bound], 4),
+            "traffic": pmc.get("hbm_bytes"), "hbm_frac": round(fr.get("hbm", 0), 4), "valu_frac": round(fr.get("valu", 0), 4),
+            "lds_frac": round(fr.get("lds", 0), 4), "wait_frac": pmc.get("wait_frac"), "profile_kernel_us": pmc.get("avg_us"),
+            "source": f"{src}: separate rocprofv3 --pmc passes of this command (per-launch means; FETCH_SIZE doubled per "
+                      "MI355X_MICROARCH.md) over the live HIP-event kernel time; peaks: 8 TB/s HBM, 1024 SIMDs x 2.4 GHz / 2 cycles per "
+                      "wave64 VALU instruction, 256 CUs x 2.4 GHz LDS-array cycles",
+        })
+    else:
+        roof.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                     "source": "no profiles/*_bound.json for this kernel yet (tools/profile_round.sh writes it)"})
+    out["roofline"] = roof
+    if builder:
+        n = wl.n_tri
+        levels = 17.9 if wl.name == "cubes120k" and args.cubes == 10_000 else float(np.log2(max(n, 2)))
+        bbytes = (32 if elem == 4 else 56) * levels * n + (2 * n - 1) * (64 if elem == 4 else 112)   # SURVEY §8d build bytes
+        fbytes = (2 * n - 1) * (64 if elem == 4 else 112) + (3 * n - 2) * flat_sz
+        out["roofline_build"] = {
+            "kernels": "k_prep, (k_bin, k_split) x levels, k_mid, k_small, k_flatten, k_wide", "bound": "hbm",
+            "algorithmic_bytes": int(bbytes + fbytes), "ms": round(phases["build_ms"] + phases["flatten_ms"], 4),
+            "achieved": round((bbytes + fbytes) / ((phases["build_ms"] + phases["flatten_ms"]) * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round((bbytes + fbytes) / ((phases["build_ms"] + phases["flatten_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "note": "a chain of ~20 dependent launches over a cache-resident working set: latency-bound, not bandwidth-bound "
+                    f"(SURVEY §8d: sum over levels of live shapes = {levels:.1f} x N)",
+        }
+        out["build_levels"] = bvh.build_levels
+    return out
+
+
+def check_parity(wl, env, orc, n_check):
+    """GPU CSR (default walk, fetched) and visit counters (binary walk) against the oracle on the first n_check rays of this
+    rank's batch; the oracle run is timed: it is also the traversal leg of cpu_baseline"""
+    from bvh_amd import RayBatch
+    last = env["last"]
+    tree = last["tree"]
+    n = min(n_check, wl.R)
+    a = wl.aabbs_np.astype(wl.np_dtype)
+    rays_o = wl.oracle_rays(orc, wl.first, n)
+    ot = orc.build(a, threads=min(16, orc.max_threads()))
+    oflat = orc.flatten(ot.nodes)
+    t0 = time.perf_counter()
+    ooff, oidx, _, ost = orc.traverse_flat(oflat, a, rays_o, threads=orc.max_threads())
+    t_or = time.perf_counter() - t0
+    sub = RayBatch(n, wl.np_dtype, host=None, device=wl.rays_buf, device_ptr=wl.rays_buf.data_ptr())
+    off, idx, _, _ = tree.traverse_batch(sub, coherent=wl.coherent)
+    st = tree.traverse_batch(sub, stats=True, fetch=False, coherent=wl.coherent)[3]
+    csr_equal = bool(np.array_equal(off, ooff) and np.array_equal(idx, oidx))
+    cnt_equal = bool(st["visited"] == ost["visited"] and st["leaf_visits"] == ost["leaf_visits"] and st["hits"] == ost["hits"])
+    nodes_equal = None
+    if last["builder"] and last["bvh"] is not None:
+        nodes_equal = bool(last["bvh"].nodes.tobytes() == ot.nodes.tobytes())
+    return {"checked_rays": int(n), "equal": bool(csr_equal and cnt_equal and nodes_equal is not False),
+            "csr_offsets_and_indices_equal": csr_equal, "visit_counters_equal": cnt_equal, "bvh_nodes_equal": nodes_equal,
+            "hits": int(ost["hits"]), "against": "oracle (C restatement of bvh_node.rs / flat_bvh.rs, see oracle/bvh_oracle.h)",
+            "oracle_traverse_s": round(t_or, 4)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
     import torch
@@ -90,206 +390,134 @@ def main():
         else:
             dist.init_process_group(backend="gloo")
 
-    import bvh_amd
-    from bvh_amd import Bvh, Context, FlatBvh, RayBatch, dist as bdist, testbase as tb
-    from bvh_amd._lib import RAY_F32, RAY_F64
-
-    dtype = np.float32 if args.dtype == "f32" else np.float64
-    tdtype = torch.float32 if args.dtype == "f32" else torch.float64
-    ray_size = (RAY_F32 if args.dtype == "f32" else RAY_F64).itemsize
-    elem = 4 if args.dtype == "f32" else 8
+    from bvh_amd import Bvh, Context, dist as bdist
+    from bvh_amd.api import _Hits
 
     # the engine enqueues on torch's current stream: torch events / synchronize see all of it
     stream = torch.cuda.current_stream(dev)
     ctx = Context(local_rank, stream=stream.cuda_stream)
+    comm, comm_err = None, None
+    if n_gpus > 1 and args.backend == "nccl" and args.scene_dist in ("auto", "bcast"):
+        try:   # the RCCL communicator of the C ABI; torch.distributed only carries the 128-byte id
+            comm = bdist.Communicator.from_torch_distributed(ctx, dev)
+        except Exception as e:   # keep the run alive on the torch transport, and say so
+            comm_err = repr(e)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            comm = None
+    env = dict(rank=rank, n_gpus=n_gpus, dev=dev, ctx=ctx, comm=comm)
 
-    # ---- synthetic inputs, resident in HBM before the timed region ----
-    bounds = tb.default_bounds()
-    _, aabbs_np = tb.create_n_cubes(args.cubes, bounds)
-    n_tri = len(aabbs_np)
-    aabbs = torch.from_numpy(aabbs_np.astype(dtype)).to(dev)
-    R = args.rays
-    rays_buf = torch.empty(R * ray_size, dtype=torch.uint8, device=dev)
-    first, _ = bdist.shard_range(rank, n_gpus, R)
-    rays = RayBatch.generate(first, R, bounds, rays_buf, dtype, ctx)
+    wl = Workload(args.workload, args, args.dtype, rank, n_gpus, dev, ctx, scaling=args.scaling, rays=args.rays)
     torch.cuda.synchronize(dev)
-
-    # N>1, two plans for getting the scene to every GPU each step:
-    #   bcast      rank 0 builds + flattens, ONE RCCL broadcast of the scene blob, peers import it
-    #   replicate  every rank runs the (deterministic) build itself: no collective on the data path
-    # auto probes both before the warmup and keeps the faster one; the probe times go into the JSON line.
-    plans = ["single"] if n_gpus == 1 else (["bcast", "replicate"] if args.scene_dist == "auto" else [args.scene_dist])
-    own_tree = rank == 0 or "replicate" in plans or n_gpus == 1
-    bvh = Bvh.from_aabbs(aabbs, ctx) if own_tree else None
-    if own_tree:
-        bvh.flatten_in_place()
-    blob = None
-    peer = None
-    if "bcast" in plans:
-        nbytes = bdist.broadcast_nbytes(bvh.scene_nbytes() if rank == 0 else 0, dev, 0)
-        blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    plan = plans[0]
-
-    def step():
-        nonlocal peer
-        if plan == "bcast":
-            if rank == 0:
-                bvh.rebuild(aabbs, flatten=True)   # Bvh::build_par + Bvh::flatten (FlatBvh::build, flat_bvh.rs:328-331)
-                bvh.scene_export(blob)
-            bdist.broadcast_scene(blob, 0)         # RCCL over xGMI: traversal array + shape AABBs
-            if rank != 0:
-                peer = FlatBvh.scene_import(blob, blob.numel(), ctx, reuse=peer)
-            tree = bvh if rank == 0 else peer
-        else:
-            bvh.rebuild(aabbs, flatten=True)
-            tree = bvh
-        return tree.traverse_batch(rays, fetch=False)[3]  # FlatBvh::traverse, CSR stays in HBM
-
-    def barrier():
-        if n_gpus > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    def timed(k):
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(k):
-            step()
-        barrier()
-        dt = time.perf_counter() - t0
-        if n_gpus > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt
-
-    probe_ms = {}
-    if len(plans) > 1:          # auto: a short probe of each plan (untimed for the metric), all ranks agree on the max-over-ranks time
-        for pl in plans:
-            plan = pl
-            step(); step()
-            probe_ms[pl] = timed(5) / 5 * 1e3
-        plan = min(plans, key=lambda q: probe_ms[q])
-    for _ in range(args.warmup):
-        step()
-    elapsed = timed(args.steps)
-    ms_per_step = elapsed * 1e3 / max(args.steps, 1)
-    value = (n_gpus * R) / (ms_per_step * 1e-3) / 1e6  # Mrays/s, whole job
-
-    # ---- per-phase HIP-event times + roofline of the dominant kernel (untimed extra steps) ----
-    ctx.enable_timing(True)
-    builder = plan != "bcast" or rank == 0
-    tree = bvh if builder else peer
-    ph = dict(build_ms=[], flatten_ms=[], traverse_kernel_ms=[], traverse_total_ms=[])
-    for _ in range(max(5, min(args.steps, 20))):
-        if builder:
-            bvh.rebuild(aabbs)
-            bvh.flatten_in_place()
-        tree.traverse_batch(rays, fetch=False)
-        t = ctx.last_timings()
-        for k in ph:
-            ph[k].append(t[k])
-    ctx.enable_timing(False)
-    phases = {k: float(np.mean(v)) for k, v in ph.items()}
-    # exact visit counters (reference-equivalent loop iterations) for the algorithmic byte count
-    stats = tree.traverse_batch(rays, stats=True, fetch=False)[3]
-    V, VL, H = stats["visited"], stats["leaf_visits"], stats["hits"]
-    hits_all = H
-    if n_gpus > 1:   # whole-job hit count (untimed): lets a reader check the shards against one process over N*R rays
-        ht = torch.tensor([H], dtype=torch.int64, device=dev)
-        dist.all_reduce(ht, op=dist.ReduceOp.SUM)
-        hits_all = int(ht.item())
-    flat_sz = 36 if args.dtype == "f32" else 64
-    # per ray  Ray in + V_nav*FlatNode + V_leaf*shape AABB + CSR out 4*(H+1)
-    algo_bytes = R * ray_size + (V - VL) * flat_sz + VL * flat_sz + VL * 6 * elem + 4 * (H + R)
-    kern_s = phases["traverse_kernel_ms"] * 1e-3
-    achieved = algo_bytes / kern_s / 1e9
-    traffic, traffic_src = args.pmc_traffic, "--pmc-traffic"
-    if traffic is None and args.cubes == 10_000 and R == 1_000_000 and args.dtype == "f32":
-        import glob
-        found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), key=os.path.getmtime)
-        if found:
-            tj = json.load(open(found[-1]))
-            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), os.path.relpath(found[-1], ROOT)
-    roofline = {
-        "kernel": "k_traverse_lds", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "traffic_source": None if traffic is None else f"{traffic_src}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                          "of this command, bytes per launch, FETCH_SIZE doubled per MI355X_MICROARCH.md",
-        "algorithmic_bytes_per_launch": int(algo_bytes), "kernel_ms": round(phases["traverse_kernel_ms"], 4),
-        "slab_tests_per_s": round(V / kern_s, 1), "visited": int(V), "leaf_visits": int(VL), "hits": int(H),
-        "device_steps": int(stats["device_steps"]),
-    }
+    res = run_workload(wl, args, env, args.steps, args.warmup, detailed=True)
+    main_env = dict(env["last"])
 
     out = {
-        "metric": "Mrays/s (build+traverse)", "value": round(value, 3), "unit": "Mrays/s", "n_gpus": n_gpus,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "metric": "Mrays/s (build+traverse)", "value": res["value"], "unit": "Mrays/s", "n_gpus": n_gpus,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {
-            "workload": f"configs[1]: create_n_cubes({args.cubes}) = {n_tri} random-cube triangles {args.dtype}/3D, "
-                        f"{R} create_ray rays per GPU; step = Bvh::build_par + flatten + FlatBvh::traverse (CSR hit lists in HBM)",
-            "triangles": n_tri, "rays_per_gpu": R, "scene_dist": plan,
-            "parallelism": f"rays sharded x{n_gpus}" + {"single": "", "bcast": ", flat scene RCCL-broadcast from rank 0 every step",
-                                                        "replicate": ", every rank rebuilds the scene (deterministic build, no data-path collective)"}[plan],
+            "workload": wl.describe(), "triangles": wl.n_tri, "rays_per_gpu": wl.R, "rays_total": wl.total_rays,
+            "scene_dist": res["scene_dist"],
+            "parallelism": f"rays sharded x{n_gpus}" + {
+                "single": "", "bcast": ", flattened tree RCCL-broadcast from rank 0 every step by the C ABI (bvhgpu_bcast_known)",
+                "bcast-torch": ", scene blob broadcast from rank 0 every step over torch.distributed",
+                "replicate": ", every rank rebuilds the scene (deterministic build, no data-path collective)"}[res["scene_dist"]],
         },
-        "phases_ms": {k: round(v, 4) for k, v in phases.items()},
-        "build_levels": bvh.build_levels if builder else None,
-        "hits_all_ranks": int(hits_all),
-        "scene_dist_probe_ms_per_step": {k: round(v, 4) for k, v in probe_ms.items()} or None,
-        "roofline": roofline,
+        "phases_ms": res["phases_ms"], "build_levels": res.get("build_levels"), "hits_all_ranks": res["hits_all_ranks"],
+        "scene_dist_probe_ms_per_step": res["scene_dist_probe_ms_per_step"],
+        "roofline": res["roofline"], "roofline_build": res.get("roofline_build"),
     }
+    if comm_err:
+        out["rccl_comm_error"] = comm_err
 
-    # ---- supplementary: independent steps in flight on several HIP streams (N = 1) ----
-    # `value` above is the time of K steps issued one after the other on ONE stream.  Steps are independent of each other
-    # (each rebuilds the scene from the shape AABBs), and the builder's ~20 small dependent kernels leave most CUs idle, so
-    # a renderer would keep the next frame's build in flight while the current frame traces.  Same K steps, same work:
-    # S host threads, each with its own context / stream / tree / hit buffers, K/S steps each.
+    # ---- parity: the GPU result of the headline batch against the CPU oracle, in-process ----
+    parity_run = None
+    if not args.no_parity and rank == 0:
+        from oracle import orc
+        parity_run = check_parity(wl, env, orc, wl.R if wl.R <= 2_000_000 else 1_000_000)
+        out["parity"] = parity_run
+
+    # ---- supplementary: independent steps kept in flight on several HIP streams by ONE host thread (N = 1) ----
+    # `value` above is the time of K steps issued one after the other, each waited for.  Steps are independent (each rebuilds the
+    # scene from the shape AABBs) and the builder's ~20 small dependent kernels leave most CUs idle, so a frame loop keeps the
+    # next frame's build in flight while the current frame traces: bvhgpu_rebuild_flat_async + bvhgpu_traverse_async on S
+    # contexts (S streams), bvhgpu_hits_wait only when a lane's result object is needed again.
     if n_gpus == 1 and args.pipeline_streams > 1:
-        import threading
         S = args.pipeline_streams
         lanes = []
         for j in range(S):
             c = Context(local_rank)                       # its own non-blocking HIP stream
-            tr = Bvh.from_aabbs(aabbs, c)
+            tr = Bvh.from_aabbs(wl.aabbs, c)
             tr.flatten_in_place()
-            lanes.append((c, tr))
-
-        def lane_steps(tr, k):
-            for _ in range(k):
-                tr.rebuild(aabbs, flatten=True)
-                tr.traverse_batch(rays, fetch=False)
-
-        per = max(args.steps // S, 1)
-        for c, tr in lanes:
-            lane_steps(tr, 3)
+            lanes.append([c, tr, _Hits(c), False])
+        for k in range(3 * S):
+            ln = lanes[k % S]
+            ln[1].rebuild_async(wl.aabbs); ln[1].traverse_async(wl.rays, ln[2]); ln[2].wait()
         torch.cuda.synchronize(dev)
-        threads = [threading.Thread(target=lane_steps, args=(tr, per)) for _, tr in lanes]
+        K = args.steps
+        hits_p = []
         t0 = time.perf_counter()
-        for th in threads:
-            th.start()
-        for th in threads:
-            th.join()
+        for k in range(K):
+            ln = lanes[k % S]
+            if ln[3]:
+                hits_p.append(ln[2].wait()["hits"])
+            ln[1].rebuild_async(wl.aabbs)
+            ln[1].traverse_async(wl.rays, ln[2])
+            ln[3] = True
+        for ln in lanes:
+            if ln[3]:
+                hits_p.append(ln[2].wait()["hits"])
         torch.cuda.synchronize(dev)
         dtp = time.perf_counter() - t0
-        hits_p = [tr.traverse_batch(rays, stats=True, fetch=False)[3]["hits"] for _, tr in lanes]
         out["pipelined"] = {
-            "streams": S, "steps": per * S, "value": round(per * S * R / dtp / 1e6, 3), "unit": "Mrays/s",
-            "ms_per_step": round(dtp * 1e3 / (per * S), 4), "hits_per_lane": hits_p,
-            "note": f"the same steps issued from {S} host threads on {S} HIP streams (own context, tree and hit buffers each): "
-                    "the build of one step overlaps the traversal of another; throughput of independent steps, not the latency of one",
+            "streams": S, "host_threads": 1, "steps": K, "value": round(K * wl.R / dtp / 1e6, 3), "unit": "Mrays/s",
+            "ms_per_step": round(dtp * 1e3 / K, 4), "hits_every_step_equal": bool(len(set(hits_p)) == 1 and len(hits_p) == K),
+            "hits": hits_p[0] if hits_p else None,
+            "note": f"the same {K} steps issued by ONE host thread on {S} HIP streams through the asynchronous C ABI "
+                    "(bvhgpu_rebuild_flat_async / bvhgpu_traverse_async / bvhgpu_hits_wait): the build of one step overlaps the traversal "
+                    "of another; throughput of independent steps, not the latency of one — never reported as `value`",
         }
-        for c, tr in lanes:
-            tr.close()
-            c.close()
+        for c, tr, h, _ in lanes:
+            h.close(); tr.close(); c.close()
+
+    # ---- the other BASELINE configs, driver-observed in the same line ----
+    if not args.no_extra and args.workload == "cubes120k" and args.dtype == "f32":
+        extras = []
+        if n_gpus == 1:
+            plan = [("standin-primary", "f32", None, None), ("standin-incoherent", "f32", "weak", 12_500_000), ("cubes120k", "f64", None, None)]
+        else:
+            plan = [("standin-incoherent", "f32", "strong", 100_000_000)]
+        for name, dt, scaling, nrays in plan:
+            try:
+                w2 = Workload(name, args, dt, rank, n_gpus, dev, ctx, scaling=scaling, rays=nrays)
+                if name == "standin-incoherent" and n_gpus == 1:   # the shard rank 5 of 8 owns (tests/test_gpu_scene.py checks the same one)
+                    from bvh_amd import RayBatch
+                    w2.first = 62_500_000
+                    w2.rays = RayBatch.generate(w2.first, w2.R, w2.bounds, w2.rays_buf, w2.np_dtype, ctx)
+                r2 = run_workload(w2, args, env, args.extra_steps, 3, detailed=False)
+                if name == "standin-incoherent" and n_gpus == 1:
+                    r2["note"] = "one GPU's share of configs[3]: rays [62.5 M, 75 M) of the 100 M-ray stream (rank 5 of 8)"
+                if rank == 0 and not args.no_parity:
+                    from oracle import orc
+                    r2["parity"] = check_parity(w2, env, orc, 200_000)
+                extras.append(r2)
+                del w2
+                torch.cuda.empty_cache()
+            except Exception as e:   # an extra config must never take the headline line down
+                extras.append({"workload": name, "dtype": dt, "error": repr(e)})
+        out["extra_configs"] = extras
 
     # ---- CPU baseline: the oracle (C port of the reference algorithm) on this box's host cores ----
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         from oracle import orc
+        native = orc.use_native()                        # -O3 -march=native, built on THIS box
         cores = orc.max_threads()
-        a = aabbs_np.astype(dtype)
+        a = wl.aabbs_np.astype(wl.np_dtype)
         orc.build(a)                                    # warm the allocator and the page cache
         tb_par, par_threads = 1e9, 0
-        for th in sorted({4, 8, 16, 32, cores} & set(range(1, cores + 1))):   # libgomp's task queue stops scaling early
+        for th in sorted({4, 8, 16, 32, 64, cores} & set(range(1, cores + 1))):   # libgomp's task queue stops scaling early
             t0 = time.perf_counter(); ot = orc.build(a, threads=th); dt = time.perf_counter() - t0
             if dt < tb_par:
                 tb_par, par_threads = dt, th
@@ -297,49 +525,41 @@ def main():
         for _ in range(2):
             t0 = time.perf_counter(); ot = orc.build(a, parallel=False); tb_ser = min(tb_ser, time.perf_counter() - t0)
         t0 = time.perf_counter(); of = orc.flatten(ot.nodes); tf = time.perf_counter() - t0
-        ns = min(args.cpu_sample_rays, R)
-        rr = orc.create_rays(0, ns)
-        if args.dtype == "f64":
-            rr = orc.make_rays(rr["o"], rr["d"], np.float64)
-        st_o = orc.TravStats()
-        import ctypes as C
-        offs = np.zeros(ns + 1, dtype=np.uint32)
-        fn = getattr(orc.lib(), f"orc_traverse_flat_{args.dtype}")
-        sa = np.ascontiguousarray(a)
-
-        def trav(threads):
-            t0 = time.perf_counter()
-            fn(orc._p(of), C.c_size_t(len(of)), orc._p(sa), orc._p(rr), C.c_size_t(ns), orc._p(offs), None,
-               C.c_uint64(0), None, C.byref(st_o), C.c_int(threads))
-            return time.perf_counter() - t0
-        trav(cores)                                     # first call creates the OpenMP team
+        ns = min(args.cpu_sample_rays, wl.R)
+        rr = wl.oracle_rays(orc, wl.first, ns)
         tt_all, trav_threads = 1e9, cores               # the box may grant fewer CPUs than it shows: keep the best team size
-        for th in sorted({8, 16, 32, 64, cores} & set(range(1, cores + 1))):
-            dt = min(trav(th), trav(th))
-            if dt < tt_all:
-                tt_all, trav_threads = dt, th
+        for th in sorted({8, 16, 32, 64, 128, cores} & set(range(1, cores + 1))):
+            for _ in range(2):
+                t0 = time.perf_counter()
+                orc.traverse_flat(of, a, rr, threads=th)        # count pass + fill pass: offsets AND indices, like Vec<&Shape> per ray
+                dt = time.perf_counter() - t0
+                if dt < tt_all:
+                    tt_all, trav_threads = dt, th
         n1 = max(ns // 16, 1000)
         t0 = time.perf_counter()
-        fn(orc._p(of), C.c_size_t(len(of)), orc._p(sa), orc._p(rr), C.c_size_t(n1), orc._p(offs), None,
-           C.c_uint64(0), None, C.byref(st_o), C.c_int(1))
+        orc.traverse_flat(of, a, rr[:n1], threads=1)
         tt_1 = time.perf_counter() - t0
         tbuild = min(tb_par, tb_ser)
-        cpu_total = tbuild + tf + tt_all * (R / ns)
+        cpu_total = tbuild + tf + tt_all * (wl.R / ns)
         out["cpu_baseline"] = {
-            "value": round(R / cpu_total / 1e6, 4), "unit": "Mrays/s", "cores": max(trav_threads, par_threads), "host_cpus_visible": cores, "kind": "port",
-            "sample": f"oracle (C restatement, gcc -O2 -ffp-contract=off, OpenMP): full {n_tri}-triangle build "
-                      f"(best of task-parallel {tb_par * 1e3:.1f} ms on {par_threads} threads / serial {tb_ser * 1e3:.1f} ms) + serial flatten "
-                      f"{tf * 1e3:.1f} ms + traversal of {ns} of the {R} rays on {trav_threads} threads (best of 8/16/32/64/{cores}: {tt_all * 1e3:.1f} ms, count pass only), "
-                      f"scaled to {R} rays; single-thread traversal {tt_1 / n1 * 1e9:.0f} ns/ray "
-                      f"(README.md:175 quotes 866 ns/ray on a Ryzen 9 3900X for the Rust crate)",
+            "value": round(wl.R / cpu_total / 1e6, 4), "unit": "Mrays/s", "cores": max(trav_threads, par_threads), "host_cpus_visible": cores,
+            "kind": "port",
+            "sample": f"oracle = C restatement of the reference, NOT the Rust crate (no cargo here); gcc "
+                      f"{'-O3 -march=native' if native else '-O2 (native rebuild failed)'} -ffp-contract=off, OpenMP; full {wl.n_tri}-triangle build "
+                      f"(best of task-parallel {tb_par * 1e3:.1f} ms on {par_threads} threads with rayon_executor's cut-off bvh_impl.rs:534 / serial "
+                      f"{tb_ser * 1e3:.1f} ms) + serial flatten {tf * 1e3:.1f} ms + traversal of {ns} of the {wl.R} rays, count AND fill pass, "
+                      f"rays-parallel on {trav_threads} threads (best team size: {tt_all * 1e3:.1f} ms), scaled to {wl.R} rays; single-thread "
+                      f"traversal {tt_1 / n1 * 1e9:.0f} ns/ray (README.md:175 quotes 866 ns/ray for the Rust crate on a Ryzen 9 3900X)",
             "build_ms": round(tbuild * 1e3, 2), "flatten_ms": round(tf * 1e3, 2),
-            "traverse_ms_all_cores": round(tt_all * (R / ns) * 1e3, 2),
-            "traverse_ns_per_ray_1thread": round(tt_1 / n1 * 1e9, 1),
+            "traverse_ms_all_cores": round(tt_all * (wl.R / ns) * 1e3, 2),
+            "traverse_ns_per_ray_1thread": round(tt_1 / n1 * 1e9, 1), "native_build": bool(native),
         }
-        out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 2)
+        out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 2)
 
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if n_gpus > 1:
         dist.destroy_process_group()
 

@@ -151,6 +151,7 @@ template <typename T> void refit_tree(bvhgpu_tree* t, const T* aabbs_dev) {
                        t->node_start.as<uint32_t>(), t->node_count.as<uint32_t>(), seg, n_pad, nn);
     BVH_HIP(hipGetLastError());
     if (t->ctx->timing) { BVH_HIP(hipEventRecord(t->ctx->ev[1], st)); t->ctx->ev_set |= 1u; }
+    t->exact_only = false;   // every child box is now the exact join of what is below it (also where the build left empty bounds)
     if (t->flattened) flatten_tree<T>(t);   // the flat / traversal arrays carry the boxes too
 }
 

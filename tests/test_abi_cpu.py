@@ -149,6 +149,11 @@ def test_shard_ranges():
     assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(7))
     with pytest.raises(ValueError):
         bdist.shard_range(8, 8, R)
+    # strong scaling (configs[3]: 100 M rays over 8 GPUs): the shards tile the stream exactly for any total / world
+    for total, world in ((100_000_000, 8), (1_000_003, 7), (5, 8), (0, 3)):
+        shards = [bdist.strong_shard(r, world, total) for r in range(world)]
+        assert shards[0][0] == 0 and sum(c for _, c in shards) == total
+        assert all(shards[r][0] + shards[r][1] == shards[r + 1][0] for r in range(world - 1))
 
 
 _GLOO_WORKER = r'''

@@ -1,7 +1,9 @@
 """The N>1 path of bench.py on the one GPU a test box has: two ranks share cuda:0 and talk over gloo (RCCL
-refuses two ranks on one device), so everything but the RCCL transport itself runs exactly as it does on an
-8-GPU node — rank 0 builds + flattens + bvhgpu_scene_export, ONE broadcast, the peer bvhgpu_scene_imports and
-traverses its own shard of the seed-0 ray stream."""
+refuses two ranks on one device), so the sharding, the plan probe, the timing protocol and the import of a received
+scene run as they do on an 8-GPU node; the transport is the torch.distributed fallback (scene blob: rank 0 builds +
+flattens + bvhgpu_scene_export, ONE broadcast, the peer bvhgpu_scene_imports).  The RCCL transport of the C ABI
+(bvhgpu_comm_* / bvhgpu_bcast*) is exercised with the one rank this box allows in test_rccl_comm_single_rank and from
+plain C (tests/c_abi/abi_roundtrip.c)."""
 import json
 import os
 import socket
@@ -21,36 +23,68 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("scene_dist", ["bcast", "replicate", "auto"])
+def test_rccl_comm_single_rank():
+    """bvhgpu_comm_unique_id / comm_init_rank / bcast / bcast_known with nranks = 1 through the Python mirror: RCCL itself
+    runs (ncclCommInitRank, ncclBroadcast on the ctx's stream), the tree survives, a wrong announcement is refused."""
+    import bvh_amd
+    from bvh_amd import Bvh, Context, RayBatch, dist as bdist, testbase as tb
+    from bvh_amd._lib import BvhGpuError
+    from oracle import orc
+    if bvh_amd.device_count() <= 0:
+        pytest.fail("GPU test selected but no HIP device is visible (no CPU fallback exists)")
+    ctx = Context(0)
+    comm = bdist.Communicator(ctx, 1, 0, bdist.Communicator.unique_id())
+    _, aabbs = tb.create_n_cubes(300)
+    bvh = Bvh.from_aabbs(aabbs, ctx)
+    with pytest.raises(BvhGpuError):
+        comm.bcast(bvh, 0)                                   # not flattened yet
+    bvh.flatten_in_place()
+    assert comm.bcast(bvh, 0) is bvh
+    assert comm.bcast(bvh, 0, "f32", len(aabbs)) is bvh
+    with pytest.raises(BvhGpuError):
+        comm.bcast(bvh, 0, "f32", len(aabbs) + 1)            # the root's tree is not what the call announces
+    rays = orc.create_rays(0, 20_000)
+    off, idx, _, _ = bvh.traverse_batch(RayBatch(len(rays), np.float32, host=rays))
+    ooff, oidx, _, _ = orc.traverse_flat(orc.flatten(orc.build(aabbs).nodes), aabbs, rays)
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+    comm.close()
+
+
+@pytest.mark.parametrize("scene_dist", ["bcast", "replicate", "auto", "strong"])
 def test_bench_two_ranks_one_gpu(scene_dist):
     import bvh_amd
     if bvh_amd.device_count() <= 0:
         pytest.fail("GPU test selected but no HIP device is visible (no CPU fallback exists)")
     cubes, R = 2000, 60_000
+    strong = scene_dist == "strong"
+    if strong:
+        scene_dist = "replicate"
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "3", "--warmup", "1", "--cubes", str(cubes), "--rays", str(R),
-           "--backend", "gloo", "--one-device", "--scene-dist", scene_dist]
+           "--backend", "gloo", "--one-device", "--scene-dist", scene_dist, "--no-extra"] + (["--scaling", "strong"] if strong else [])
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]               # rank 0 prints ONE line
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
-    assert out["config"]["rays_per_gpu"] == R and out["value"] > 0
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == ("strong" if strong else "weak")
+    assert out["config"]["rays_per_gpu"] == (R // 2 if strong else R) and out["value"] > 0
     assert "roofline" in out and "cpu_baseline" not in out  # the CPU leg is rank 0 at N=1 only
+    assert out["parity"]["equal"] is True                   # rank 0's shard against the oracle, in-process
+    torch_plan = {"bcast": "bcast-torch", "replicate": "replicate"}   # over gloo there is no RCCL: the blob transport stands in
     if scene_dist == "auto":
-        assert out["config"]["scene_dist"] in ("bcast", "replicate")
-        assert set(out["scene_dist_probe_ms_per_step"]) == {"bcast", "replicate"}
+        assert out["config"]["scene_dist"] in ("bcast-torch", "replicate")
+        assert set(out["scene_dist_probe_ms_per_step"]) == {"bcast-torch", "replicate"}
     else:
-        assert out["config"]["scene_dist"] == scene_dist
+        assert out["config"]["scene_dist"] == torch_plan[scene_dist]
 
     # the two shards together == one process over the first 2R rays of the stream (oracle as the checker)
     from bvh_amd import testbase as tb
     from oracle import orc
     _, aabbs = tb.create_n_cubes(cubes)
     flat = orc.flatten(orc.build(aabbs).nodes)
-    off, idx, _, _ = orc.traverse_flat(flat, aabbs, orc.create_rays(0, 2 * R))
+    off, idx, _, _ = orc.traverse_flat(flat, aabbs, orc.create_rays(0, R if strong else 2 * R))
     assert out["hits_all_ranks"] == len(idx)
