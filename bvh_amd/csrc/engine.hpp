@@ -126,7 +126,9 @@ struct bvhgpu_hits {
     bool ctr_clean = false;  // the counters were zeroed behind the previous call's readback
     // wide walk
     bvhgpu::DevBuf wcounts;   // n_rays+1 u32: hit count | item mask << 28, all-zero between batches
-    bvhgpu::DevBuf ray_mask;  // n_rays u8: items of the ray that reported hits (valid for rays with hits)
+    bvhgpu::DevBuf ray_mask;  // n_rays u16: items of the ray that reported hits (valid for rays with hits)
+    bvhgpu::DevBuf ray_items; // n_rays u32: the same set while the walk collects it (atomicOr), all-zero between batches
+    bvhgpu::DevBuf witems;    // live items (ray << 5 | j) of the batch, from k_wide_items
     bvhgpu::DevBuf item_cnt;  // per item: hits (valid where the ray's mask has the item's bit)
     bvhgpu::DevBuf wstack;    // the part of the lanes' stacks that does not fit in LDS
     bool wcounts_clean = false;

@@ -67,7 +67,8 @@ template <typename T> struct WalkOut {
     const T* tris;               // n x 9 vertices (triangle modes)
     T* closest;                  // per ray {distance,u,v} (closest mode)
     uint32_t* closest_prim;      // per ray shape index or NONE
-    uint32_t* item_cnt;          // wide walk with several items per ray: hits of item i, written only when non-zero
+    uint32_t* item_cnt;          // wide walk with several items per ray: hits of item (ray, j), written only when non-zero
+    uint32_t* ray_items;         // ... and per ray the set of j that wrote one (kept all-zero between batches like counts)
 };
 
 // ---- Ray::intersects_triangle (ray_impl.rs:154-213), Möller–Trumbore with back-face culling.  Same
@@ -686,7 +687,17 @@ constexpr int WIDE_INNER_STEPS = BVH_WIDE_INNER_STEPS;   // walk steps between t
 #ifndef BVH_WIDE_MIN_WAVES_F64
 #define BVH_WIDE_MIN_WAVES_F64 4   // f64: two 512-thread workgroups per CU
 #endif
-constexpr uint32_t WIDE_COUNT_BITS = 28;     // per-ray word: hit count | (mask of the items that reported hits) << 28
+// An ITEM is (ray, j): the part of a ray's walk below the j-th of the 4^L subtrees L wide levels under the root (L = 1: the
+// root's grandchildren, L = 2: their grandchildren).  No ancestor test is owed for a finite ray (see above), so items
+// are independent walks and a ray's list is the concatenation of its items' lists in j order.  A workgroup tests each of
+// its rays against the 4^L subtree boxes first and keeps the items whose box is hit in a compact list (62 % / 86 % of
+// the items of the BASELINE stream die there); the walk then only ever draws live items.  Why: at 1 M rays a resident
+// lane gets two rays, and the launch lasts as long as its unluckiest lanes (up to 66 dependent steps per ray); items of
+// a quarter / a sixteenth of that length pack the lanes better (simulated critical path per workgroup 80 → 63 → 54 steps).
+// Rays with a non-finite component are not cut: they travel as one item (j = WIDE_ITEM_WHOLE) from the root.
+constexpr uint32_t WIDE_ITEM_BITS = 5;                 // item = ray << 5 | j
+constexpr uint32_t WIDE_ITEM_WHOLE = 16;               // j of an uncut ray (its hits are filed under j = 0)
+constexpr size_t WIDE_ITEM_MAX_RAYS = (size_t)1 << 27;
 
 template <typename T> struct WideRegs { T mn[3][4], mx[3][4]; uint32_t ref[4]; };
 template <typename T> struct WideIo {
@@ -701,27 +712,31 @@ template <typename T> struct WideIo {
         __builtin_memcpy(&r, c, sizeof r);
         return r;
     }
-    static __device__ __forceinline__ WideRegs<T> from_lds(const uint4* planes, uint32_t K, uint32_t slot) {
+    // LDS copy: node-major, CHUNKS x 16 bytes per slot, so the chunk offsets are immediates of the ds_read_b128s
+    static __device__ __forceinline__ WideRegs<T> from_lds(const uint4* nodes, uint32_t slot) {
+        const uint4* q = nodes + (size_t)slot * CHUNKS;
         uint4 c[CHUNKS];
 #pragma unroll
-        for (int j = 0; j < CHUNKS; j++) c[j] = planes[(uint32_t)j * K + slot];
+        for (int j = 0; j < CHUNKS; j++) c[j] = q[j];
         WideRegs<T> r;
         __builtin_memcpy(&r, c, sizeof r);
         return r;
     }
-    static __device__ __forceinline__ void to_lds(uint4* planes, uint32_t K, uint32_t slot, const WideNode<T>* __restrict__ g) {
-        const uint4* q = reinterpret_cast<const uint4*>(g);
-#pragma unroll
-        for (int j = 0; j < CHUNKS; j++) planes[(uint32_t)j * K + slot] = q[j];
-    }
 };
+
+// reference of the subtree in slot `c` of a node that sits in LDS slot `q`: grandchildren that are resident too are named by
+// their LDS slot (4-ary heap number), so that the walk never has to translate
+__device__ __forceinline__ uint32_t wide_resident_ref(uint32_t ref, uint32_t q, uint32_t c, uint32_t K) {
+    const uint32_t cs = 4u * q + 1u + c;
+    return (ref != NONE && (ref & WIDE_INNER) && cs < K) ? (WIDE_INNER | WIDE_RESIDENT | cs) : ref;
+}
 
 // the four slab tests of one wide node → hit bits.  EXACT: the reference's NaN-aware sequence with the skipped child
 // boxes rebuilt and tested first (see the header above).
 template <typename T, bool EXACT>
 __device__ __forceinline__ uint32_t wide_hits(const T o[3], const T inv[3], const WideRegs<T>& nd) {
     uint32_t m = 0;
-    if (!EXACT) {
+    if (!EXACT) {   // absent slots carry NaN boxes: v_min / v_max3 keep the NaN and both compares fail
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const T mn[3] = {nd.mn[0][c], nd.mn[1][c], nd.mn[2][c]}, mx[3] = {nd.mx[0][c], nd.mx[1][c], nd.mx[2][c]};
@@ -750,40 +765,149 @@ __device__ __forceinline__ uint32_t wide_hits(const T o[3], const T inv[3], cons
     return m;
 }
 
+// The 4^L item subtrees of a tree: box + reference, in pre-order (j = 4 * slot at wide level 1 + slot at wide level 2).  Every
+// workgroup that needs them derives them itself from the root's wide node (and its four children's): two dependent loads.
+template <typename T> struct ItemTable {
+    T box[16][6];
+    uint32_t ref[16];
+};
+template <typename T, int ITEMS_LOG4>
+__device__ __forceinline__ void item_table_build(const WideNode<T>* __restrict__ wide, ItemTable<T>* tb, uint32_t tid) {
+    constexpr uint32_t ITEMS = 1u << (2 * ITEMS_LOG4);
+    if (tid < ITEMS) {
+        const uint32_t c = ITEMS_LOG4 == 2 ? tid >> 2 : tid, k = tid & 3u;
+        const WideNode<T>* root = wide;   // tree node 0
+        uint32_t ref = root->ref[c];
+        T b[6];
+#pragma unroll
+        for (int a = 0; a < 3; a++) { b[a] = root->mn[a][c]; b[3 + a] = root->mx[a][c]; }
+        if (ITEMS_LOG4 == 2) {
+            if (ref != NONE && (ref & WIDE_INNER)) {   // an inner grandchild of the root: its own four grandchildren
+                const WideNode<T>* g = wide + (ref & (WIDE_RESIDENT - 1u));
+                ref = g->ref[k];
+#pragma unroll
+                for (int a = 0; a < 3; a++) { b[a] = g->mn[a][k]; b[3 + a] = g->mx[a][k]; }
+            } else if (k != 0) {                       // a leaf (or nothing): the whole of it is item 4c
+                ref = NONE;
+            }
+        }
+        if (ref == NONE) {
+            const T nan = __builtin_nan("");
+#pragma unroll
+            for (int a = 0; a < 6; a++) b[a] = nan;
+        }
+#pragma unroll
+        for (int a = 0; a < 6; a++) tb->box[tid][a] = b[a];
+        tb->ref[tid] = ref;
+    }
+}
+// LDS slot (4-ary heap number) of item j's subtree root
+template <int ITEMS_LOG4> __device__ __forceinline__ uint32_t item_slot(uint32_t j) {
+    return ITEMS_LOG4 == 2 ? 5u + j : 1u + j;   // level 1: 1 + c; level 2: 4 * (1 + c) + 1 + k = 5 + 4c + k
+}
+
+// ITEMS_LOG4 = 0: one item per ray, drawn by ray number.  1 / 2: every workgroup first cuts ITS rays into live items (its
+// region of `list`, filled through an LDS counter — no global atomic: one address only takes ~88 atomics per µs on this
+// chip, which made a separate filter kernel with one atomic per wave cost more than the walk) and then walks them.
 template <typename T, int MODE, int ITEMS_LOG4, int MAX_THREADS, int MIN_WAVES>
 __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     const WideNode<T>* __restrict__ wide, const uint32_t* __restrict__ wslot_node, uint32_t K, uint32_t stack_lds,
-    const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_items, uint32_t items_per_wg, WalkOut<T> w,
+    const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_rays, uint32_t* __restrict__ list_all, WalkOut<T> w,
     uint32_t* __restrict__ gstack, uint32_t gstack_cap, uint32_t* __restrict__ overflow) {
-    constexpr uint32_t ITEMS = 1u << (2 * ITEMS_LOG4);
-    static_assert(ITEMS_LOG4 == 0 || ITEMS_LOG4 == 1, "1 or 4 items per ray");
+    static_assert(ITEMS_LOG4 >= 0 && ITEMS_LOG4 <= 2, "1, 4 or 16 items per ray");
     static_assert(MODE != MODE_T_SLICE, "the t-slice output walks the binary array");
+    static_assert(MODE != MODE_CLOSEST || ITEMS_LOG4 == 0, "closest hit: one lane owns the ray");
+    constexpr int CH = WideIo<T>::CHUNKS;
+    constexpr int L4 = ITEMS_LOG4 > 0 ? ITEMS_LOG4 : 1;      // (so that the item code compiles when it is not used)
+    constexpr uint32_t ITEMS = 1u << (2 * L4);
     extern __shared__ __attribute__((aligned(16))) uint4 wsmem[];
     uint32_t& s_next = *reinterpret_cast<uint32_t*>(wsmem);
-    uint4* planes = wsmem + 1;
-    uint32_t* s_stack = reinterpret_cast<uint32_t*>(planes + (size_t)WideIo<T>::CHUNKS * K);
+    uint32_t& s_nlist = *(reinterpret_cast<uint32_t*>(wsmem) + 1);
+    uint32_t* s_item_ref = reinterpret_cast<uint32_t*>(wsmem + 1);           // 16 references (64 bytes)
+    uint4* nodes = wsmem + 5;
+    uint32_t* s_stack = reinterpret_cast<uint32_t*>(nodes + (size_t)CH * K);
     const uint32_t bd = blockDim.x, tid = threadIdx.x;
     const size_t G = (size_t)gridDim.x * bd, gid = (size_t)blockIdx.x * bd + tid;
-    const unsigned long long g0 = (unsigned long long)blockIdx.x * items_per_wg;
-    const unsigned long long g1 = g0 + items_per_wg;
-    const uint32_t wg_begin = (uint32_t)(g0 < n_items ? g0 : n_items);
-    const uint32_t wg_end = (uint32_t)(g1 < n_items ? g1 : n_items);
-    if (tid == 0) s_next = wg_begin;
-    for (uint32_t q = tid; q < K; q += bd) {
-        const uint32_t node = wslot_node[q];
-        if (node != NONE) WideIo<T>::to_lds(planes, K, q, wide + node);
-    }
-    __syncthreads();
-
     const int lane = lane_id();
     const unsigned long long lt = lanemask_lt();
+    // this workgroup's rays
+    const unsigned long long per_wg = ((unsigned long long)n_rays + gridDim.x - 1) / gridDim.x;
+    const unsigned long long g0 = (unsigned long long)blockIdx.x * per_wg, g1 = g0 + per_wg;
+    const uint32_t ray_begin = (uint32_t)(g0 < n_rays ? g0 : n_rays);
+    const uint32_t ray_end = (uint32_t)(g1 < n_rays ? g1 : n_rays);
+    if (tid == 0) { s_next = ITEMS_LOG4 == 0 ? ray_begin : 0u; s_nlist = 0u; }
+    for (uint32_t q = tid; q < K; q += bd) {
+        const uint32_t node = wslot_node[q];
+        if (node != NONE) {
+            const uint4* src = reinterpret_cast<const uint4*>(wide + node);
+            uint4* dst = nodes + (size_t)q * CH;
+#pragma unroll
+            for (int c = 0; c < CH - 1; c++) dst[c] = src[c];
+            uint4 rf = src[CH - 1];   // the four references: resident grandchildren by LDS slot
+            rf.x = wide_resident_ref(rf.x, q, 0u, K); rf.y = wide_resident_ref(rf.y, q, 1u, K);
+            rf.z = wide_resident_ref(rf.z, q, 2u, K); rf.w = wide_resident_ref(rf.w, q, 3u, K);
+            dst[CH - 1] = rf;
+        }
+    }
+    uint32_t* list = nullptr;
+    if (ITEMS_LOG4 > 0) {
+        __shared__ ItemTable<T> tb;
+        item_table_build<T, L4>(wide, &tb, tid);
+        __syncthreads();
+        if (tid < ITEMS) {   // references of the item subtrees, resident ones by LDS slot
+            const uint32_t ref = tb.ref[tid], slot = item_slot<L4>(tid);
+            s_item_ref[tid] = (ref != NONE && (ref & WIDE_INNER) && slot < K) ? (WIDE_INNER | WIDE_RESIDENT | slot) : ref;
+        }
+        // rays → live items, into this workgroup's region of the list (at most ITEMS per ray)
+        list = list_all + (size_t)blockIdx.x * per_wg * ITEMS;
+        for (uint32_t r0 = ray_begin; r0 < ray_end; r0 += bd) {   // workgroup-uniform
+            const uint32_t r = r0 + tid;
+            uint32_t mask = 0;
+            if (r < ray_end) {
+                const typename Traits<T>::Ray* rp = rays + r;
+                const T o[3] = {rp->o[0], rp->o[1], rp->o[2]}, inv[3] = {rp->inv[0], rp->inv[1], rp->inv[2]};
+                if (!ray_is_finite<T>(o, inv)) {
+                    mask = 1u << WIDE_ITEM_WHOLE;
+                } else {
+#pragma unroll 4
+                    for (uint32_t j = 0; j < ITEMS; j++) {   // the boxes are workgroup-uniform: LDS broadcast reads
+                        const T mn[3] = {tb.box[j][0], tb.box[j][1], tb.box[j][2]}, mx[3] = {tb.box[j][3], tb.box[j][4], tb.box[j][5]};
+                        mask |= slab_hit_finite<T>(o, inv, mn, mx) ? (1u << j) : 0u;
+                    }
+                }
+            }
+            // wave-level compaction (a ray's items stay together, in j order), one LDS atomic per wave
+            const uint32_t mine = (uint32_t)__popc(mask);
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                const uint32_t u = __shfl_up(incl, d);
+                if (lane >= d) incl += u;
+            }
+            const uint32_t total = __shfl(incl, WAVE - 1);
+            uint32_t base = 0;
+            if (lane == 0 && total) base = atomicAdd(&s_nlist, total);
+            base = __shfl(base, 0) + incl - mine;
+            uint32_t mm = mask;
+            while (mm) {
+                const uint32_t bit = (uint32_t)__ffs(mm) - 1u;
+                mm &= mm - 1u;
+                list[base++] = (r << WIDE_ITEM_BITS) | bit;
+            }
+        }
+        __threadfence_block();
+    }
+    __syncthreads();
+    const uint32_t wg_begin = ITEMS_LOG4 == 0 ? ray_begin : 0u;
+    const uint32_t wg_end = ITEMS_LOG4 == 0 ? ray_end : s_nlist;
+
     LaneRay<T, MODE> ray;
     ray.clear();
-    uint32_t cur = CUR_NONE, sp = 0, item = NONE, stepmask = 15u;
+    uint32_t cur = CUR_NONE, sp = 0, item = NONE;
     bool exhausted = wg_begin >= wg_end;   // wave-uniform: the workgroup's range has been handed out
     bool ovf = false;
     PoolCursor pc;
-    auto push = [&](uint32_t v) {
+    auto push_slow = [&](uint32_t v) {
         if (sp < stack_lds) s_stack[sp * bd + tid] = v;
         else if (sp - stack_lds < gstack_cap) gstack[(size_t)(sp - stack_lds) * G + gid] = v;
         else ovf = true;
@@ -806,11 +930,14 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                     w.closest[3 * r] = ray.best[0]; w.closest[3 * r + 1] = ray.best[1]; w.closest[3 * r + 2] = ray.best[2];
                     w.closest_prim[r] = ray.best_prim;
                 } else if (ray.cnt) {
-                    if (ITEMS == 1) {
-                        w.counts[item] = ray.cnt | (1u << WIDE_COUNT_BITS);
+                    if (ITEMS_LOG4 == 0) {
+                        w.counts[item] = ray.cnt;
                     } else {
-                        atomicAdd(&w.counts[item >> (2 * ITEMS_LOG4)], ray.cnt | (1u << (WIDE_COUNT_BITS + (item & (ITEMS - 1u)))));
-                        w.item_cnt[item] = ray.cnt;
+                        const uint32_t r = item >> WIDE_ITEM_BITS, j = item & ((1u << WIDE_ITEM_BITS) - 1u);
+                        const uint32_t jj = j == WIDE_ITEM_WHOLE ? 0u : j;
+                        atomicAdd(&w.counts[r], ray.cnt);
+                        atomicOr(&w.ray_items[r], 1u << jj);
+                        w.item_cnt[((size_t)r << (2 * ITEMS_LOG4)) + jj] = ray.cnt;
                     }
                 }
                 item = NONE;
@@ -822,12 +949,19 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                 base = __builtin_amdgcn_readfirstlane(base);
                 const uint32_t mine = base + (uint32_t)__popcll(idle & lt);
                 if (!run && base < wg_end && mine < wg_end) {
-                    ray.load(rays, mine >> (2 * ITEMS_LOG4));
-                    ray.r = mine;                          // pool records are per item
-                    item = mine;
-                    cur = WIDE_INNER | WIDE_RESIDENT | 0u;   // the root is heap slot 0 (K >= 1)
+                    if (ITEMS_LOG4 == 0) {
+                        item = mine;
+                        ray.load(rays, mine);
+                        cur = WIDE_INNER | WIDE_RESIDENT | 0u;   // the root is heap slot 0 (K >= 1)
+                    } else {
+                        item = list[mine];
+                        const uint32_t j = item & ((1u << WIDE_ITEM_BITS) - 1u);
+                        ray.load(rays, item >> WIDE_ITEM_BITS);
+                        cur = j == WIDE_ITEM_WHOLE ? (WIDE_INNER | WIDE_RESIDENT | 0u) : s_item_ref[j];
+                        if (j == WIDE_ITEM_WHOLE) item = item & ~((1u << WIDE_ITEM_BITS) - 1u);   // filed under j = 0
+                    }
+                    ray.r = item;                                // pool records are per item
                     sp = 0;
-                    stepmask = ITEMS == 1 ? 15u : (1u << (mine & (ITEMS - 1u)));
                     run = true;
                 }
                 exhausted = base >= wg_end || (wg_end - base) <= nidle;
@@ -837,28 +971,26 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
         const bool fast = !__any(run && !ray.fin);   // wave-uniform
         for (int s = 0; s < WIDE_INNER_STEPS; s++) {
             if (cur & WIDE_INNER) {   // (CUR_NONE and shape indices have bit 31 clear)
-                const bool res = (cur & WIDE_RESIDENT) != 0u;
                 const uint32_t id = cur & (WIDE_RESIDENT - 1u);
                 WideRegs<T> nd;
-                if (res) nd = WideIo<T>::from_lds(planes, K, id);
+                if (cur & WIDE_RESIDENT) nd = WideIo<T>::from_lds(nodes, id);
                 else nd = WideIo<T>::from_global(wide + id);
-                uint32_t m = fast ? wide_hits<T, false>(ray.o, ray.inv, nd) : wide_hits<T, true>(ray.o, ray.inv, nd);
-                // slots 1 and 3 may be absent (their NaN boxes fail the test anyway; the mask keeps a stray bit from
-                // ever turning NONE into a node reference); an item's first step enables its own slot only
-                m &= stepmask & (5u | (nd.ref[1] != NONE ? 2u : 0u) | (nd.ref[3] != NONE ? 8u : 0u));
-                stepmask = 15u;
-                const uint32_t cbase = res ? 4u * id + 1u : 0xFFFFFFF0u;   // heap slots of the four grandchildren
-                uint32_t enc[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-                    enc[c] = ((nd.ref[c] & WIDE_INNER) && cbase + (uint32_t)c < K) ? (WIDE_INNER | WIDE_RESIDENT | (cbase + (uint32_t)c))
-                                                                                   : nd.ref[c];
+                const uint32_t m = fast ? wide_hits<T, false>(ray.o, ray.inv, nd) : wide_hits<T, true>(ray.o, ray.inv, nd);
+                // the lowest hit slot is visited now, the others wait on the stack, highest slot first
                 const uint32_t first = m & (0u - m);
                 const uint32_t rest = m ^ first;
-                if (rest & 8u) push(enc[3]);
-                if (rest & 4u) push(enc[2]);
-                if (rest & 2u) push(enc[1]);
-                cur = first == 0u ? pop_or_none() : (first == 1u ? enc[0] : (first == 2u ? enc[1] : (first == 4u ? enc[2] : enc[3])));
+                const uint32_t s0 = (rest & 8u) ? nd.ref[3] : ((rest & 4u) ? nd.ref[2] : nd.ref[1]);
+                const uint32_t s1 = ((rest & 12u) == 12u) ? nd.ref[2] : nd.ref[1];
+                if (sp + 3u <= stack_lds) {   // room for three: store them all, count what is real
+                    uint32_t* at = s_stack + sp * bd + tid;
+                    at[0] = s0; at[bd] = s1; at[2 * bd] = nd.ref[1];
+                    sp += (uint32_t)__popc(rest);
+                } else {
+                    if (rest & 8u) push_slow(nd.ref[3]);
+                    if (rest & 4u) push_slow(nd.ref[2]);
+                    if (rest & 2u) push_slow(nd.ref[1]);
+                }
+                cur = first == 0u ? pop_or_none() : (first == 1u ? nd.ref[0] : (first == 2u ? nd.ref[1] : (first == 4u ? nd.ref[2] : nd.ref[3])));
             }
             const bool rec = cur < CUR_NONE;   // a leaf: report it, take the next pending grandchild
             const uint32_t shape = cur;
@@ -876,13 +1008,13 @@ constexpr int SCAN_ITEMS = 4;
 constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;
 
 // KIND 1 (pair): every ray was walked as two items (k_traverse_lds split): its count is counts[2r] + counts[2r+1].
-// KIND 2 (wide walk): counts[r] = hit count | item mask << 28, non-zero only for rays with hits; k_scan_final moves the
-// mask to ray_mask[r] and puts the zero back, so the array is all zero again for the next batch (the walk then stores
-// nothing for the rays — most of them on a sparse scene — that hit nothing).
+// KIND 2 (wide walk): counts[r] is non-zero only for rays with hits and ray_items[r] holds the set of the ray's items that
+// reported some; k_scan_final copies that set to ray_mask[r] (for the scatter) and puts the zeros back, so both arrays are
+// all zero again for the next batch (the walk then stores nothing for the rays — most of them on a sparse scene — that
+// hit nothing).
 constexpr int COUNT_PLAIN = 0, COUNT_PAIR = 1, COUNT_MASKED = 2;
 template <int KIND> __device__ __forceinline__ uint32_t ray_count(const uint32_t* __restrict__ counts, uint32_t r) {
-    if (KIND == COUNT_PLAIN) return counts[r];
-    if (KIND == COUNT_MASKED) return counts[r] & ((1u << WIDE_COUNT_BITS) - 1u);
+    if (KIND == COUNT_PLAIN || KIND == COUNT_MASKED) return counts[r];
     const uint2 c = reinterpret_cast<const uint2*>(counts)[r];
     return c.x + c.y;
 }
@@ -932,7 +1064,8 @@ template <int KIND, bool PREFIXED>
 __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__ counts, uint32_t n,
                                                     const unsigned long long* __restrict__ blocksums,
                                                     unsigned long long* __restrict__ total,
-                                                    uint32_t* __restrict__ offsets, uint8_t* __restrict__ ray_mask) {
+                                                    uint32_t* __restrict__ offsets, uint32_t* __restrict__ ray_items,
+                                                    uint16_t* __restrict__ ray_mask) {
     __shared__ uint32_t ws[4];
     __shared__ unsigned long long wb[4];
     const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
@@ -955,7 +1088,7 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__
 #pragma unroll
         for (int j = 0; j < SCAN_ITEMS; j++) {
             if (v[j]) {
-                ray_mask[base + j] = (uint8_t)(counts[base + j] >> WIDE_COUNT_BITS);
+                if (ray_items) { ray_mask[base + j] = (uint16_t)ray_items[base + j]; ray_items[base + j] = 0u; }
                 const_cast<uint32_t*>(counts)[base + j] = 0u;
             }
         }
@@ -1007,27 +1140,31 @@ __global__ __launch_bounds__(256) void k_hits_scatter(const HitRec* __restrict__
     }
 }
 
-// wide walk: a record's `ray` is an item (ray << 2*ITEMS_LOG4 | j); the records of item j follow those of the ray's earlier
-// items that reported hits (ray_mask) — item_cnt is only valid for those
+// wide walk: a record's `ray` is an item (ray << 5 | j, or the ray itself with one item per ray); the records of item j follow
+// those of the ray's earlier items that reported hits (ray_mask) — item_cnt is only valid for those
 template <typename T, int NV, int ITEMS_LOG4>
 __global__ __launch_bounds__(256) void k_hits_scatter_wide(const HitRec* __restrict__ pool, const T* __restrict__ pool_v,
                                                            const unsigned long long* __restrict__ ctr,
                                                            unsigned long long pool_cap, const uint32_t* __restrict__ offsets,
-                                                           const uint32_t* __restrict__ item_cnt, const uint8_t* __restrict__ ray_mask,
+                                                           const uint32_t* __restrict__ item_cnt, const uint16_t* __restrict__ ray_mask,
                                                            uint32_t* __restrict__ indices, T* __restrict__ vals) {
-    constexpr uint32_t ITEMS = 1u << (2 * ITEMS_LOG4);
     const unsigned long long n = ctr[0];
     if (n > pool_cap) return;  // pool overflowed: the host grows it and replays
     for (unsigned long long j = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; j < n;
          j += (unsigned long long)gridDim.x * blockDim.x) {
         const HitRec h = pool[j];
         if (h.ray == NONE) continue;   // unused tail of a per-wave chunk
-        const uint32_t ray = h.ray >> (2 * ITEMS_LOG4), it = h.ray & (ITEMS - 1u);
-        uint32_t d = offsets[ray] + h.k;
-        if (ITEMS > 1 && it) {
-            const uint32_t mask = ray_mask[ray];
-            for (uint32_t i = 0; i < it; i++)
-                if (mask & (1u << i)) d += item_cnt[(h.ray - it) + i];
+        uint32_t d;
+        if (ITEMS_LOG4 == 0) {
+            d = offsets[h.ray] + h.k;
+        } else {
+            const uint32_t ray = h.ray >> WIDE_ITEM_BITS, it = h.ray & ((1u << WIDE_ITEM_BITS) - 1u);
+            d = offsets[ray] + h.k;
+            if (it) {
+                const uint32_t mask = ray_mask[ray];
+                for (uint32_t i = 0; i < it; i++)
+                    if (mask & (1u << i)) d += item_cnt[((size_t)ray << (2 * ITEMS_LOG4)) + i];
+            }
         }
         indices[d] = h.shape;
 #pragma unroll
@@ -1099,14 +1236,14 @@ template <typename T> struct WideGeom {
         threads = (uint32_t)std::min(f64 ? 512 : 1024, std::max(64, want_threads & ~63));
         wg_per_cu = (uint32_t)std::max(1, std::min(ctx->tune[BVHGPU_TUNE_WIDE_WG_PER_CU] > 0 ? ctx->tune[BVHGPU_TUNE_WIDE_WG_PER_CU] : 2,
                                                    (int)(2048 / threads)));
-        stack_lds = (uint32_t)std::max(0, std::min(ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] >= 0 ? ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] : 8, 32));
-        const size_t budget = (size_t)(160 * 1024) / wg_per_cu;
-        const size_t fixed = 16 + (size_t)stack_lds * threads * 4;
+        stack_lds = (uint32_t)std::max(0, std::min(ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] >= 0 ? ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] : 6, 32));   // 4 / 6 / 8 / 10 / 12 measured: 6
+        const size_t budget = (size_t)(160 * 1024) / wg_per_cu - 1024;   // 1 KB for the kernel's static LDS (item table)
+        const size_t fixed = 80 + (size_t)stack_lds * threads * 4;
         const size_t per_slot = (size_t)WideIo<T>::CHUNKS * 16;
         size_t k = budget > fixed + per_slot ? (budget - fixed) / per_slot : 1;
         if (ctx->tune[BVHGPU_TUNE_WIDE_SLOTS] > 0) k = std::min<size_t>(k, (size_t)ctx->tune[BVHGPU_TUNE_WIDE_SLOTS]);
         K = (uint32_t)std::max<size_t>(1, std::min<size_t>(k, WIDE_SLOTS));
-        lds_bytes = 16 + (size_t)K * per_slot + (size_t)stack_lds * threads * 4;
+        lds_bytes = 80 + (size_t)K * per_slot + (size_t)stack_lds * threads * 4;
     }
 };
 constexpr uint32_t WIDE_GSTACK = 24;   // stack entries per lane beyond the LDS part, in HBM (a walk pushes at most 3 per wide level)
@@ -1115,13 +1252,16 @@ template <typename T, int MODE, int ITEMS_LOG4>
 static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, const WalkOut<T>& w, bvhgpu_hits* h,
                         uint32_t* ovf_flag) {
     bvhgpu_ctx* ctx = t->ctx;
+    hipStream_t st = ctx->stream;
     const WideGeom<T> g(ctx);
-    const size_t n_items = n_rays << (2 * ITEMS_LOG4);
-    const size_t full = (n_items + WAVE - 1) / WAVE;
-    const uint32_t wpw = g.threads / WAVE;
-    const uint32_t n_waves = (uint32_t)std::min<size_t>(full, (size_t)ctx->n_cu * g.wg_per_cu * wpw);
-    const dim3 grid((n_waves + wpw - 1) / wpw);
-    const uint32_t ipw = (uint32_t)((n_items + grid.x - 1) / grid.x);   // items per workgroup
+    const size_t full = (n_rays + g.threads - 1) / g.threads;
+    const dim3 grid((unsigned)std::min<size_t>(std::max<size_t>(full, 1), (size_t)ctx->n_cu * g.wg_per_cu));
+    uint32_t* list = nullptr;
+    if (ITEMS_LOG4 > 0) {   // every workgroup's region of the live-item list: its rays x 4^L entries
+        const size_t per_wg = (n_rays + grid.x - 1) / grid.x;
+        h->witems.reserve(((size_t)grid.x * per_wg << (2 * ITEMS_LOG4)) * 4 + 16);
+        list = h->witems.as<uint32_t>();
+    }
     const size_t lanes = (size_t)grid.x * g.threads;
     h->wstack.reserve(lanes * WIDE_GSTACK * 4);
     constexpr int MAXT = sizeof(T) == 8 ? 512 : 1024;
@@ -1133,8 +1273,8 @@ static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
         BVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
         have = g.lds_bytes;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(g.threads), g.lds_bytes, ctx->stream, t->wide.as<WideNode<T>>(), t->wslot_node.as<uint32_t>(),
-                       g.K, g.stack_lds, rays_dev, (uint32_t)n_items, ipw, w, h->wstack.as<uint32_t>(), WIDE_GSTACK, ovf_flag);
+    hipLaunchKernelGGL(kern, grid, dim3(g.threads), g.lds_bytes, st, t->wide.as<WideNode<T>>(), t->wslot_node.as<uint32_t>(),
+                       g.K, g.stack_lds, rays_dev, (uint32_t)n_rays, list, w, h->wstack.as<uint32_t>(), WIDE_GSTACK, ovf_flag);
 }
 
 // ---- one batch = enqueue (no host round trip) + check (after the stream has been synchronised) --------------------
@@ -1164,10 +1304,9 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     if (use_lds && mode != MODE_CLOSEST && ctx->tune[BVHGPU_TUNE_TRAVERSE_SPLIT] != 0 && t->n >= 2 && !t->unfolded && few_rays)
         split_at = 1;   // the kernel reads the boundary itself: exit index of entry 0 (the root's left child)
     int items_log4 = 0;
-    if (use_wide && mode != MODE_CLOSEST) {
+    if (use_wide && mode != MODE_CLOSEST && n_rays < WIDE_ITEM_MAX_RAYS) {
         const int want = ctx->tune[BVHGPU_TUNE_WIDE_ITEMS_LOG4];
-        items_log4 = want >= 0 ? std::min(want, 1) : (few_rays ? 1 : 0);
-        if ((n_rays << (2 * items_log4)) >= 0xFFFFFFFFull) items_log4 = 0;
+        items_log4 = want >= 0 ? std::min(want, 2) : (few_rays ? 2 : 0);
     }
     const size_t n_items = split_at ? 2 * n_rays : n_rays;
     h->ctx = ctx; h->dtype = Traits<T>::dtype; h->n_rays = n_rays; h->flags = flags; h->total = 0;
@@ -1180,7 +1319,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
 
     WalkOut<T> w;
     w.counts = nullptr; w.pool = nullptr; w.pool_v = nullptr; w.pool_cap = 0; w.ctr = ctr;
-    w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr; w.item_cnt = nullptr;
+    w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr; w.item_cnt = nullptr; w.ray_items = nullptr;
 
     uint32_t* ovf_flag = reinterpret_cast<uint32_t*>(ctr + 7);   // bit 0 ordered-iterator stack, bit 1 heap workspace, bit 2 wide-walk stack
     const bool best_first = ordered && (flags & BVHGPU_TRAVERSE_BEST_FIRST) != 0;
@@ -1208,7 +1347,8 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     };
     auto dispatch_wide = [&](auto mode_tag) {
         constexpr int M = decltype(mode_tag)::value;
-        if (M != MODE_CLOSEST && items_log4 == 1) launch_wide<T, M, (M == MODE_CLOSEST ? 0 : 1)>(t, rays_dev, n_rays, w, h, ovf_flag);
+        if (M != MODE_CLOSEST && items_log4 == 2) launch_wide<T, M, (M == MODE_CLOSEST ? 0 : 2)>(t, rays_dev, n_rays, w, h, ovf_flag);
+        else if (M != MODE_CLOSEST && items_log4 == 1) launch_wide<T, M, (M == MODE_CLOSEST ? 0 : 1)>(t, rays_dev, n_rays, w, h, ovf_flag);
         else launch_wide<T, M, 0>(t, rays_dev, n_rays, w, h, ovf_flag);
     };
 #define DISPATCH_WALK()                                                                              \
@@ -1277,10 +1417,14 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         if (h->wcounts.reserve((n_rays + 1) * 4)) h->wcounts_clean = false;
         if (!h->wcounts_clean) BVH_HIP(hipMemsetAsync(h->wcounts.p, 0, h->wcounts.cap, st));
         h->wcounts_clean = false;
-        h->ray_mask.reserve(n_rays + 1);
-        if (items_log4) h->item_cnt.reserve(((n_rays << (2 * items_log4)) + 1) * 4);
+        if (items_log4) {
+            h->ray_mask.reserve((n_rays + 1) * 2);
+            h->item_cnt.reserve(((n_rays << (2 * items_log4)) + 1) * 4);
+            if (h->ray_items.reserve((n_rays + 1) * 4)) BVH_HIP(hipMemsetAsync(h->ray_items.p, 0, h->ray_items.cap, st));   // then kept zero like wcounts
+            w.item_cnt = h->item_cnt.as<uint32_t>();
+            w.ray_items = h->ray_items.as<uint32_t>();
+        }
         counts = h->wcounts.as<uint32_t>();
-        w.item_cnt = h->item_cnt.as<uint32_t>();
     } else {
         h->counts.reserve((n_items + 1) * 4);
         counts = h->counts.as<uint32_t>();
@@ -1291,7 +1435,8 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); }
     unsigned long long* bs = h->blocksums.as<unsigned long long>();
     uint32_t* offs = h->offsets.as<uint32_t>();
-    uint8_t* rmask = h->ray_mask.as<uint8_t>();
+    uint16_t* rmask = h->ray_mask.as<uint16_t>();
+    uint32_t* ritems = (use_wide && items_log4) ? h->ray_items.as<uint32_t>() : nullptr;
     const uint32_t nr = (uint32_t)n_rays;
     const int kind = use_wide ? COUNT_MASKED : (split_at ? COUNT_PAIR : COUNT_PLAIN);
     auto scan = [&](auto kind_tag) {
@@ -1299,9 +1444,9 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         hipLaunchKernelGGL(k_scan_reduce<KD>, dim3(nb), dim3(256), 0, st, counts, nr, bs);
         if (nb > SCAN_FUSED_MAX_BLOCKS) {
             hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, bs, nb, ctr + 3);
-            hipLaunchKernelGGL((k_scan_final<KD, true>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, rmask);
+            hipLaunchKernelGGL((k_scan_final<KD, true>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, ritems, rmask);
         } else {
-            hipLaunchKernelGGL((k_scan_final<KD, false>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, rmask);
+            hipLaunchKernelGGL((k_scan_final<KD, false>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, ritems, rmask);
         }
     };
     if (kind == COUNT_MASKED) scan(std::integral_constant<int, COUNT_MASKED>{});
@@ -1314,13 +1459,10 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     uint32_t* indices = h->indices.as<uint32_t>();
     if (use_wide) {
         const uint32_t* icnt = h->item_cnt.as<uint32_t>();
-        if (nv == 3) {
-            if (items_log4) hipLaunchKernelGGL((k_hits_scatter_wide<T, 3, 1>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, icnt, rmask, indices, vals);
-            else hipLaunchKernelGGL((k_hits_scatter_wide<T, 3, 0>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, icnt, rmask, indices, vals);
-        } else {
-            if (items_log4) hipLaunchKernelGGL((k_hits_scatter_wide<T, 0, 1>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, icnt, rmask, indices, vals);
-            else hipLaunchKernelGGL((k_hits_scatter_wide<T, 0, 0>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, icnt, rmask, indices, vals);
-        }
+#define SCATTER_WIDE(NV, L4) hipLaunchKernelGGL((k_hits_scatter_wide<T, NV, L4>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, icnt, rmask, indices, vals)
+        if (nv == 3) { if (items_log4 == 2) SCATTER_WIDE(3, 2); else if (items_log4 == 1) SCATTER_WIDE(3, 1); else SCATTER_WIDE(3, 0); }
+        else { if (items_log4 == 2) SCATTER_WIDE(0, 2); else if (items_log4 == 1) SCATTER_WIDE(0, 1); else SCATTER_WIDE(0, 0); }
+#undef SCATTER_WIDE
     } else if (nv == 2) {
         hipLaunchKernelGGL((k_hits_scatter<T, 2>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, pair_counts, indices, vals);
     } else if (nv == 3) {
@@ -1347,11 +1489,11 @@ bool traverse_check(bvhgpu_hits* h) {
     BVH_HIP(hipGetLastError());
     if (best_first && (pin[7] & HEAP_OVERFLOW_BIT)) {   // a lane's heap outgrew the workspace
         if (++h->pend_attempts > 24) throw HipFail{hipErrorUnknown, "best-first heap did not converge", __LINE__};
-        h->heap_cap *= 2; h->wcounts_clean = false; return false;
+        h->heap_cap *= 2; return false;
     }
     if (ordered && (pin[7] & 1ull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
     if (h->pend_wide && (pin[7] & 4ull)) {   // a lane's stack outgrew LDS + workspace: the binary walks need no stack
-        h->force_binary = true; h->wcounts_clean = false; return false;
+        h->force_binary = true; h->wcounts_clean = false; h->ray_items.release(); return false;
     }
     if (flags & BVHGPU_TRAVERSE_CLOSEST) {
         if (stats) {

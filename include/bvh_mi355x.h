@@ -58,7 +58,10 @@ typedef enum { BVHGPU_HOST = 0, BVHGPU_DEVICE = 1 } bvhgpu_mem;
 
 /* traversal flags */
 #define BVHGPU_TRAVERSE_T_SLICE 1u /* also return (tmin,tmax) per hit: Ray::intersection_slice_for_aabb (ray_impl.rs:118-145) */
-#define BVHGPU_TRAVERSE_STATS 2u   /* also count reference-equivalent loop iterations (flat_bvh.rs:408) */
+#define BVHGPU_TRAVERSE_STATS 2u   /* also count reference-equivalent loop iterations (flat_bvh.rs:408).  Exact for every tree whose
+                                      leaves' navigator boxes equal the shapes' AABBs — all but trees with a split that had no SAH
+                                      winner (empty child bounds, bvh_node.rs:225-230): there the leaf-entry visits behind an empty
+                                      navigator box are not counted (the hit lists are still the reference's) */
 #define BVHGPU_TRAVERSE_TRIANGLES 4u /* also run Ray::intersects_triangle (ray_impl.rs:154-213) on every returned shape, as the
                                         reference's harness does after traverse (testbase.rs:826-836): Intersection{distance,u,v} per hit */
 #define BVHGPU_TRAVERSE_CLOSEST 8u   /* triangle stage fused into the walk, no CSR: per ray the candidate with the smallest
@@ -301,8 +304,8 @@ typedef enum {
     BVHGPU_TUNE_TRAVERSE_VARIANT = 0,      /* 0 one ray per lane per launch; 2 persistent workgroups over the binary traversal
                                               array with ray refill and the top of the tree resident in LDS; 3 (default) wide
                                               walk (four grandchild boxes per step) where its preconditions hold, else 2 */
-    BVHGPU_TUNE_WIDE_ITEMS_LOG4 = 1,       /* variant 3, CSR outputs: walk every ray as 4^v items (0 or 1); default -1 = by batch size */
-    BVHGPU_TUNE_WIDE_STACK_LDS = 2,        /* variant 3: stack entries per lane kept in LDS (default -1 = 8; deeper entries live in HBM) */
+    BVHGPU_TUNE_WIDE_ITEMS_LOG4 = 1,       /* variant 3, CSR outputs: cut every ray into up to 4^v items (v = 0, 1, 2); default -1 = by batch size */
+    BVHGPU_TUNE_WIDE_STACK_LDS = 2,        /* variant 3: stack entries per lane kept in LDS (default -1 = 6; deeper entries live in HBM) */
     BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS = 3, /* variant 2 is used for batches of at least this many rays (default 16384) */
     BVHGPU_TUNE_TRAVERSE_LDS_SLOTS = 4,    /* variant 2: top-of-tree entries kept in LDS per workgroup (default 0 = as many as let two workgroups share a CU: f32 2559, f64 1462) */
     BVHGPU_TUNE_TRAVERSE_LDS_THREADS = 5,  /* variant 2: workgroup size (default 0 = per type: f32 1024, f64 512) */

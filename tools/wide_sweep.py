@@ -45,11 +45,10 @@ ref = run("variant 2 (binary, LDS top, 2 items/ray)")
 ctx.set_tuning(TUNE_TRAVERSE_VARIANT, 3)
 threads_opts = [1024, 512] if dt == "f32" else [512, 256]
 for items, wg, thr, stack, slots in itertools.chain(
-        itertools.product([1, 0], [2, 1], threads_opts, [8], [0]),
-        itertools.product([1], [2], threads_opts[:1], [4, 6, 12, 0], [0]),
-        itertools.product([1], [2, 4], [256], [8], [0]),
-        itertools.product([1], [2], threads_opts[:1], [8], [85, 341]),
-        itertools.product([1], [1], threads_opts[:1], [8], [341, 1365])):
+        itertools.product([2, 1, 0], [2, 1], threads_opts[:1], [8], [0]),
+        itertools.product([2, 1], [2], threads_opts[1:], [8], [0]),
+        itertools.product([2], [2], threads_opts[:1], [4, 6, 10, 12], [0]),
+        itertools.product([2], [2], threads_opts[:1], [8], [85, 341])):
     if wg * thr > 2048:
         continue
     ctx.set_tuning(TUNE_WIDE_ITEMS_LOG4, items); ctx.set_tuning(TUNE_WIDE_WG_PER_CU, wg); ctx.set_tuning(TUNE_WIDE_THREADS, thr)
