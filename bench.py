@@ -173,6 +173,7 @@ def run_workload(wl, args, env, steps, warmup, detailed):
     import torch
     import torch.distributed as dist
     from bvh_amd import Bvh, FlatBvh, dist as bdist
+    from bvh_amd._lib import TRAVERSE_COHERENT
     rank, n_gpus, dev, ctx, comm = env["rank"], env["n_gpus"], env["dev"], env["ctx"], env["comm"]
     R, aabbs, rays = wl.R, wl.aabbs, wl.rays
 
@@ -210,8 +211,10 @@ def run_workload(wl, args, env, steps, warmup, detailed):
                 state["peer"] = FlatBvh.scene_import(blob, blob.numel(), ctx, reuse=state["peer"])
             tree = bvh if rank == 0 else state["peer"]
         else:
-            bvh.rebuild(aabbs, flatten=True)   # FlatBvh::build (flat_bvh.rs:328-331)
-            tree = bvh
+            # FlatBvh::build (flat_bvh.rs:328-331) and FlatBvh::traverse enqueued back to back, ONE host round trip per step:
+            # the wait validates the build, completes the batch and is the end of the step (nothing of the next step is in flight)
+            bvh.rebuild_async(aabbs)
+            return bvh.traverse_async(rays, flags=TRAVERSE_COHERENT if wl.coherent else 0).wait()
         return tree.traverse_batch(rays, fetch=False, coherent=wl.coherent)[3]   # FlatBvh::traverse, CSR stays in HBM
 
     def barrier():

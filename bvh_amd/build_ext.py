@@ -38,6 +38,17 @@ def is_stale() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(out: str, defines, verbose: bool = True) -> str:
+    """developer builds with extra -D flags (instrumentation, tuning sweeps) into another file; load with BVH_AMD_SO=<out>"""
+    rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
+    cmd = [hipcc()] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES] + \
+          [f"-L{rocm_lib}", "-lrccl", f"-Wl,-rpath,{rocm_lib}"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=CSRC)
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return OUT
@@ -57,4 +68,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--variant" in sys.argv:   # python build_ext.py --variant <out.so> DEFINE[=v] ...
+        k = sys.argv.index("--variant")
+        print(build_variant(sys.argv[k + 1], sys.argv[k + 2:]))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

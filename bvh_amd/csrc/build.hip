@@ -87,6 +87,7 @@ template <typename T> struct BuildArgs {
     uint16_t* node_slot;     // heap number of every node (SLOT_NONE beyond the first 15 levels): traversal's LDS slots
     uint32_t* slot_entry;    // cleared here, filled by flatten
     uint32_t n_slots;
+    uint32_t* wslot_node;    // WIDE_SLOTS entries: LDS slot table of the wide walk, cleared here, filled by flatten
     uint32_t* idx[2];
     uint8_t* bk;
     Item<T>* big[2];
@@ -119,8 +120,10 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T>
     T loc[STAT_KEYS];   // joined on floats (one v_min/v_max each); keys only for the atomics that merge waves
 #pragma unroll
     for (int j = 0; j < STAT_KEYS; j++) loc[j] = key_is_min(j) ? Tr::inf() : -Tr::inf();
-    if (blockIdx.x == 0)   // the LDS slot table of the previous tree (filled again by flatten)
+    if (blockIdx.x == 0) {   // the LDS slot tables of the previous tree (filled again by flatten)
         for (uint32_t i = threadIdx.x; i < a.n_slots; i += blockDim.x) a.slot_entry[i] = NONE;
+        for (uint32_t i = threadIdx.x; i < WIDE_SLOTS; i += blockDim.x) a.wslot_node[i] = NONE;
+    }
     const bool copy = a.src != a.aabbs;
     T* own = const_cast<T*>(a.aabbs);
     bool bad = false;   // input contract: the reference panics on NaN / inf centroids (bvh_node.rs:214-217); a single shape is never bucketed
@@ -281,6 +284,15 @@ template <typename T> __global__ __launch_bounds__(256) void k_init(BuildArgs<T>
     using Tr = Traits<T>;
     for (int i = threadIdx.x; i < (int)(ROOTKEY_OFF / 4); i += 256) a.ctr[i] = 0;
     if (threadIdx.x < STAT_KEYS) a.rootkeys[threadIdx.x] = key_is_min(threadIdx.x) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
+}
+
+// The build's counters go to the tree's pinned host page and are reset for the next build in the same launch (the
+// runtime's copy kernel plus k_init cost ~4.5 µs each on the stream; this is one ~4 µs launch)
+template <typename T> __global__ __launch_bounds__(256) void k_publish_build(BuildArgs<T> a, uint32_t* __restrict__ host_page) {
+    using Tr = Traits<T>;
+    for (int i = threadIdx.x; i < (int)(ROOTKEY_OFF / 4); i += 256) { host_page[i] = a.ctr[i]; a.ctr[i] = 0; }
+    if (threadIdx.x < STAT_KEYS) a.rootkeys[threadIdx.x] = key_is_min(threadIdx.x) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
+    __threadfence_system();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1221,6 +1233,7 @@ template <typename T> static BuildArgs<T> make_args(bvhgpu_tree* t, const T* src
     a.node_slot = t->node_slot.as<uint16_t>();
     a.slot_entry = t->slot_entry.as<uint32_t>();
     a.n_slots = TopCfg<T>::SLOTS;
+    a.wslot_node = t->wslot_node.as<uint32_t>();
     a.idx[0] = t->idx[0].as<uint32_t>(); a.idx[1] = t->idx[1].as<uint32_t>();
     a.bk = t->bk.as<uint8_t>();
     a.big[0] = t->big[0].as<Item<T>>(); a.big[1] = t->big[1].as<Item<T>>();
@@ -1292,6 +1305,7 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     t->shape_node.reserve(n * 4);
     if (t->node_slot.reserve(t->n_nodes * 2)) BVH_HIP(hipMemsetAsync(t->node_slot.p, 0xFF, t->node_slot.cap, st));
     t->slot_entry.reserve(TopCfg<T>::SLOTS * 4);
+    t->wslot_node.reserve(WIDE_SLOTS * 4);
     t->idx[0].reserve(n * 4);
     t->idx[1].reserve(n * 4);
     t->bk.reserve(n);
@@ -1328,8 +1342,7 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     }
     run_lower_tiers<T>(t, a, g, 0u, 0u);
     if (flatten_after) flatten_tree<T>(t);   // optimistic too: redone if the build turns out to be unfinished
-    BVH_HIP(hipMemcpyAsync(t->pin, a.ctr, ROOTKEY_OFF, hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(k_init<T>, dim3(1), dim3(256), 0, st, a);   // reset for the next build of this tree (behind the readback)
+    hipLaunchKernelGGL(k_publish_build<T>, dim3(1), dim3(256), 0, st, a, reinterpret_cast<uint32_t*>(t->pin));   // readback + reset for the next build
     t->ctr_ready = true;
     t->pending_build = true; t->pend_level = level; t->pend_flatten = flatten_after;
 }
@@ -1364,10 +1377,13 @@ template <typename T> void build_finalize(bvhgpu_tree* t) {
             if (pin[CTR_LEVEL0 + 2 * lvl_slot(level)] == 0) break;
         }
         run_lower_tiers<T>(t, a, g, mid2_done, small_done);
-        BVH_HIP(hipMemcpyAsync(t->pin, a.ctr, ROOTKEY_OFF, hipMemcpyDeviceToHost, st));
-        hipLaunchKernelGGL(k_init<T>, dim3(1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_publish_build<T>, dim3(1), dim3(256), 0, st, a, reinterpret_cast<uint32_t*>(t->pin));
         t->ctr_ready = true;
-        if (t->pend_flatten) flatten_tree<T>(t);   // the optimistic one ran over an unfinished tree
+        if (t->pend_flatten) {   // the optimistic one ran over an unfinished tree (and may have left stray LDS slot entries)
+            BVH_HIP(hipMemsetAsync(t->wslot_node.p, 0xFF, WIDE_SLOTS * 4, st));
+            BVH_HIP(hipMemsetAsync(t->slot_entry.p, 0xFF, TopCfg<T>::SLOTS * 4, st));
+            flatten_tree<T>(t);
+        }
         BVH_HIP(hipStreamSynchronize(st));
         BVH_HIP(hipGetLastError());
         t->redone = true;   // whoever traversed the optimistic result must do it again

@@ -348,6 +348,9 @@ int do_nearest(bvhgpu_tree* t, const T* points, size_t n, int mem, int kind, uin
 #ifdef BVH_PROFILE_MID
 namespace bvhgpu { void debug_mid_prof(unsigned long long* out, bool reset); }
 #endif
+#ifdef BVH_WIDE_PROFILE
+namespace bvhgpu { void debug_wide_prof(unsigned long long* out, size_t n); }
+#endif
 
 extern "C" {
 
@@ -870,6 +873,9 @@ int bvhgpu_get_tuning(const bvhgpu_ctx* ctx, int knob, int* value) {
     return BVHGPU_OK;
 }
 
+#ifdef BVH_WIDE_PROFILE
+void bvhgpu_debug_wide_prof(unsigned long long* out, size_t n) { bvhgpu::debug_wide_prof(out, n); }
+#endif
 #ifdef BVH_PROFILE_MID
 void bvhgpu_debug_mid_prof(unsigned long long* out, int reset) { bvhgpu::debug_mid_prof(out, reset != 0); }
 #endif

@@ -33,17 +33,71 @@ template <> __device__ __forceinline__ void write_trav<double>(TravNode<double>*
     p[3] = make_double2(__longlong_as_double((long long)es), 0.0);
 }
 
+// The wide node (common.hpp WideNode) of inner tree node i, straight from the BvhNode array: slots 0,1 = the left child's
+// children (or the left child itself when it is a leaf), slots 2,3 likewise on the right.  A child's box is its parent's
+// child_l_aabb / child_r_aabb; a leaf's is bit-identical to its shape's AABB (join(empty, aabb) == aabb).
+template <typename T>
+__device__ __forceinline__ void flatten_wide_node(const typename Traits<T>::Node* __restrict__ nodes, const typename Traits<T>::Node& nd,
+                                                  uint32_t i, const uint16_t* __restrict__ node_slot, WideNode<T>* __restrict__ wide,
+                                                  uint32_t* __restrict__ wslot_node, uint32_t n_nodes, uint32_t n_shapes) {
+    const T nan = __builtin_nan("");
+    const typename Traits<T>::Node cl = nodes[nd.l], cr = nodes[nd.r];
+    // references of the four grandchildren: a leaf by its shape, an inner node by its index
+    uint32_t gidx[4] = {cl.l, cl.r, cr.l, cr.r};
+    uint32_t gshape[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const bool has = (c < 2 ? cl.shape : cr.shape) == NONE && gidx[c] < n_nodes;
+        gshape[c] = has ? nodes[gidx[c]].shape : NONE;
+    }
+    WideNode<T> w;
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        const typename Traits<T>::Node& c = side ? cr : cl;
+        const T* cmn = side ? nd.r_min : nd.l_min;
+        const T* cmx = side ? nd.r_max : nd.l_max;
+        if (c.shape != NONE) {   // the child is a leaf
+#pragma unroll
+            for (int k = 0; k < 3; k++) { w.mn[k][2 * side] = cmn[k]; w.mx[k][2 * side] = cmx[k]; w.mn[k][2 * side + 1] = nan; w.mx[k][2 * side + 1] = nan; }
+            w.ref[2 * side] = c.shape < n_shapes ? c.shape : NONE;
+            w.ref[2 * side + 1] = NONE;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                w.mn[k][2 * side] = c.l_min[k]; w.mx[k][2 * side] = c.l_max[k];
+                w.mn[k][2 * side + 1] = c.r_min[k]; w.mx[k][2 * side + 1] = c.r_max[k];
+            }
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                const uint32_t gi = gidx[2 * side + g], gs = gshape[2 * side + g];
+                w.ref[2 * side + g] = gi >= n_nodes ? NONE : (gs != NONE ? (gs < n_shapes ? gs : NONE) : (WIDE_INNER | gi));
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(w._pad) / 4); k++) w._pad[k] = 0;
+    wide[i] = w;
+    // LDS slot table of the wide walk: tree levels 0, 2, .., 10 in 4-ary heap order (binary heap number h: root 1)
+    const uint32_t h = node_slot[i];
+    if (h >= 1u && h < 2048u) {
+        const int level = 31 - __clz((int)h);
+        if ((level & 1) == 0) wslot_node[wide_level_base(level >> 1) + (h - (1u << level))] = i;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node* __restrict__ nodes,
                                                  const uint32_t* __restrict__ node_start,
                                                  const uint32_t* __restrict__ node_count, const T* __restrict__ aabbs,
                                                  const uint16_t* __restrict__ node_slot, uint32_t* __restrict__ slot_entry,
                                                  typename Traits<T>::Flat* __restrict__ flat, TravNode<T>* __restrict__ trav,
+                                                 WideNode<T>* __restrict__ wide, uint32_t* __restrict__ wslot_node,
                                                  uint32_t n_nodes, uint32_t n_shapes) {
     using Tr = Traits<T>;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     const typename Tr::Node nd = nodes[i];
+    if (wide && nd.shape == NONE && nd.l < n_nodes && nd.r < n_nodes) flatten_wide_node<T>(nodes, nd, i, node_slot, wide, wslot_node, n_nodes, n_shapes);
     if (n_nodes == 1) {
         // single-shape tree: the root is a leaf and emits one leaf entry (flat_bvh.rs:129-141); its
         // traversal entry tests the shape's own AABB (flat_bvh.rs:411-418)
@@ -196,13 +250,17 @@ template <typename T> void flatten_tree(bvhgpu_tree* t) {
     t->trav.reserve(t->n_trav * sizeof(TravNode<T>));
     const uint32_t nn = (uint32_t)t->n_nodes;
     hipStream_t st = t->ctx->stream;
+    // the wide nodes come out of the same pass (their LDS slot table was cleared by the build's first kernel)
+    const bool with_wide = t->n >= 2 && t->n < WIDE_MAX_SHAPES && t->wslot_node.p != nullptr;
+    if (with_wide) t->wide.reserve((size_t)nn * sizeof(WideNode<T>));
     hipLaunchKernelGGL(k_flatten<T>, dim3((nn + 255) / 256), dim3(256), 0, st,
                        t->nodes.as<typename Tr::Node>(), t->node_start.as<uint32_t>(), t->node_count.as<uint32_t>(),
                        t->aabbs.as<T>(), t->node_slot.as<uint16_t>(), t->slot_entry.as<uint32_t>(),
                        t->flat.as<typename Tr::Flat>(),
-                       t->trav.as<TravNode<T>>(), nn, (uint32_t)t->n);
+                       t->trav.as<TravNode<T>>(), with_wide ? t->wide.as<WideNode<T>>() : nullptr, t->wslot_node.as<uint32_t>(), nn,
+                       (uint32_t)t->n);
     BVH_HIP(hipGetLastError());
-    wide_from_trav<T>(t);
+    t->has_wide = with_wide;
     t->flattened = true;
 }
 

@@ -806,6 +806,9 @@ template <int ITEMS_LOG4> __device__ __forceinline__ uint32_t item_slot(uint32_t
     return ITEMS_LOG4 == 2 ? 5u + j : 1u + j;   // level 1: 1 + c; level 2: 4 * (1 + c) + 1 + k = 5 + 4c + k
 }
 
+#ifdef BVH_WIDE_PROFILE   // developer build: per-wave timestamps (100 MHz wall clock) of the wide walk's phases
+__device__ unsigned long long g_wide_prof[4 * 16384];
+#endif
 // ITEMS_LOG4 = 0: one item per ray, drawn by ray number.  1 / 2: every workgroup first cuts ITS rays into live items (its
 // region of `list`, filled through an LDS counter — no global atomic: one address only takes ~88 atomics per µs on this
 // chip, which made a separate filter kernel with one atomic per wave cost more than the walk) and then walks them.
@@ -830,12 +833,19 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     const size_t G = (size_t)gridDim.x * bd, gid = (size_t)blockIdx.x * bd + tid;
     const int lane = lane_id();
     const unsigned long long lt = lanemask_lt();
-    // this workgroup's rays
-    const unsigned long long per_wg = ((unsigned long long)n_rays + gridDim.x - 1) / gridDim.x;
-    const unsigned long long g0 = (unsigned long long)blockIdx.x * per_wg, g1 = g0 + per_wg;
-    const uint32_t ray_begin = (uint32_t)(g0 < n_rays ? g0 : n_rays);
-    const uint32_t ray_end = (uint32_t)(g1 < n_rays ? g1 : n_rays);
-    if (tid == 0) { s_next = ITEMS_LOG4 == 0 ? ray_begin : 0u; s_nlist = 0u; }
+#ifdef BVH_WIDE_PROFILE
+    const unsigned long long prof_t0 = wall_clock64();
+    unsigned long long prof_steps = 0;
+#endif
+    // This workgroup's rays: the 64-ray blocks b, b + grid, b + 2 grid, ... of the batch.  (Contiguous ranges per workgroup
+    // put all of a stream's expensive stretch — the BASELINE stream's first 5 000 rays start inside a cube — on a few
+    // workgroups: the slowest workgroup finished at 158 µs against a mean of 115 µs.)
+    const uint32_t n_blocks = (n_rays + 63u) >> 6;
+    const uint32_t my_blocks = n_blocks > blockIdx.x ? (n_blocks - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
+    const uint32_t per_wg = ((n_blocks + gridDim.x - 1u) / gridDim.x) << 6;   // capacity of a workgroup's share (host: the same formula)
+    const uint32_t my_rays = my_blocks << 6;                                   // local ray numbers [0, my_rays), some beyond n_rays in the last block
+    auto ray_of = [&](uint32_t local) -> uint32_t { return (((local >> 6) * gridDim.x + blockIdx.x) << 6) | (local & 63u); };
+    if (tid == 0) { s_next = 0u; s_nlist = 0u; }
     for (uint32_t q = tid; q < K; q += bd) {
         const uint32_t node = wslot_node[q];
         if (node != NONE) {
@@ -860,10 +870,10 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
         }
         // rays → live items, into this workgroup's region of the list (at most ITEMS per ray)
         list = list_all + (size_t)blockIdx.x * per_wg * ITEMS;
-        for (uint32_t r0 = ray_begin; r0 < ray_end; r0 += bd) {   // workgroup-uniform
-            const uint32_t r = r0 + tid;
+        for (uint32_t l0 = 0; l0 < my_rays; l0 += bd) {   // workgroup-uniform
+            const uint32_t r = l0 + tid < my_rays ? ray_of(l0 + tid) : n_rays;
             uint32_t mask = 0;
-            if (r < ray_end) {
+            if (r < n_rays) {
                 const typename Traits<T>::Ray* rp = rays + r;
                 const T o[3] = {rp->o[0], rp->o[1], rp->o[2]}, inv[3] = {rp->inv[0], rp->inv[1], rp->inv[2]};
                 if (!ray_is_finite<T>(o, inv)) {
@@ -898,8 +908,11 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
         __threadfence_block();
     }
     __syncthreads();
-    const uint32_t wg_begin = ITEMS_LOG4 == 0 ? ray_begin : 0u;
-    const uint32_t wg_end = ITEMS_LOG4 == 0 ? ray_end : s_nlist;
+    const uint32_t wg_begin = 0u;
+    const uint32_t wg_end = ITEMS_LOG4 == 0 ? my_rays : s_nlist;
+#ifdef BVH_WIDE_PROFILE
+    const unsigned long long prof_t1 = wall_clock64();
+#endif
 
     LaneRay<T, MODE> ray;
     ray.clear();
@@ -950,9 +963,13 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                 const uint32_t mine = base + (uint32_t)__popcll(idle & lt);
                 if (!run && base < wg_end && mine < wg_end) {
                     if (ITEMS_LOG4 == 0) {
-                        item = mine;
-                        ray.load(rays, mine);
-                        cur = WIDE_INNER | WIDE_RESIDENT | 0u;   // the root is heap slot 0 (K >= 1)
+                        item = ray_of(mine);
+                        if (item < n_rays) {
+                            ray.load(rays, item);
+                            cur = WIDE_INNER | WIDE_RESIDENT | 0u;   // the root is heap slot 0 (K >= 1)
+                        } else {
+                            item = NONE;                         // padding of the batch's last 64-ray block
+                        }
                     } else {
                         item = list[mine];
                         const uint32_t j = item & ((1u << WIDE_ITEM_BITS) - 1u);
@@ -962,13 +979,16 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                     }
                     ray.r = item;                                // pool records are per item
                     sp = 0;
-                    run = true;
+                    run = cur != CUR_NONE;
                 }
                 exhausted = base >= wg_end || (wg_end - base) <= nidle;
             }
             if (!__any(run)) break;
         }
         const bool fast = !__any(run && !ray.fin);   // wave-uniform
+#ifdef BVH_WIDE_PROFILE
+        prof_steps += WIDE_INNER_STEPS;
+#endif
         for (int s = 0; s < WIDE_INNER_STEPS; s++) {
             if (cur & WIDE_INNER) {   // (CUR_NONE and shape indices have bit 31 clear)
                 const uint32_t id = cur & (WIDE_RESIDENT - 1u);
@@ -1001,6 +1021,12 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     }
     if (__any(ovf) && lane == 0) atomicOr(overflow, 4u);
     walk_epilogue<T, MODE>(w, pc, lane, false, 0, 0, 0, 0);
+#ifdef BVH_WIDE_PROFILE
+    if (lane == 0) {
+        const size_t wv = gid >> 6;
+        if (wv < 16384) { g_wide_prof[4 * wv] = prof_t0; g_wide_prof[4 * wv + 1] = prof_t1; g_wide_prof[4 * wv + 2] = wall_clock64(); g_wide_prof[4 * wv + 3] = prof_steps; }
+    }
+#endif
 }
 
 // ---- exclusive scan of per-ray counts ----------------------------------------------------------
@@ -1258,7 +1284,8 @@ static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
     const dim3 grid((unsigned)std::min<size_t>(std::max<size_t>(full, 1), (size_t)ctx->n_cu * g.wg_per_cu));
     uint32_t* list = nullptr;
     if (ITEMS_LOG4 > 0) {   // every workgroup's region of the live-item list: its rays x 4^L entries
-        const size_t per_wg = (n_rays + grid.x - 1) / grid.x;
+        const size_t n_blocks = (n_rays + 63) / 64;
+        const size_t per_wg = ((n_blocks + grid.x - 1) / grid.x) * 64;   // k_traverse_wide: capacity of a workgroup's share
         h->witems.reserve(((size_t)grid.x * per_wg << (2 * ITEMS_LOG4)) * 4 + 16);
         list = h->witems.as<uint32_t>();
     }
@@ -1541,6 +1568,13 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
         if (traverse_check(h)) return;
     }
 }
+
+#ifdef BVH_WIDE_PROFILE
+void debug_wide_prof(unsigned long long* out, size_t n) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_prof), sizeof(unsigned long long) * n);
+}
+#endif
 
 template void traverse_enqueue<float>(bvhgpu_tree*, const bvhgpu_ray_f32*, size_t, unsigned, bvhgpu_hits*);
 template void traverse_enqueue<double>(bvhgpu_tree*, const bvhgpu_ray_f64*, size_t, unsigned, bvhgpu_hits*);

@@ -1,0 +1,45 @@
+"""developer tool: per-wave phase times inside k_traverse_wide.  Build the instrumented library first:
+   python bvh_amd/build_ext.py --variant tools/libbvh_wideprof.so BVH_WIDE_PROFILE
+   then on the GPU box: python tools/wide_prof.py [rays] [items_log4]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["BVH_AMD_SO"] = os.path.join(ROOT, "tools", "libbvh_wideprof.so")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from bvh_amd import Bvh, Context, RayBatch, _lib, testbase as tb  # noqa: E402
+from bvh_amd._lib import RAY_F32, TUNE_WIDE_ITEMS_LOG4  # noqa: E402
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+items = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+lib = _lib.load()
+dev = torch.device("cuda", 0)
+ctx = Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+ctx.set_tuning(TUNE_WIDE_ITEMS_LOG4, items)
+bounds = tb.default_bounds()
+_, aabbs = tb.create_n_cubes(10_000, bounds)
+bvh = Bvh.from_aabbs(torch.from_numpy(aabbs).to(dev), ctx)
+bvh.flatten_in_place()
+buf = torch.empty(R * RAY_F32.itemsize, dtype=torch.uint8, device=dev)
+rays = RayBatch.generate(0, R, bounds, buf, np.float32, ctx)
+for _ in range(3):
+    bvh.traverse_batch(rays, fetch=False)
+n_waves = 8192
+out = (C.c_ulonglong * (4 * n_waves))()
+lib.bvhgpu_debug_wide_prof(out, 4 * n_waves)
+a = np.array(out[:], dtype=np.float64).reshape(-1, 4)
+a = a[a[:, 0] > 0]
+t0 = a[:, 0].min()
+us = lambda x: (x - t0) / 100.0  # noqa: E731  100 MHz wall clock
+start, pro, end, steps = us(a[:, 0]), us(a[:, 1]), us(a[:, 2]), a[:, 3]
+print(f"waves {len(a)}  rays {R}  items_log4 {items}")
+print(f"wave start      : mean {start.mean():7.2f}  max {start.max():7.2f} us")
+print(f"prologue end    : mean {pro.mean():7.2f}  max {pro.max():7.2f} us   (duration mean {(pro - start).mean():6.2f})")
+print(f"wave end        : mean {end.mean():7.2f}  p50 {np.percentile(end, 50):7.2f}  p90 {np.percentile(end, 90):7.2f}  max {end.max():7.2f} us")
+print(f"walk steps/wave : mean {steps.mean():6.1f}  max {steps.max():6.0f};  walk time per step (mean over waves) {((end - pro) / np.maximum(steps, 1)).mean():6.3f} us")
+wg_end = end.reshape(-1, 16).max(axis=1) if len(end) % 16 == 0 else end
+print(f"workgroup end   : mean {wg_end.mean():7.2f}  min {wg_end.min():7.2f}  max {wg_end.max():7.2f} us")
