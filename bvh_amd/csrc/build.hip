@@ -637,6 +637,64 @@ template <typename T> __global__ __launch_bounds__(256) void k_split(BuildArgs<T
 }
 
 // ------------------------------------------------------------------------------------------------
+// Wave-level SEGMENTED inclusive scans of the 12 bound values (aabb min3 max3, centroid min3 max3) with join as the
+// operator: lane i ends with the join over [lo_i, i] (prefix) / [i, hi_i) (suffix), where [lo_i, hi_i) is the run of
+// lanes lane i belongs to.  Inside a row of 16 lanes the partners come by DPP (row_shr / row_shl: a VALU move, no
+// LDS crossbar trip — 288 ds_bpermute per level made the wave tier LDS-bound); across rows the carry is one lane's
+// value: row_bcast:15 / :31 upwards, v_readlane of lanes 48 / 32 / 16 downwards.  A lane only ever joins a partner of
+// its own run.  `span`: an upper bound (power of two) on the length of the live runs: the steps beyond are skipped.
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void join12(T (&a)[STAT_KEYS], const T (&b)[STAT_KEYS]) {
+#pragma unroll
+    for (int k = 0; k < STAT_KEYS; k++) a[k] = key_is_min(k) ? join_min(a[k], b[k]) : join_max(a[k], b[k]);
+}
+template <typename T, int D> __device__ __forceinline__ void seg_prefix_step(T (&P)[STAT_KEYS], int lane, int lo) {
+    T u[STAT_KEYS];
+#pragma unroll
+    for (int k = 0; k < STAT_KEYS; k++) u[k] = dpp_fetch<0x110 + D>(P[k]);
+    if (lane - D >= lo) join12(P, u);
+}
+template <typename T, int D> __device__ __forceinline__ void seg_suffix_step(T (&S)[STAT_KEYS], int lane, int hi) {
+    T u[STAT_KEYS];
+#pragma unroll
+    for (int k = 0; k < STAT_KEYS; k++) u[k] = dpp_fetch<0x100 + D>(S[k]);
+    if (lane + D < hi) join12(S, u);
+}
+template <typename T> __device__ __forceinline__ void seg_prefix_scan(T (&P)[STAT_KEYS], int lane, int lo, int span) {
+    if (span > 1) seg_prefix_step<T, 1>(P, lane, lo);
+    if (span > 2) seg_prefix_step<T, 2>(P, lane, lo);
+    if (span > 4) seg_prefix_step<T, 4>(P, lane, lo);
+    if (span > 8) seg_prefix_step<T, 8>(P, lane, lo);
+    const int row0 = lane & ~15;   // first lane of this lane's row
+    if (__any(lo < row0)) {        // a run that began in an earlier row takes the finished prefix of the row below
+        T u[STAT_KEYS];
+#pragma unroll
+        for (int k = 0; k < STAT_KEYS; k++) u[k] = dpp_fetch<0x142, 0xA>(P[k]);   // rows 1 and 3 from lanes 15 / 47
+        if ((lane & 16) && lo < row0) join12(P, u);
+#pragma unroll
+        for (int k = 0; k < STAT_KEYS; k++) u[k] = dpp_fetch<0x143, 0xC>(P[k]);   // rows 2 and 3 from lane 31 (complete by now)
+        if (lane >= 32 && lo < 32) join12(P, u);
+    }
+}
+template <typename T, int ROW> __device__ __forceinline__ void seg_suffix_carry(T (&S)[STAT_KEYS], int lane, int hi) {
+    T u[STAT_KEYS];
+#pragma unroll
+    for (int k = 0; k < STAT_KEYS; k++) u[k] = lane_bcast<16 * (ROW + 1)>(S[k]);
+    if ((lane & ~15) == 16 * ROW && hi > 16 * (ROW + 1)) join12(S, u);
+}
+template <typename T> __device__ __forceinline__ void seg_suffix_scan(T (&S)[STAT_KEYS], int lane, int hi, int span) {
+    if (span > 1) seg_suffix_step<T, 1>(S, lane, hi);
+    if (span > 2) seg_suffix_step<T, 2>(S, lane, hi);
+    if (span > 4) seg_suffix_step<T, 4>(S, lane, hi);
+    if (span > 8) seg_suffix_step<T, 8>(S, lane, hi);
+    if (__any(hi > (lane & ~15) + 16)) {   // top row first: a run that continues into the next row takes that row's first lane
+        seg_suffix_carry<T, 2>(S, lane, hi);
+        seg_suffix_carry<T, 1>(S, lane, hi);
+        seg_suffix_carry<T, 0>(S, lane, hi);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // mid tier — one workgroup finishes a whole node of 65 .. Cfg::MAXN shapes down to <= 64-shape
 // sub-nodes, level by level, entirely in LDS: the node's index slice AND its shapes' AABBs are
 // loaded once and then only permuted in LDS.  Same-address LDS atomics were the bottleneck of a
@@ -896,23 +954,17 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
                 T sv[STAT_KEYS];
 #pragma unroll
                 for (int k = 0; k < STAT_KEYS; k++) sv[k] = curv[k];
-#pragma unroll
-                for (int d = 1; d < WAVE; d <<= 1) {
-                    if (!__any((lane - chain0) >= d)) break;   // no chain is longer than d lanes
-                    const int up4 = ((lane - d) >= chain0 ? lane - d : lane) << 2;
-                    T u[STAT_KEYS];
-#pragma unroll
-                    for (int k = 0; k < STAT_KEYS; k++) u[k] = lane_fetch(sv[k], up4);
-#pragma unroll
-                    for (int k = 0; k < STAT_KEYS; k++) sv[k] = key_is_min(k) ? join_min(sv[k], u[k]) : join_max(sv[k], u[k]);
+                {
+                    const int len = lane - chain0;   // lanes of this lane's chain below it
+                    const int span = __any(len >= 8) ? 16 : (__any(len >= 4) ? 8 : (__any(len >= 2) ? 4 : (__any(len >= 1) ? 2 : 1)));
+                    seg_prefix_scan<T>(sv, lane, chain0, span);
                 }
                 // the first run of a multi-run thread ends here: join the carry of the previous lane, flush
                 {
                     const bool need = have_first && cont_prev;
-                    const int pv4 = (lane > 0 ? lane - 1 : 0) << 2;
-                    T c[STAT_KEYS];
+                    T c[STAT_KEYS];   // the previous lane's value (lane 0: its own) — wave_shr:1
 #pragma unroll
-                    for (int k = 0; k < STAT_KEYS; k++) c[k] = lane_fetch(sv[k], pv4);
+                    for (int k = 0; k < STAT_KEYS; k++) c[k] = dpp_fetch<0x138>(sv[k]);
 #pragma unroll
                     for (int k = 0; k < STAT_KEYS; k++) {
                         const T j2 = key_is_min(k) ? join_min(firstv[k], c[k]) : join_max(firstv[k], c[k]);
@@ -1120,31 +1172,17 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
 #pragma unroll
         for (int k = 0; k < 3; k++) c[k] = center1(box[k], box[3 + k]);
 
-        // ---- segmented inclusive prefix (P) and suffix (S) joins of AABB and centroid bounds.  One
-        //      v_min/v_max per join (common.hpp join_min/join_max: -0 < +0 like the oracle).  A lane at the
-        //      edge of its segment fetches from ITSELF (join(x, x) = x), so no select is needed, and all 24
-        //      cross-lane moves of a step are issued before any is consumed (a ds_bpermute round trip is
-        //      ~100 cycles).  Steps whose distance is not below the longest live segment are skipped.
+        // ---- segmented inclusive prefix (P) and suffix (S) joins of AABB and centroid bounds over the lanes of the segment
+        //      (seg_prefix_scan / seg_suffix_scan above: DPP inside a row, one-lane carries across rows)
         T P[12], S[12];
 #pragma unroll
         for (int k = 0; k < 6; k++) { P[k] = box[k]; S[k] = box[k]; }
 #pragma unroll
         for (int k = 0; k < 3; k++) { P[6 + k] = c[k]; P[9 + k] = c[k]; S[6 + k] = c[k]; S[9 + k] = c[k]; }
-#pragma unroll
-        for (int d = 1; d < WAVE; d <<= 1) {
-            if (!__any(!done && segn > d)) break;
-            const int up4 = ((lane - d) >= lo ? lane - d : lane) << 2;
-            const int dn4 = ((lane + d) < hi ? lane + d : lane) << 2;
-            T u[12], v[12];
-#pragma unroll
-            for (int k = 0; k < 12; k++) u[k] = lane_fetch(P[k], up4);
-#pragma unroll
-            for (int k = 0; k < 12; k++) v[k] = lane_fetch(S[k], dn4);
-#pragma unroll
-            for (int k = 0; k < 12; k++) {
-                P[k] = key_is_min(k) ? join_min(P[k], u[k]) : join_max(P[k], u[k]);
-                S[k] = key_is_min(k) ? join_min(S[k], v[k]) : join_max(S[k], v[k]);
-            }
+        {
+            const int span = __any(!done && segn > 8) ? 16 : (__any(!done && segn > 4) ? 8 : (__any(!done && segn > 2) ? 4 : (__any(!done && segn > 1) ? 2 : 1)));
+            seg_prefix_scan<T>(P, lane, lo, span);
+            seg_suffix_scan<T>(S, lane, hi, span);
         }
         // ---- SAH cost of the 5 candidates (:231-247): L = prefix at the last lane of bucket <= s,
         //      R = suffix at the first lane of bucket > s

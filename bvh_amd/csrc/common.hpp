@@ -288,6 +288,27 @@ __device__ __forceinline__ double lane_fetch(double v, int addr4) {
     const int hi = __builtin_amdgcn_ds_bpermute(addr4, (int)(b >> 32));
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// DPP lane moves: the value of the lane the control selects, or the lane's OWN value where that lane is outside the row /
+// masked (so that join(x, fetched) is a no-op there).  No LDS crossbar trip, unlike ds_bpermute.
+// controls: row_shr:n = 0x110 + n, row_shl:n = 0x100 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ float dpp_fetch(float v) {
+    const int b = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(b, b, CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ double dpp_fetch(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = (int)(b & 0xFFFFFFFFll), hi = (int)(b >> 32);
+    const int l2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);
+    const int h2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+    return __longlong_as_double(((long long)h2 << 32) | (unsigned int)l2);
+}
+// value of one (compile-time) lane in every lane, through an SGPR
+template <int LANE> __device__ __forceinline__ float lane_bcast(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), LANE)); }
+template <int LANE> __device__ __forceinline__ double lane_bcast(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), LANE), hi = __builtin_amdgcn_readlane((int)(b >> 32), LANE);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     int l = lane_id();
