@@ -42,4 +42,6 @@ print(f"prologue end    : mean {pro.mean():7.2f}  max {pro.max():7.2f} us   (dur
 print(f"wave end        : mean {end.mean():7.2f}  p50 {np.percentile(end, 50):7.2f}  p90 {np.percentile(end, 90):7.2f}  max {end.max():7.2f} us")
 print(f"walk steps/wave : mean {steps.mean():6.1f}  max {steps.max():6.0f};  walk time per step (mean over waves) {((end - pro) / np.maximum(steps, 1)).mean():6.3f} us")
 wg_end = end.reshape(-1, 16).max(axis=1) if len(end) % 16 == 0 else end
+wg_pro = pro.reshape(-1, 16).max(axis=1) if len(pro) % 16 == 0 else pro
+print(f"per subtree (wg % 16) end: " + " ".join(f"{wg_end[j::16].mean():.0f}" for j in range(16)))
 print(f"workgroup end   : mean {wg_end.mean():7.2f}  min {wg_end.min():7.2f}  max {wg_end.max():7.2f} us")
