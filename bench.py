@@ -103,7 +103,7 @@ class Workload:
             self.label = (f"procedural atrium STAND-IN for media/sponza.obj (absent from the reference checkout), "
                           f"{len(self.aabbs_np)} triangles through the OBJ loader")
             if name == "standin-primary":
-                self.config_id, per, self.coherent = 2, rays or 10_000_000, True
+                self.config_id, per, self.coherent = 2, rays or 10_000_000, False   # (the engine picks the walk; the COHERENT hint is not needed)
                 self.scaling = scaling or "weak"
                 c = (self.bounds[:3] + self.bounds[3:]) * 0.5   # pinhole at the scene-bounds centre
                 self.cam = camera(c, c + np.array([1.0, -0.15, 0.25]), fov_y_deg=70.0, aspect=4000 / 2500)
@@ -128,11 +128,10 @@ class Workload:
             self.rays = RayBatch.generate(self.first, self.R, self.bounds, self.rays_buf, self.np_dtype, ctx)
 
     def oracle_rays(self, orc, first, n):
-        """the same rays from the oracle's restatement of the generators (f32 stream, widened for f64 like the device does)"""
-        r = orc.primary_rays(self.cam, self.W, self.H, first, n) if self.cam is not None else orc.create_rays(first, n, self.bounds)
-        if self.dtype_name == "f64":
-            r = orc.make_rays(r["o"].astype(np.float64), r["d"].astype(np.float64), np.float64)
-        return r
+        """the same rays from the oracle's restatement of the generators (f64: the f32 points widened BEFORE Ray::new, like the device)"""
+        if self.cam is not None:
+            return orc.primary_rays(self.cam, self.W, self.H, first, n, self.np_dtype)
+        return orc.create_rays(first, n, self.bounds, self.np_dtype)
 
     def describe(self):
         kind = "coherent primary rays (4000x2500 pinhole)" if self.coherent else "create_ray rays (seed-0 stream)"
@@ -143,7 +142,7 @@ class Workload:
 
 def newest_bound(kernel_prefix):
     """profiles/*_bound.json of the newest profile round that holds PMC counters for this kernel"""
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bound.json")), key=os.path.getmtime, reverse=True)
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bound.json")), reverse=True)   # newest round / version tag first (r2_v4 > r2_v1)
     for f in found:
         try:
             j = json.load(open(f))

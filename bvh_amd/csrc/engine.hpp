@@ -73,6 +73,8 @@ struct bvhgpu_tree {
                                  // grandchildren, so traversal must test every ancestor (binary walk only)
     int pend_level = 0;
     int levels = 0;
+    int hint_levels = 0;         // level-synchronous passes the previous build of hint_n shapes needed
+    size_t hint_n = 0;
     void* pin = nullptr;         // pinned host copy of the build counters (1 KiB), one per tree so that builds can be in flight
     // persistent device arrays
     bvhgpu::DevBuf aabbs;       // n * 6 T
@@ -132,6 +134,7 @@ struct bvhgpu_hits {
     bvhgpu::DevBuf item_cnt;  // per item: hits (valid where the ray's mask has the item's bit)
     bvhgpu::DevBuf wstack;    // the part of the lanes' stacks that does not fit in LDS
     bool wcounts_clean = false;
+    bool bs_clean = false;       // blocksums are all-zero (the wide walk adds into them)
     bool force_binary = false;   // the wide walk overflowed a lane's stack on this batch: replay with the binary walk
     // the batch in flight (traverse_enqueue → traverse_check): what a replay needs
     void* pin = nullptr;         // 64 B of pinned host memory: the 8 walk / scan counters of the last batch

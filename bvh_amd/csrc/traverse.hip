@@ -23,6 +23,9 @@
 
 namespace bvhgpu {
 
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;   // rays per workgroup of the count scan
+
 // what a walk produces besides the CSR of shape indices
 enum : int {
     MODE_INDICES = 0,   // Vec<&Shape> only
@@ -69,6 +72,7 @@ template <typename T> struct WalkOut {
     uint32_t* closest_prim;      // per ray shape index or NONE
     uint32_t* item_cnt;          // wide walk with several items per ray: hits of item (ray, j), written only when non-zero
     uint32_t* ray_items;         // ... and per ray the set of j that wrote one (kept all-zero between batches like counts)
+    unsigned long long* blocksums;   // wide walk: hits per block of SCAN_BLOCK rays, summed as the items retire (or NULL: k_scan_reduce does it)
 };
 
 // ---- Ray::intersects_triangle (ray_impl.rs:154-213), Möller–Trumbore with back-face culling.  Same
@@ -943,15 +947,18 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                     w.closest[3 * r] = ray.best[0]; w.closest[3 * r + 1] = ray.best[1]; w.closest[3 * r + 2] = ray.best[2];
                     w.closest_prim[r] = ray.best_prim;
                 } else if (ray.cnt) {
+                    uint32_t r = item;
                     if (ITEMS_LOG4 == 0) {
                         w.counts[item] = ray.cnt;
                     } else {
-                        const uint32_t r = item >> WIDE_ITEM_BITS, j = item & ((1u << WIDE_ITEM_BITS) - 1u);
+                        const uint32_t j = item & ((1u << WIDE_ITEM_BITS) - 1u);
                         const uint32_t jj = j == WIDE_ITEM_WHOLE ? 0u : j;
+                        r = item >> WIDE_ITEM_BITS;
                         atomicAdd(&w.counts[r], ray.cnt);
                         atomicOr(&w.ray_items[r], 1u << jj);
                         w.item_cnt[((size_t)r << (2 * ITEMS_LOG4)) + jj] = ray.cnt;
                     }
+                    if (w.blocksums) atomicAdd(&w.blocksums[r / SCAN_BLOCK], (unsigned long long)ray.cnt);   // saves the reduce pass of the scan
                 }
                 item = NONE;
             }
@@ -1030,8 +1037,6 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
 }
 
 // ---- exclusive scan of per-ray counts ----------------------------------------------------------
-constexpr int SCAN_ITEMS = 4;
-constexpr int SCAN_BLOCK = 256 * SCAN_ITEMS;
 
 // KIND 1 (pair): every ray was walked as two items (k_traverse_lds split): its count is counts[2r] + counts[2r+1].
 // KIND 2 (wide walk): counts[r] is non-zero only for rays with hits and ray_items[r] holds the set of the ray's items that
@@ -1200,11 +1205,13 @@ __global__ __launch_bounds__(256) void k_hits_scatter_wide(const HitRec* __restr
 
 // The 8 walk / scan counters go to the context's pinned host page and are zeroed for the next call: one 64-thread
 // launch instead of the runtime's copy kernel plus its fill kernel (≈4.5 µs each on the stream).
-__global__ void k_publish_counters(unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ host_page) {
+__global__ void k_publish_counters(unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ host_page,
+                                   unsigned long long* __restrict__ blocksums, uint32_t nb) {
     if (threadIdx.x < 8) {
         host_page[threadIdx.x] = ctr[threadIdx.x];
         ctr[threadIdx.x] = 0;
     }
+    for (uint32_t i = threadIdx.x; i < nb; i += 64u) blocksums[i] = 0ull;   // the wide walk adds into them: zero again for the next batch
     __threadfence_system();
 }
 
@@ -1319,7 +1326,10 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
                    : (flags & BVHGPU_TRAVERSE_T_SLICE) ? MODE_T_SLICE : MODE_INDICES;
     const int nv = mode == MODE_T_SLICE ? 2 : (mode == MODE_TRIANGLES ? 3 : 0);
     const int variant = ctx->tune[BVHGPU_TUNE_TRAVERSE_VARIANT];
-    const bool big_batch = !coherent && !ordered && n_rays >= (size_t)ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS];
+    // (the COHERENT hint only matters below the large-batch threshold: on 10 M primary rays the wide walk takes 1.8 ms, the
+    //  persistent binary walk 2.2 ms and one ray per lane per launch 5.4 ms)
+    (void)coherent;
+    const bool big_batch = !ordered && n_rays >= (size_t)ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS];
     // walk kernel: wide walk (see k_traverse_wide for what it needs), else persistent workgroups over the binary array with
     // its top in LDS, else one ray per lane per launch
     const bool use_wide = variant >= 3 && big_batch && t->has_wide && !t->exact_only && !t->unfolded && !stats &&
@@ -1346,7 +1356,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
 
     WalkOut<T> w;
     w.counts = nullptr; w.pool = nullptr; w.pool_v = nullptr; w.pool_cap = 0; w.ctr = ctr;
-    w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr; w.item_cnt = nullptr; w.ray_items = nullptr;
+    w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr; w.item_cnt = nullptr; w.ray_items = nullptr; w.blocksums = nullptr;
 
     uint32_t* ovf_flag = reinterpret_cast<uint32_t*>(ctr + 7);   // bit 0 ordered-iterator stack, bit 1 heap workspace, bit 2 wide-walk stack
     const bool best_first = ordered && (flags & BVHGPU_TRAVERSE_BEST_FIRST) != 0;
@@ -1418,14 +1428,14 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
         DISPATCH_WALK();
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
-        hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);   // readback + reset for the next call
+        hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin, (unsigned long long*)nullptr, 0u);   // readback + reset for the next call
         h->ctr_clean = true;
         return;
     }
 
     h->offsets.reserve((n_rays + 1) * 4);
     const uint32_t nb = (uint32_t)((n_rays + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    h->blocksums.reserve((nb + 1) * sizeof(unsigned long long));
+    if (h->blocksums.reserve((nb + 1) * sizeof(unsigned long long))) h->bs_clean = false;
     if (h->pool_cap == 0) h->pool_cap = std::max<size_t>(n_rays, (size_t)1 << 16);
     if (n_rays == 0) {
         BVH_HIP(hipMemsetAsync(h->offsets.p, 0, 4, st));
@@ -1452,6 +1462,9 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
             w.ray_items = h->ray_items.as<uint32_t>();
         }
         counts = h->wcounts.as<uint32_t>();
+        // (Summing the hits per scan block in the walk — one atomic per retiring item — to save k_scan_reduce was tried: the
+        //  BASELINE stream's 10 000 hits all fall into the first five blocks, i.e. onto ONE cache line, which takes ≈ 88 atomics
+        //  per µs: the walk went from 128 to 162 µs.  WalkOut::blocksums stays NULL.)
     } else {
         h->counts.reserve((n_items + 1) * 4);
         counts = h->counts.as<uint32_t>();
@@ -1468,7 +1481,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     const int kind = use_wide ? COUNT_MASKED : (split_at ? COUNT_PAIR : COUNT_PLAIN);
     auto scan = [&](auto kind_tag) {
         constexpr int KD = decltype(kind_tag)::value;
-        hipLaunchKernelGGL(k_scan_reduce<KD>, dim3(nb), dim3(256), 0, st, counts, nr, bs);
+        if (!w.blocksums) hipLaunchKernelGGL(k_scan_reduce<KD>, dim3(nb), dim3(256), 0, st, counts, nr, bs);
         if (nb > SCAN_FUSED_MAX_BLOCKS) {
             hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, bs, nb, ctr + 3);
             hipLaunchKernelGGL((k_scan_final<KD, true>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, ritems, rmask);
@@ -1498,7 +1511,8 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         hipLaunchKernelGGL((k_hits_scatter<T, 0>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, pair_counts, indices, vals);
     }
     if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
-    hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);   // readback + reset for the next call
+    hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin, w.blocksums, w.blocksums ? nb : 0u);   // readback + reset for the next call
+    h->bs_clean = w.blocksums != nullptr;   // (k_scan_reduce / k_scan_sums leave their own values behind)
     h->ctr_clean = true;
 #undef DISPATCH_WALK
 }
@@ -1520,7 +1534,7 @@ bool traverse_check(bvhgpu_hits* h) {
     }
     if (ordered && (pin[7] & 1ull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
     if (h->pend_wide && (pin[7] & 4ull)) {   // a lane's stack outgrew LDS + workspace: the binary walks need no stack
-        h->force_binary = true; h->wcounts_clean = false; h->ray_items.release(); return false;
+        h->force_binary = true; h->wcounts_clean = false; h->bs_clean = false; h->ray_items.release(); return false;
     }
     if (flags & BVHGPU_TRAVERSE_CLOSEST) {
         if (stats) {

@@ -74,7 +74,8 @@ typedef enum { BVHGPU_HOST = 0, BVHGPU_DEVICE = 1 } bvhgpu_mem;
                                               farthest_traverse_iterator (bvh_impl.rs:145-176) = DistanceTraverseIterator
                                               (distance_traverse.rs:40-158), a best-first walk driven by a BinaryHeap, instead of
                                               the child-ordered depth-first iterator */
-#define BVHGPU_TRAVERSE_COHERENT 16u /* hint: neighbouring rays are similar (primary rays): walk one ray per lane in lock-step */
+#define BVHGPU_TRAVERSE_COHERENT 16u /* hint: neighbouring rays are similar (primary rays).  Only consulted for batches below the
+                                        large-batch threshold (BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS); results never depend on it */
 
 /* ---- POD layouts (little-endian, natural alignment, no packing pragmas) ---- */
 

@@ -166,6 +166,39 @@ void orc_primary_rays(const float cam[14], uint32_t width, uint32_t height, uint
     }
 }
 
+/* The f64 twins of the two streams, as the engine defines them for BASELINE.json configs[4]: the SAME f32 points
+ * (origin and target / camera direction computed in f32 as above), widened to f64, then Ray::new in f64
+ * (include/bvh_mi355x.h bvhgpu_gen_rays_f64 / bvhgpu_gen_primary_rays_f64). */
+void orc_create_rays_f64(uint64_t first, size_t n, const float bounds[6], orc_ray_f64 *rays) {
+    uint64_t seed = 2ull * first * 0x9E3779B97F4A7C15ull;
+    for (size_t i = 0; i < n; i++) {
+        float o[3], d[3];
+        orc_next_point3(&seed, bounds, o);
+        orc_next_point3(&seed, bounds, d);
+        const double oo[3] = { (double)o[0], (double)o[1], (double)o[2] }, dd[3] = { (double)d[0], (double)d[1], (double)d[2] };
+        orc_ray_new_f64(oo, dd, &rays[i]);
+    }
+}
+void orc_primary_rays_f64(const float cam[14], uint32_t width, uint32_t height, uint64_t first, size_t n, orc_ray_f64 *rays) {
+    (void)height;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t id = first + i;
+        const uint32_t x = (uint32_t)(id % width), y = (uint32_t)(id / width);
+        float fx = (float)x + 0.5f; fx = fx / (float)width; fx = fx * 2.0f; const float sx = fx - 1.0f;
+        float fy = (float)y + 0.5f; fy = fy / (float)height; fy = fy * 2.0f; const float sy = 1.0f - fy;
+        const float ax = sx * cam[12], ay = sy * cam[13];
+        double oo[3], dd[3];
+        for (int k = 0; k < 3; k++) {
+            const float r = ax * cam[3 + k], u = ay * cam[6 + k];
+            float t = cam[9 + k] + r;
+            const float d = t + u;
+            oo[k] = (double)cam[k];
+            dd[k] = (double)d;
+        }
+        orc_ray_new_f64(oo, dd, &rays[i]);
+    }
+}
+
 /* generate_aligned_boxes + UnitBox::aabb — testbase.rs:109-116, 84-89 */
 void orc_aligned_boxes(float *aabbs) {
     int i = 0;

@@ -89,6 +89,9 @@ void orc_create_n_cubes(size_t n_cubes, const float bounds[6], float *tris, floa
 /* create_ray stream (testbase.rs:687-691), rays [first, first+n) of the seed-0 stream. */
 void orc_create_rays(uint64_t first, size_t n, const float bounds[6], orc_ray_f32 *rays);
 void orc_primary_rays(const float cam[14], uint32_t width, uint32_t height, uint64_t first, size_t n, orc_ray_f32 *rays);
+/* the f64 twins (configs[4]): the same f32 points widened to f64 BEFORE Ray::new, as bvhgpu_gen_rays_f64 does */
+void orc_create_rays_f64(uint64_t first, size_t n, const float bounds[6], orc_ray_f64 *rays);
+void orc_primary_rays_f64(const float cam[14], uint32_t width, uint32_t height, uint64_t first, size_t n, orc_ray_f64 *rays);
 /* generate_aligned_boxes (testbase.rs:109-116) → 21 AABBs (UnitBox::aabb :84-89). */
 void orc_aligned_boxes(float *aabbs /* 21*6 */);
 

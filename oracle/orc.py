@@ -118,18 +118,26 @@ def create_n_cubes(n_cubes: int, bounds=DEFAULT_BOUNDS):
     return tris, aabbs
 
 
-def create_rays(first: int, n: int, bounds=DEFAULT_BOUNDS):
-    rays = np.empty(n, dtype=RAY_F32)
+def create_rays(first: int, n: int, bounds=DEFAULT_BOUNDS, dtype=np.float32):
+    """create_ray stream (testbase.rs:687-691); dtype f64: the same f32 points widened before Ray::new (the engine's
+    definition of the configs[4] stream, bvhgpu_gen_rays_f64)"""
     b = np.ascontiguousarray(bounds, dtype=np.float32)
+    if np.dtype(dtype) == np.float64:
+        rays = np.empty(n, dtype=RAY_F64)
+        lib().orc_create_rays_f64(C.c_uint64(first), C.c_size_t(n), _p(b), _p(rays))
+        return rays
+    rays = np.empty(n, dtype=RAY_F32)
     lib().orc_create_rays(C.c_uint64(first), C.c_size_t(n), _p(b), _p(rays))
     return rays
 
 
-def primary_rays(cam, width: int, height: int, first: int, n: int):
+def primary_rays(cam, width: int, height: int, first: int, n: int, dtype=np.float32):
     """coherent primary rays (bvh_oracle.c orc_primary_rays): cam = eye3, right3, up3, forward3, tan_x, tan_y"""
     c = np.ascontiguousarray(cam, dtype=np.float32).reshape(14)
-    rays = np.zeros(n, dtype=RAY_F32)
-    lib().orc_primary_rays(_p(c), C.c_uint32(width), C.c_uint32(height), C.c_uint64(first), C.c_size_t(n), _p(rays))
+    f64 = np.dtype(dtype) == np.float64
+    rays = np.zeros(n, dtype=RAY_F64 if f64 else RAY_F32)
+    fn = lib().orc_primary_rays_f64 if f64 else lib().orc_primary_rays
+    fn(_p(c), C.c_uint32(width), C.c_uint32(height), C.c_uint64(first), C.c_size_t(n), _p(rays))
     return rays
 
 

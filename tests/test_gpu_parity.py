@@ -236,6 +236,12 @@ def test_device_ray_stream_matches_reference_generator(eng, orc):
     ctx.synchronize()
     got = buf.cpu().numpy().view(RAY_F32)
     assert got.tobytes() == orc.create_rays(999_000, 4096).tobytes()
+    # the f64 twin (BASELINE.json configs[4]): the same f32 points, widened BEFORE Ray::new
+    from bvh_amd._lib import RAY_F64
+    buf64 = torch.empty(4096 * RAY_F64.itemsize, dtype=torch.uint8, device="cuda")
+    eng.RayBatch.generate(999_000, 4096, tb.default_bounds(), buf64, np.float64, ctx)
+    ctx.synchronize()
+    assert buf64.cpu().numpy().view(RAY_F64).tobytes() == orc.create_rays(999_000, 4096, dtype=np.float64).tobytes()
     # Ray::new on device == oracle Ray::new (sqrt and divides correctly rounded)
     rng = np.random.default_rng(5)
     o = rng.normal(size=(1000, 3)).astype(np.float32) * 1e3

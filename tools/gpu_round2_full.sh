@@ -1,0 +1,10 @@
+#!/bin/bash
+# full validation of the round: every GPU test, smoke, the default bench line, the profile round
+tag=${1:-r2_v4}
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p gpurun_out
+( timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -30 ) > gpurun_out/full_tests.log 2>&1
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/full_smoke.log 2>&1 )
+( timeout 900 python bench.py > gpurun_out/full_bench.json 2> gpurun_out/full_bench.err )
+( timeout 900 bash tools/profile_round.sh $tag > gpurun_out/full_profile.log 2>&1 )
+tail -n 4 gpurun_out/full_tests.log; tail -n 2 gpurun_out/full_smoke.log; head -c 400 gpurun_out/full_bench.json
