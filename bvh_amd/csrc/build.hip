@@ -30,7 +30,7 @@ namespace bvhgpu {
 
 constexpr int MAXLV = 96;        // counter slots (levels beyond reuse the last two, host-synchronised)
 constexpr int CTR_SMALL = 0;     // u32: number of small items (<= 64 shapes, wave-subtree tier)
-constexpr int CTR_TICKET = 3;    // u32: k_prep arrival ticket (the last workgroup creates the root item)
+// (u32 slot 3 is unused: it was the arrival ticket of a k_prep that created the root item itself)
 constexpr int CTR_MID2 = 2;      // u32: number of workgroup-tier items (65 .. BuildArgs::mid_max shapes)
 constexpr int CTR_FLAGS = 4;     // u32: BUILD_FLAG_* bits raised by the kernels, read back by the host with the counters
 constexpr uint32_t BUILD_FLAG_NONFINITE = 1u;    // a shape AABB holds NaN / ±inf, or the root centroid extent overflows: the
@@ -66,7 +66,8 @@ constexpr int STAT_REP = BVH_STAT_REP;   // global replicas of an item's statist
                               // the root do not serialise on 78 addresses (k_bin of level 0: 13.4 -> see profiles); the
                               // selection merges the replicas
 constexpr int CTR_LEVEL0 = 16;   // u32 pairs (n_items, n_tiles) per level slot
-constexpr size_t ROOTKEY_OFF = 1024;  // byte offset of the 12 root keys inside the ctr buffer
+constexpr size_t ROOTKEY_OFF = 1024;  // byte offset of k_prep's per-workgroup partial bounds (12 keys each) inside the ctr buffer
+constexpr int PREP_MAX_WG = 1024;     // k_prep's grid never exceeds this
 
 __host__ __device__ inline int lvl_slot(int L) { return L < MAXLV - 2 ? L : (MAXLV - 2 + (L & 1)); }
 
@@ -97,7 +98,7 @@ template <typename T> struct BuildArgs {
     uint32_t* tile_item[2];
     uint32_t* tile_cnt;
     uint32_t* ctr;
-    typename Traits<T>::Key* rootkeys;
+    typename Traits<T>::Key* rootkeys;   // [gridDim of k_prep][12]: every workgroup's bounds; the last one to arrive joins them
     uint32_t n;
 };
 
@@ -168,27 +169,32 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T>
     }
     if (a.n > 1 && __any(bad) && lane_id() == 0) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_NONFINITE);
     __syncthreads();
-    if (threadIdx.x < STAT_KEYS) {
-        int j = threadIdx.x;
-        if (key_is_min(j)) atomicMin(&a.rootkeys[j], sk[j]);
-        else atomicMax(&a.rootkeys[j], sk[j]);
+    // Every workgroup leaves its 12 bounds in its own row; k_root joins the rows.  (History: 12 global min / max atomics per
+    // workgroup on one cache line; then plain rows + fence + ticket with the last workgroup creating the root item in this
+    // launch — measured with tools/prep_diag.sh: this kernel 7 µs, the agent-scope fence +6.5 µs, ticket + last-workgroup
+    // phase +7 µs.  A dependent launch of one workgroup costs less than either.)
+    if (threadIdx.x < STAT_KEYS) a.rootkeys[(size_t)blockIdx.x * STAT_KEYS + threadIdx.x] = sk[threadIdx.x];
+}
+
+// joint_aabb_of_shapes finished (bvh_impl.rs:74) → the root work item (BvhNodeBuildArgs, bvh_impl.rs:75-87).  One workgroup.
+template <typename T> __global__ __launch_bounds__(256) void k_root(BuildArgs<T> a, uint32_t prep_wgs) {
+    using Tr = Traits<T>;
+    using Key = typename Tr::Key;
+    __shared__ Key sk[STAT_KEYS];
+    if (threadIdx.x < STAT_KEYS) sk[threadIdx.x] = key_is_min(threadIdx.x) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
+    __syncthreads();
+    for (uint32_t e = threadIdx.x; e < prep_wgs * (uint32_t)STAT_KEYS; e += blockDim.x) {   // rows x keys, coalesced
+        const Key v = a.rootkeys[e];
+        const int j = (int)(e % (uint32_t)STAT_KEYS);
+        if (key_is_min(j)) atomicMin(&sk[j], v);
+        else atomicMax(&sk[j], v);
     }
-    // the workgroup that arrives last sees every contribution and creates the root item
-    // (BvhNodeBuildArgs of bvh_impl.rs:75-87) — saves a kernel boundary on the latency-bound build
-    __shared__ uint32_t s_last;
-    __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&a.ctr[CTR_TICKET], 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (s_last && threadIdx.x < WAVE) {
-        __threadfence();
+    if (threadIdx.x < WAVE) {
         T A[6], C[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            A[k] = Tr::unkey(__hip_atomic_load(&a.rootkeys[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            C[k] = Tr::unkey(__hip_atomic_load(&a.rootkeys[6 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
-        uint32_t flags = __hip_atomic_load(&a.ctr[CTR_FLAGS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 0; k < 6; k++) { A[k] = Tr::unkey(sk[k]); C[k] = Tr::unkey(sk[6 + k]); }
+        uint32_t flags = a.ctr[CTR_FLAGS];
         if (a.n > 1) {   // finite boxes whose centroid extent overflows: (c - cmin) / ext is NaN for some shape → same panic
             bool ovf = false;
 #pragma unroll
@@ -279,19 +285,15 @@ __device__ void push_pair(const BuildArgs<T>& a, int next_level, uint32_t parent
     }
 }
 
-// counters = 0, root keys = identities of min / max
+// counters = 0
 template <typename T> __global__ __launch_bounds__(256) void k_init(BuildArgs<T> a) {
-    using Tr = Traits<T>;
     for (int i = threadIdx.x; i < (int)(ROOTKEY_OFF / 4); i += 256) a.ctr[i] = 0;
-    if (threadIdx.x < STAT_KEYS) a.rootkeys[threadIdx.x] = key_is_min(threadIdx.x) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
 }
 
 // The build's counters go to the tree's pinned host page and are reset for the next build in the same launch (the
 // runtime's copy kernel plus k_init cost ~4.5 µs each on the stream; this is one ~4 µs launch)
 template <typename T> __global__ __launch_bounds__(256) void k_publish_build(BuildArgs<T> a, uint32_t* __restrict__ host_page) {
-    using Tr = Traits<T>;
     for (int i = threadIdx.x; i < (int)(ROOTKEY_OFF / 4); i += 256) { host_page[i] = a.ctr[i]; a.ctr[i] = 0; }
-    if (threadIdx.x < STAT_KEYS) a.rootkeys[threadIdx.x] = key_is_min(threadIdx.x) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
     __threadfence_system();
 }
 
@@ -1355,7 +1357,7 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     t->mid2.reserve(g.max_mid2 * sizeof(Item<T>));
     t->small.reserve((n + 1) * sizeof(Item<T>));
     t->tile_cnt.reserve(g.max_tiles * NUM_BUCKETS * 4);
-    if (t->ctr.reserve(ROOTKEY_OFF + STAT_KEYS * sizeof(Key))) t->ctr_ready = false;   // a fresh buffer has not been zeroed by the previous build
+    if (t->ctr.reserve(ROOTKEY_OFF + (size_t)PREP_MAX_WG * STAT_KEYS * sizeof(Key))) t->ctr_ready = false;   // a fresh buffer has not been zeroed by the previous build
     if (!t->pin) BVH_HIP(hipHostMalloc(&t->pin, ROOTKEY_OFF, hipHostMallocDefault));
 
     const BuildArgs<T> a = make_args<T>(t, aabbs_dev);
@@ -1365,8 +1367,9 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
 #ifndef BVH_PREP_PER_WG
 #define BVH_PREP_PER_WG 1024
 #endif
-    const int prep_grid = (int)std::min<size_t>((n + BVH_PREP_PER_WG - 1) / BVH_PREP_PER_WG, 1024);   // 256 / 512 / 1024 / 2048 shapes per workgroup measured
-    hipLaunchKernelGGL(k_prep<T>, dim3(prep_grid), dim3(256), 0, st, a);   // + aabbs copy + input validation + root item
+    const int prep_grid = (int)std::min<size_t>((n + BVH_PREP_PER_WG - 1) / BVH_PREP_PER_WG, (size_t)PREP_MAX_WG);   // 256 / 512 / 1024 / 2048 shapes per workgroup measured
+    hipLaunchKernelGGL(k_prep<T>, dim3(prep_grid), dim3(256), 0, st, a);   // + aabbs copy + input validation
+    hipLaunchKernelGGL(k_root<T>, dim3(1), dim3(256), 0, st, a, (uint32_t)prep_grid);
 
     // Optimistic schedule with no host round trip: enough level-synchronous passes for a balanced
     // tree, then the workgroup tier over everything queued so far, then the wave tier.  ONE readback
@@ -1384,8 +1387,10 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
         for (; level < fixed; level++) run_level<T>(t, a, g, level);
     }
     run_lower_tiers<T>(t, a, g, 0u, 0u);
-    if (flatten_after) flatten_tree<T>(t);   // optimistic too: redone if the build turns out to be unfinished
-    hipLaunchKernelGGL(k_publish_build<T>, dim3(1), dim3(256), 0, st, a, reinterpret_cast<uint32_t*>(t->pin));   // readback + reset for the next build
+    // counters: readback through the pinned page + reset for the next build, by the flatten kernel when there is one
+    // (optimistic too: redone if the build turns out to be unfinished) and by a launch of their own otherwise
+    if (flatten_after && n >= 1) flatten_tree<T>(t, a.ctr, reinterpret_cast<uint32_t*>(t->pin), (uint32_t)(ROOTKEY_OFF / 4));
+    else hipLaunchKernelGGL(k_publish_build<T>, dim3(1), dim3(256), 0, st, a, reinterpret_cast<uint32_t*>(t->pin));
     t->ctr_ready = true;
     t->pending_build = true; t->pend_level = level; t->pend_flatten = flatten_after;
 }

@@ -121,11 +121,13 @@ struct bvhgpu_hits {
     bvhgpu::DevBuf closest;  // n_rays * 3 T (CLOSEST)
     bvhgpu::DevBuf closest_prim;  // n_rays u32
     bvhgpu::DevBuf blocksums;
+    bvhgpu::DevBuf bsum64;    // wide walk: hits per 64-ray block (k_scan_final's input instead of a reduce pass)
     bvhgpu::DevBuf ctr;      // [0] pool count (u64) [1] visited [2] leaf_visits [3] device_steps [4] ray ticket
     bvhgpu::DevBuf heap_dist, heap_node;  // best-first traversal: the part of the lanes' heaps that does not fit in LDS
     uint32_t heap_cap = 48;  // ... entries per lane (doubles when a batch overflows it)
     size_t pool_cap = 0;
     bool ctr_clean = false;  // the counters were zeroed behind the previous call's readback
+    int ctr_set = 0;         // which of the two counter sets the next batch uses
     // wide walk
     bvhgpu::DevBuf wcounts;   // n_rays+1 u32: hit count | item mask << 28, all-zero between batches
     bvhgpu::DevBuf ray_mask;  // n_rays u16: items of the ray that reported hits (valid for rays with hits)
@@ -151,7 +153,8 @@ template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t
 template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after);
 template <typename T> void build_finalize(bvhgpu_tree* t);
 // flatten.hip
-template <typename T> void flatten_tree(bvhgpu_tree* t);
+// pub_*: also publish + reset the builder's counters (build_enqueue's last launch); see k_flatten
+template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr = nullptr, uint32_t* pub_host = nullptr, uint32_t pub_words = 0);
 template <typename T> void wide_from_trav(bvhgpu_tree* t);   // wide nodes + their LDS slot table from trav + slot_entry
 // refit.hip
 template <typename T> void refit_tree(bvhgpu_tree* t, const T* aabbs_dev);

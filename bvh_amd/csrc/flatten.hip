@@ -92,8 +92,16 @@ __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node*
                                                  const uint16_t* __restrict__ node_slot, uint32_t* __restrict__ slot_entry,
                                                  typename Traits<T>::Flat* __restrict__ flat, TravNode<T>* __restrict__ trav,
                                                  WideNode<T>* __restrict__ wide, uint32_t* __restrict__ wslot_node,
-                                                 uint32_t n_nodes, uint32_t n_shapes) {
+                                                 uint32_t n_nodes, uint32_t n_shapes, uint32_t* __restrict__ pub_ctr,
+                                                 uint32_t* __restrict__ pub_host, uint32_t pub_words) {
     using Tr = Traits<T>;
+    // build + flatten in one enqueue: this launch is the last of the chain, so its first workgroup also stores the builder's
+    // counters in the tree's pinned host page and zeroes them for the next build (nothing in this kernel reads them) —
+    // a launch of its own for that cost 4.4 µs of the step
+    if (pub_ctr && blockIdx.x == 0) {
+        for (uint32_t k = threadIdx.x; k < pub_words; k += blockDim.x) { pub_host[k] = pub_ctr[k]; pub_ctr[k] = 0; }
+        __threadfence_system();
+    }
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     const typename Tr::Node nd = nodes[i];
@@ -243,7 +251,7 @@ template <typename T> void wide_from_trav(bvhgpu_tree* t) {
 template void wide_from_trav<float>(bvhgpu_tree*);
 template void wide_from_trav<double>(bvhgpu_tree*);
 
-template <typename T> void flatten_tree(bvhgpu_tree* t) {
+template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr, uint32_t* pub_host, uint32_t pub_words) {
     using Tr = Traits<T>;
     if (t->n == 0) { t->flattened = true; return; }
     t->flat.reserve(t->n_flat * sizeof(typename Tr::Flat));
@@ -258,13 +266,13 @@ template <typename T> void flatten_tree(bvhgpu_tree* t) {
                        t->aabbs.as<T>(), t->node_slot.as<uint16_t>(), t->slot_entry.as<uint32_t>(),
                        t->flat.as<typename Tr::Flat>(),
                        t->trav.as<TravNode<T>>(), with_wide ? t->wide.as<WideNode<T>>() : nullptr, t->wslot_node.as<uint32_t>(), nn,
-                       (uint32_t)t->n);
+                       (uint32_t)t->n, pub_ctr, pub_host, pub_words);
     BVH_HIP(hipGetLastError());
     t->has_wide = with_wide;
     t->flattened = true;
 }
 
-template void flatten_tree<float>(bvhgpu_tree*);
-template void flatten_tree<double>(bvhgpu_tree*);
+template void flatten_tree<float>(bvhgpu_tree*, uint32_t*, uint32_t*, uint32_t);
+template void flatten_tree<double>(bvhgpu_tree*, uint32_t*, uint32_t*, uint32_t);
 
 }  // namespace bvhgpu

@@ -72,7 +72,7 @@ template <typename T> struct WalkOut {
     uint32_t* closest_prim;      // per ray shape index or NONE
     uint32_t* item_cnt;          // wide walk with several items per ray: hits of item (ray, j), written only when non-zero
     uint32_t* ray_items;         // ... and per ray the set of j that wrote one (kept all-zero between batches like counts)
-    unsigned long long* blocksums;   // wide walk: hits per block of SCAN_BLOCK rays, summed as the items retire (or NULL: k_scan_reduce does it)
+    uint32_t* bsum64;         // wide walk: hits per 64-ray block, left by the workgroup that owns the block (or NULL: k_scan_reduce does the sums)
 };
 
 // ---- Ray::intersects_triangle (ray_impl.rs:154-213), Möller–Trumbore with back-face culling.  Same
@@ -701,6 +701,7 @@ constexpr int WIDE_INNER_STEPS = BVH_WIDE_INNER_STEPS;   // walk steps between t
 // Rays with a non-finite component are not cut: they travel as one item (j = WIDE_ITEM_WHOLE) from the root.
 constexpr uint32_t WIDE_ITEM_BITS = 5;                 // item = ray << 5 | j
 constexpr uint32_t WIDE_ITEM_WHOLE = 16;               // j of an uncut ray (its hits are filed under j = 0)
+constexpr uint32_t WIDE_BSUM_MAX = 128;                // 64-ray blocks per workgroup up to which the walk keeps the scan's block sums
 constexpr size_t WIDE_ITEM_MAX_RAYS = (size_t)1 << 27;
 
 template <typename T> struct WideRegs { T mn[3][4], mx[3][4]; uint32_t ref[4]; };
@@ -718,7 +719,7 @@ template <typename T> struct WideIo {
     }
     // LDS copy: node-major, CHUNKS x 16 bytes per slot, so the chunk offsets are immediates of the ds_read_b128s
     static __device__ __forceinline__ WideRegs<T> from_lds(const uint4* nodes, uint32_t slot) {
-        const uint4* q = nodes + (size_t)slot * CHUNKS;
+        const uint4* q = nodes + __umul24(slot, (uint32_t)CHUNKS);   // (24-bit multiply: full rate, v_mul_lo_u32 is quarter rate)
         uint4 c[CHUNKS];
 #pragma unroll
         for (int j = 0; j < CHUNKS; j++) c[j] = q[j];
@@ -849,6 +850,11 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     const uint32_t per_wg = ((n_blocks + gridDim.x - 1u) / gridDim.x) << 6;   // capacity of a workgroup's share (host: the same formula)
     const uint32_t my_rays = my_blocks << 6;                                   // local ray numbers [0, my_rays), some beyond n_rays in the last block
     auto ray_of = [&](uint32_t local) -> uint32_t { return (((local >> 6) * gridDim.x + blockIdx.x) << 6) | (local & 63u); };
+    // hits per 64-ray block of this workgroup (local block numbers): retiring items add to them, the workgroup stores them at
+    // the end — the CSR scan then needs no reduce pass over the counts.  (LDS atomics: adding straight into global sums put
+    // the BASELINE stream's 10 000 hits on one cache line, 128 → 162 µs.)
+    __shared__ uint32_t s_bsum[WIDE_BSUM_MAX];
+    if (w.bsum64) for (uint32_t b = tid; b < WIDE_BSUM_MAX; b += bd) s_bsum[b] = 0u;
     if (tid == 0) { s_next = 0u; s_nlist = 0u; }
     for (uint32_t q = tid; q < K; q += bd) {
         const uint32_t node = wslot_node[q];
@@ -925,7 +931,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     bool ovf = false;
     PoolCursor pc;
     auto push_slow = [&](uint32_t v) {
-        if (sp < stack_lds) s_stack[sp * bd + tid] = v;
+        if (sp < stack_lds) s_stack[__umul24(sp, bd) + tid] = v;
         else if (sp - stack_lds < gstack_cap) gstack[(size_t)(sp - stack_lds) * G + gid] = v;
         else ovf = true;
         sp++;
@@ -933,7 +939,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     auto pop_or_none = [&]() -> uint32_t {
         if (sp == 0) return CUR_NONE;
         sp--;
-        if (sp < stack_lds) return s_stack[sp * bd + tid];
+        if (sp < stack_lds) return s_stack[__umul24(sp, bd) + tid];
         return sp - stack_lds < gstack_cap ? gstack[(size_t)(sp - stack_lds) * G + gid] : CUR_NONE;
     };
     while (true) {
@@ -958,7 +964,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                         atomicOr(&w.ray_items[r], 1u << jj);
                         w.item_cnt[((size_t)r << (2 * ITEMS_LOG4)) + jj] = ray.cnt;
                     }
-                    if (w.blocksums) atomicAdd(&w.blocksums[r / SCAN_BLOCK], (unsigned long long)ray.cnt);   // saves the reduce pass of the scan
+                    if (w.bsum64) atomicAdd(&s_bsum[((r >> 6) - blockIdx.x) / gridDim.x], ray.cnt);
                 }
                 item = NONE;
             }
@@ -1009,7 +1015,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                 const uint32_t s0 = (rest & 8u) ? nd.ref[3] : ((rest & 4u) ? nd.ref[2] : nd.ref[1]);
                 const uint32_t s1 = ((rest & 12u) == 12u) ? nd.ref[2] : nd.ref[1];
                 if (sp + 3u <= stack_lds) {   // room for three: store them all, count what is real
-                    uint32_t* at = s_stack + sp * bd + tid;
+                    uint32_t* at = s_stack + __umul24(sp, bd) + tid;
                     at[0] = s0; at[bd] = s1; at[2 * bd] = nd.ref[1];
                     sp += (uint32_t)__popc(rest);
                 } else {
@@ -1028,6 +1034,10 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     }
     if (__any(ovf) && lane == 0) atomicOr(overflow, 4u);
     walk_epilogue<T, MODE>(w, pc, lane, false, 0, 0, 0, 0);
+    if (MODE != MODE_CLOSEST && w.bsum64) {   // every wave of the workgroup gets here: all items of its rays have retired
+        __syncthreads();
+        for (uint32_t b = tid; b < my_blocks; b += bd) w.bsum64[b * gridDim.x + blockIdx.x] = s_bsum[b];
+    }
 #ifdef BVH_WIDE_PROFILE
     if (lane == 0) {
         const size_t wv = gid >> 6;
@@ -1096,7 +1106,8 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__
                                                     const unsigned long long* __restrict__ blocksums,
                                                     unsigned long long* __restrict__ total,
                                                     uint32_t* __restrict__ offsets, uint32_t* __restrict__ ray_items,
-                                                    uint16_t* __restrict__ ray_mask) {
+                                                    uint16_t* __restrict__ ray_mask, unsigned long long* __restrict__ host_page,
+                                                    unsigned long long* __restrict__ other_ctr, const uint32_t* __restrict__ bsum64) {
     __shared__ uint32_t ws[4];
     __shared__ unsigned long long wb[4];
     const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
@@ -1106,7 +1117,15 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__
         before = blocksums[blockIdx.x];
     } else {
         unsigned long long part = 0;
-        for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256) part += blocksums[j];
+        if (bsum64) {   // the walk left one sum per 64 rays: SCAN_BLOCK / 64 of them (one 64-byte line) per scan block
+            const uint4* q = reinterpret_cast<const uint4*>(bsum64);
+            for (uint32_t j = threadIdx.x; j < blockIdx.x * (SCAN_BLOCK / 256u); j += 256) {
+                const uint4 v4 = q[j];
+                part += (unsigned long long)v4.x + v4.y + v4.z + v4.w;
+            }
+        } else {
+            for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256) part += blocksums[j];
+        }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) part += __shfl_down(part, d);
         if (lane == 0) wb[threadIdx.x >> 6] = part;
@@ -1147,6 +1166,15 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__
         const unsigned long long t = before + ws[0] + ws[1] + ws[2] + ws[3];
         offsets[n] = (uint32_t)t;
         *total = t;
+        // With the total every counter of the batch is final (the scatter only reads them): they go to the result's pinned
+        // host page from here, and the OTHER counter set — the previous batch's, whose scatter is long done — is zeroed for
+        // the next batch.  k_publish_counters as a launch of its own cost 3.8 µs per batch.  (total = ctr[3] of this set.)
+        if (host_page) {
+            const unsigned long long* ctr = total - 3;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { host_page[k] = k == 3 ? t : ctr[k]; other_ctr[k] = 0ull; }
+            __threadfence_system();
+        }
     }
 }
 
@@ -1205,13 +1233,11 @@ __global__ __launch_bounds__(256) void k_hits_scatter_wide(const HitRec* __restr
 
 // The 8 walk / scan counters go to the context's pinned host page and are zeroed for the next call: one 64-thread
 // launch instead of the runtime's copy kernel plus its fill kernel (≈4.5 µs each on the stream).
-__global__ void k_publish_counters(unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ host_page,
-                                   unsigned long long* __restrict__ blocksums, uint32_t nb) {
+__global__ void k_publish_counters(unsigned long long* __restrict__ ctr, unsigned long long* __restrict__ host_page) {
     if (threadIdx.x < 8) {
         host_page[threadIdx.x] = ctr[threadIdx.x];
         ctr[threadIdx.x] = 0;
     }
-    for (uint32_t i = threadIdx.x; i < nb; i += 64u) blocksums[i] = 0ull;   // the wide walk adds into them: zero again for the next batch
     __threadfence_system();
 }
 
@@ -1270,7 +1296,8 @@ template <typename T> struct WideGeom {
         wg_per_cu = (uint32_t)std::max(1, std::min(ctx->tune[BVHGPU_TUNE_WIDE_WG_PER_CU] > 0 ? ctx->tune[BVHGPU_TUNE_WIDE_WG_PER_CU] : 2,
                                                    (int)(2048 / threads)));
         stack_lds = (uint32_t)std::max(0, std::min(ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] >= 0 ? ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] : 6, 32));   // 4 / 6 / 8 / 10 / 12 measured: 6
-        const size_t budget = (size_t)(160 * 1024) / wg_per_cu - 1024;   // 1 KB for the kernel's static LDS (item table)
+        // static LDS of the kernel: item table (448 / 832 bytes) + block sums (512 bytes)
+        const size_t budget = (size_t)(160 * 1024) / wg_per_cu - (f64 ? 1536 : 1024);
         const size_t fixed = 80 + (size_t)stack_lds * threads * 4;
         const size_t per_slot = (size_t)WideIo<T>::CHUNKS * 16;
         size_t k = budget > fixed + per_slot ? (budget - fixed) / per_slot : 1;
@@ -1349,14 +1376,16 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     h->ctx = ctx; h->dtype = Traits<T>::dtype; h->n_rays = n_rays; h->flags = flags; h->total = 0;
     h->stats = bvhgpu_traverse_stats{0, 0, 0, 0, 0};
     h->pend_tree = t; h->pend_rays = rays_dev; h->pend_wide = use_wide; h->pend_unfolded = t->unfolded || t->n == 1;
-    if (h->ctr.reserve(8 * sizeof(unsigned long long))) h->ctr_clean = false;
+    // two counter sets: a batch uses one and (k_scan_final) zeroes the other for the batch after it
+    if (h->ctr.reserve(16 * sizeof(unsigned long long))) h->ctr_clean = false;
     if (!h->pin) BVH_HIP(hipHostMalloc(&h->pin, 64, hipHostMallocDefault));
     unsigned long long* pin = reinterpret_cast<unsigned long long*>(h->pin);
-    unsigned long long* ctr = h->ctr.as<unsigned long long>();
+    unsigned long long* ctr = h->ctr.as<unsigned long long>() + 8 * (h->ctr_set & 1);
+    unsigned long long* ctr_other = h->ctr.as<unsigned long long>() + 8 * ((h->ctr_set & 1) ^ 1);
 
     WalkOut<T> w;
     w.counts = nullptr; w.pool = nullptr; w.pool_v = nullptr; w.pool_cap = 0; w.ctr = ctr;
-    w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr; w.item_cnt = nullptr; w.ray_items = nullptr; w.blocksums = nullptr;
+    w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr; w.item_cnt = nullptr; w.ray_items = nullptr; w.bsum64 = nullptr;
 
     uint32_t* ovf_flag = reinterpret_cast<uint32_t*>(ctr + 7);   // bit 0 ordered-iterator stack, bit 1 heap workspace, bit 2 wide-walk stack
     const bool best_first = ordered && (flags & BVHGPU_TRAVERSE_BEST_FIRST) != 0;
@@ -1418,7 +1447,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         }                                                                                            \
     } while (0)
 
-    if (!h->ctr_clean) BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));
+    if (!h->ctr_clean) BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));   // (only this batch's set has to be clean)
     h->ctr_clean = false;
     if (mode == MODE_CLOSEST) {   // no CSR: one Intersection + shape per ray
         h->closest.reserve(std::max<size_t>(n_rays, 1) * 3 * sizeof(T));
@@ -1428,7 +1457,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
         DISPATCH_WALK();
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
-        hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin, (unsigned long long*)nullptr, 0u);   // readback + reset for the next call
+        hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);   // readback + reset for the next call
         h->ctr_clean = true;
         return;
     }
@@ -1462,9 +1491,17 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
             w.ray_items = h->ray_items.as<uint32_t>();
         }
         counts = h->wcounts.as<uint32_t>();
-        // (Summing the hits per scan block in the walk — one atomic per retiring item — to save k_scan_reduce was tried: the
-        //  BASELINE stream's 10 000 hits all fall into the first five blocks, i.e. onto ONE cache line, which takes ≈ 88 atomics
-        //  per µs: the walk went from 128 to 162 µs.  WalkOut::blocksums stays NULL.)
+        // the walk's workgroups leave the hits per 64-ray block (their own blocks: LDS sums): no reduce pass for the scan
+        {
+            const WideGeom<T> g(ctx);
+            const size_t full = (n_rays + g.threads - 1) / g.threads;
+            const size_t grid = std::min<size_t>(std::max<size_t>(full, 1), (size_t)ctx->n_cu * g.wg_per_cu);   // launch_wide: the same
+            const size_t n_blocks = (n_rays + 63) / 64;
+            if (nb <= SCAN_FUSED_MAX_BLOCKS && (n_blocks + grid - 1) / grid <= WIDE_BSUM_MAX) {
+                h->bsum64.reserve((n_blocks + 16) * 4);
+                w.bsum64 = h->bsum64.as<uint32_t>();
+            }
+        }
     } else {
         h->counts.reserve((n_items + 1) * 4);
         counts = h->counts.as<uint32_t>();
@@ -1481,12 +1518,14 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     const int kind = use_wide ? COUNT_MASKED : (split_at ? COUNT_PAIR : COUNT_PLAIN);
     auto scan = [&](auto kind_tag) {
         constexpr int KD = decltype(kind_tag)::value;
-        if (!w.blocksums) hipLaunchKernelGGL(k_scan_reduce<KD>, dim3(nb), dim3(256), 0, st, counts, nr, bs);
+        if (!w.bsum64) hipLaunchKernelGGL(k_scan_reduce<KD>, dim3(nb), dim3(256), 0, st, counts, nr, bs);
         if (nb > SCAN_FUSED_MAX_BLOCKS) {
             hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, bs, nb, ctr + 3);
-            hipLaunchKernelGGL((k_scan_final<KD, true>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, ritems, rmask);
+            hipLaunchKernelGGL((k_scan_final<KD, true>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, ritems, rmask,
+                               (unsigned long long*)nullptr, (unsigned long long*)nullptr, (const uint32_t*)nullptr);
         } else {
-            hipLaunchKernelGGL((k_scan_final<KD, false>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, ritems, rmask);
+            hipLaunchKernelGGL((k_scan_final<KD, false>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, ritems, rmask, pin, ctr_other,
+                               (const uint32_t*)w.bsum64);
         }
     };
     if (kind == COUNT_MASKED) scan(std::integral_constant<int, COUNT_MASKED>{});
@@ -1511,8 +1550,11 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         hipLaunchKernelGGL((k_hits_scatter<T, 0>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, pair_counts, indices, vals);
     }
     if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
-    hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin, w.blocksums, w.blocksums ? nb : 0u);   // readback + reset for the next call
-    h->bs_clean = w.blocksums != nullptr;   // (k_scan_reduce / k_scan_sums leave their own values behind)
+    if (nb > SCAN_FUSED_MAX_BLOCKS) {   // readback + reset for the next call (smaller batches: k_scan_final's last block did both)
+        hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);
+    } else {
+        h->ctr_set ^= 1;   // the set that was just zeroed
+    }
     h->ctr_clean = true;
 #undef DISPATCH_WALK
 }
