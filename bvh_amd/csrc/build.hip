@@ -77,7 +77,25 @@ template <typename T> struct ItemStats {
     uint32_t _pad[2];
 };
 
+// Addressing of the level tier when a level is ONE launch (k_level): nothing a workgroup needs during the launch may come out
+// of an atomic another workgroup of the same launch executes, so queue slots and tile numbers are ARITHMETIC:
+//   item slot  = start / slot_div          slot_div = mid_max + 1: two items of a level are disjoint slices of more than
+//                                          mid_max positions each, so their slots differ
+//   tile id    = start / TILE + slot + k   k-th tile of the item; strictly increasing over a level's items (the slot term
+//                                          separates the last tile of an item from the first of the next)
+// and the arrays a level accumulates into (statistics, per-tile bucket counts, tile → item map) rotate over three buffers:
+// level L reads the parents' [(L-1) % 3], accumulates into [L % 3] and resets [(L+1) % 3] for the launch after it.
+template <typename T> struct LevelArgs {
+    Item<T>* item[2];        // [L & 1][slot]
+    uint4* tile_map[3];      // [L % 3][tile id] = {item slot (NONE: no such tile at this level), start, count, 0}
+    ItemStats<T>* stats[3];  // [L % 3][slot * STAT_REP + replica]
+    uint32_t* tile_cnt[3];   // [L % 3][tile id * NUM_BUCKETS + bucket]
+    uint8_t* bk[2];          // [L & 1][position]: bucket of the shape at that position
+    uint32_t slot_div, n_slots, n_tiles;
+};
+
 template <typename T> struct BuildArgs {
+    LevelArgs<T> lv;
     uint32_t mid_max;        // nodes with at most this many shapes (and more than 64) go to the workgroup tier
     const T* aabbs;          // the tree's own copy (what every later kernel gathers from)
     const T* src;            // the caller's array: k_prep copies it into `aabbs` while it reduces the bounds
@@ -111,6 +129,7 @@ __device__ __forceinline__ bool key_is_min(int j) { return j < 3 || (j >= 6 && j
 template <typename T>
 __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, uint32_t parent, uint32_t start,
                           uint32_t count, const T* A, const T* C, uint32_t heap, int lane);
+template <typename T> __device__ void init_stats(ItemStats<T>* s, int lane);
 
 template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T> a) {
     using Tr = Traits<T>;
@@ -121,6 +140,12 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T>
     T loc[STAT_KEYS];   // joined on floats (one v_min/v_max each); keys only for the atomics that merge waves
 #pragma unroll
     for (int j = 0; j < STAT_KEYS; j++) loc[j] = key_is_min(j) ? Tr::inf() : -Tr::inf();
+    if (a.lv.tile_map[0]) {   // level tier, one launch per level: tile maps and tile counts of all three rotating buffers
+        const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x, gs = gridDim.x * blockDim.x;
+        for (uint32_t i = gt; i < 3u * a.lv.n_tiles; i += gs) a.lv.tile_map[i / a.lv.n_tiles][i % a.lv.n_tiles] = make_uint4(NONE, 0u, 0u, 0u);
+        const uint32_t nc = a.lv.n_tiles * (uint32_t)NUM_BUCKETS;
+        for (uint32_t i = gt; i < 3u * nc; i += gs) a.lv.tile_cnt[i / nc][i % nc] = 0u;
+    }
     if (blockIdx.x == 0) {   // the LDS slot tables of the previous tree (filled again by flatten)
         for (uint32_t i = threadIdx.x; i < a.n_slots; i += blockDim.x) a.slot_entry[i] = NONE;
         for (uint32_t i = threadIdx.x; i < WIDE_SLOTS; i += blockDim.x) a.wslot_node[i] = NONE;
@@ -177,7 +202,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T>
 }
 
 // joint_aabb_of_shapes finished (bvh_impl.rs:74) → the root work item (BvhNodeBuildArgs, bvh_impl.rs:75-87).  One workgroup.
-template <typename T> __global__ __launch_bounds__(256) void k_root(BuildArgs<T> a, uint32_t prep_wgs) {
+template <typename T> __global__ __launch_bounds__(256) void k_root(BuildArgs<T> a, uint32_t prep_wgs, int fused) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
     __shared__ Key sk[STAT_KEYS];
@@ -202,7 +227,21 @@ template <typename T> __global__ __launch_bounds__(256) void k_root(BuildArgs<T>
             if (ovf) { flags |= BUILD_FLAG_NONFINITE; if (threadIdx.x == 0) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_NONFINITE); }
         }
         // invalid input: no root item, so every later kernel of the optimistic schedule finds empty queues
-        if (!(flags & BUILD_FLAG_NONFINITE)) push_item<T>(a, 0, 0u, 0u, 0u, a.n, A, C, 1u, (int)threadIdx.x);
+        if (flags & BUILD_FLAG_NONFINITE) return;
+        if (fused && a.n > a.mid_max) {   // level tier, one launch per level: the root is item 0 of level 0, its tiles are 0 .. ntile-1
+            const int lane = (int)threadIdx.x;
+            Item<T>* it = &a.lv.item[0][0];
+            if (lane == 0) {
+                it->ni = 0; it->parent = 0; it->start = 0; it->count = a.n; it->tile_base = 0; it->parity = 0; it->heap = 1u; it->_r1 = 0;
+                a.ctr[CTR_LEVEL0] = 1u;
+            }
+            if (lane < 6) { it->A[lane] = A[lane]; it->C[lane] = C[lane]; }
+            const uint32_t ntile = (a.n + TILE - 1) / TILE;
+            for (uint32_t j = lane; j < ntile; j += WAVE) a.lv.tile_map[0][j] = make_uint4(0u, 0u, a.n, 0u);
+            for (int r = 0; r < STAT_REP; r++) init_stats<T>(&a.lv.stats[0][r], lane);
+        } else {
+            push_item<T>(a, 0, 0u, 0u, 0u, a.n, A, C, 1u, (int)threadIdx.x);
+        }
     }
 }
 
@@ -637,6 +676,513 @@ template <typename T> __global__ __launch_bounds__(256) void k_split(BuildArgs<T
     if (blockIdx.x < sel_blocks) select_role<T>(a, level, blockIdx.x, sel_blocks);
     else scatter_role<T>(a, level, blockIdx.x - sel_blocks, gridDim.x - sel_blocks);
 }
+
+// ------------------------------------------------------------------------------------------------
+// tier 1 in ONE launch per level.  k_level(L) is scatter(L-1) and bin(L) of the two-launch schedule above, fused, with the
+// selection of level L-1 recomputed by every workgroup that needs it:
+//   a workgroup owns one tile of a level-(L-1) item P.  Wave 0 merges P's statistic replicas and runs the SAH selection
+//   (bvh_node.rs:224-247) — every tile of P does, redundantly: the alternative is a launch boundary (≈2.5 µs + the chain of
+//   the selection's own round trips) per level.  The other waves meanwhile add up the bucket counts of P's earlier tiles.
+//   Then every shape of the tile moves to its place in the stable bucket-major order (:250-272) and — if the child it lands
+//   in stays in this tier — is binned for the NEXT split right away: bucket id against the child's centroid bounds
+//   (:204-217), 6 x (count, AABB, centroid AABB) per child in LDS (key atomics, 16 replicas), merged into the child's
+//   statistics with global atomics; the bucket counts per child tile likewise.  The child's statistics slot and tile numbers
+//   are arithmetic (LevelArgs), so no workgroup waits for another.  The workgroup of P's tile 0 also writes P's BvhNode and
+//   the children's work items (level tier: LevelArgs arrays; workgroup / wave tier: their queues, as before).
+// ROOT: level 0 has no parent — the root item (k_root) is binned in place.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct LevelSel {
+    uint32_t nl, no_winner;
+    T AL[6], CL[6], AR[6], CR[6];
+};
+// sah_select by ONE WAVE with the work spread over its lanes (the serial form above is ~1 400 instructions on the critical
+// path of a level; this is ~200): lanes (b, k) build the running prefix / suffix joins of the AABB keys, lanes 0..4 price the
+// five candidate splits — each with exactly the operations of bvh_node.rs:231-238 —, every lane then replays the strict-<
+// first-wins scan over the five costs (:239-247), lanes 0..5 assemble the children's bounds.  st, out, scratch: LDS.
+template <typename T>
+__device__ __forceinline__ void sah_select_wave(const ItemStats<T>* st, const T* A, bool degen, LevelSel<T>* out,
+                                                typename Traits<T>::Key* scratch /* 72 keys */, int lane) {
+    using Tr = Traits<T>;
+    using Key = typename Tr::Key;
+    if (lane < 36) {
+        const int b = lane / 6, k = lane % 6;
+        const bool mn = k < 3;
+        Key p = st->k[k];
+#pragma unroll
+        for (int bb = 1; bb < NUM_BUCKETS; bb++) {
+            const Key x = st->k[bb * STAT_KEYS + k];
+            const Key j = mn ? (x < p ? x : p) : (x > p ? x : p);
+            p = bb <= b ? j : p;
+        }
+        Key q = st->k[(NUM_BUCKETS - 1) * STAT_KEYS + k];
+#pragma unroll
+        for (int bb = NUM_BUCKETS - 2; bb >= 0; bb--) {
+            const Key x = st->k[bb * STAT_KEYS + k];
+            const Key j = mn ? (x < q ? x : q) : (x > q ? x : q);
+            q = bb >= b ? j : q;
+        }
+        scratch[b * 6 + k] = p;          // join of buckets 0..b
+        scratch[36 + b * 6 + k] = q;     // join of buckets b..5
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t cnt[NUM_BUCKETS], total = 0;
+#pragma unroll
+    for (int b = 0; b < NUM_BUCKETS; b++) { cnt[b] = st->cnt[b]; total += cnt[b]; }
+    T cost = Tr::inf();
+    if (lane < NUM_BUCKETS - 1) {
+        const int sp = lane;
+        uint32_t ln = 0;
+#pragma unroll
+        for (int b = 0; b < NUM_BUCKETS - 1; b++) ln += b <= sp ? cnt[b] : 0u;
+        T la[6], ra[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { la[k] = Tr::unkey(scratch[sp * 6 + k]); ra[k] = Tr::unkey(scratch[36 + (sp + 1) * 6 + k]); }
+        const T sa_parent = surface_area(A);
+        const T cl = (T)ln * surface_area(la);
+        const T cr = (T)(total - ln) * surface_area(ra);
+        const T num = cl + cr;
+        cost = num / sa_parent;                                  // :236-238
+    }
+    T min_cost = Tr::inf();
+    int best = -1;   // no winner (NaN/inf costs): the reference keeps min_bucket = 0 and EMPTY child bounds (:225-230)
+#pragma unroll
+    for (int sp = 0; sp < NUM_BUCKETS - 1; sp++) {
+        const T c = __shfl(cost, sp);
+        const bool take = degen ? (sp == 0) : (c < min_cost);   // strict <, first wins (:239)
+        if (take) { min_cost = c; best = sp; }
+    }
+    uint32_t nl = 0;
+#pragma unroll
+    for (int b = 0; b < NUM_BUCKETS; b++) nl += (best < 0 ? b == 0 : b <= best) ? cnt[b] : 0u;
+    if (lane < 6) {
+        const int k = lane;
+        const bool mn = k < 3;
+        T al, ar, cl, cr;
+        if (best < 0) {
+            al = ar = cl = cr = mn ? Tr::inf() : -Tr::inf();
+        } else {
+            Key kl = mn ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF, kr = kl;
+#pragma unroll
+            for (int b = 0; b < NUM_BUCKETS; b++) {
+                const Key x = st->k[b * STAT_KEYS + 6 + k];
+                const Key jl = mn ? (x < kl ? x : kl) : (x > kl ? x : kl);
+                const Key jr = mn ? (x < kr ? x : kr) : (x > kr ? x : kr);
+                kl = b <= best ? jl : kl;
+                kr = b <= best ? kr : jr;
+            }
+            al = Tr::unkey(scratch[best * 6 + k]);
+            ar = Tr::unkey(scratch[36 + (best + 1) * 6 + k]);
+            cl = Tr::unkey(kl); cr = Tr::unkey(kr);
+        }
+        out->AL[k] = al; out->AR[k] = ar; out->CL[k] = cl; out->CR[k] = cr;
+    }
+    if (lane == 0) { out->nl = nl; out->no_winner = best < 0 ? 1u : 0u; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename T> struct LevelChild {
+    uint32_t start, count, kind, slot, tile0, ax, degen, half;   // kind: 3 level tier, 1 workgroup tier, 0 wave tier
+    T cmin, ext;
+};
+constexpr int LEVEL_TGT = 4;   // child tiles the shapes of ONE (parent tile, bucket) can land in: a run of <= TILE positions
+                               // touches <= 2 tiles of a child, and it may straddle the boundary between the two children
+
+template <typename T> __device__ __forceinline__ void level_child_derive(LevelChild<T>* c, const T* C, uint32_t start, uint32_t count,
+                                                                          uint32_t mid_max, uint32_t slot_div) {
+    c->start = start; c->count = count;
+    c->kind = count <= (uint32_t)SMALL_MAX ? 0u : (count <= mid_max ? 1u : 3u);
+    c->slot = start / slot_div;
+    c->tile0 = start / (uint32_t)TILE + c->slot;
+    const int ax = largest_axis(C);                     // bvh_node.rs:107
+    c->ax = (uint32_t)ax;
+    c->cmin = C[ax];
+    c->ext = C[3 + ax] - C[ax];                         // :108
+    c->degen = (c->ext < Traits<T>::eps()) ? 1u : 0u;   // :114
+    c->half = count / 2;                                // :117
+}
+
+#ifdef BVH_LEVEL_PROFILE   // developer build: wall-clock stamps (100 MHz) of k_level's phases at level BVH_LEVEL_PROFILE, per workgroup
+__device__ unsigned long long g_level_prof[8 * 1024];
+#define LEVEL_STAMP(i) do { if (L == BVH_LEVEL_PROFILE && threadIdx.x == 0 && blockIdx.x < 1024) g_level_prof[8 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+#else
+#define LEVEL_STAMP(i) do { } while (0)
+#endif
+// sum of a u32 over the wave, valid in every lane: 4 DPP row_shr steps (zero for lanes without a source) leave each row's
+// sum in its last lane; the four row sums are read by lane number
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    return (uint32_t)(__builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31) + __builtin_amdgcn_readlane(v, 47) +
+                      __builtin_amdgcn_readlane(v, 63));
+}
+constexpr int LEVEL_TC_REP = 4;   // LDS replicas of the per-(bucket, target tile) counts
+constexpr int LEVEL_PT = TILE / 256;   // shapes per thread
+
+#ifndef BVH_LEVEL_THREADS
+#define BVH_LEVEL_THREADS 256
+#endif
+// 256: wave 0 runs the selection and then carries shapes like the other three.  320: wave 0 ONLY selects (and writes the node /
+// the children's items), four more waves carry the shapes — measured slower (build 0.204 → 0.226 ms at 120 k): five-wave
+// workgroups start up to 4 µs apart.
+constexpr int LEVEL_THREADS = BVH_LEVEL_THREADS;
+constexpr bool LEVEL_DEDICATED = LEVEL_THREADS > 256;
+template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) void k_level(BuildArgs<T> a, int L) {
+    using Tr = Traits<T>;
+    using Key = typename Tr::Key;
+    static_assert(TILE % 256 == 0 && LEVEL_PT >= 1 && LEVEL_PT <= 4, "a tile is a whole number of 256-thread rounds");
+    const LevelArgs<T>& v = a.lv;
+    const int bP = (L + 2) % 3, bC = L % 3, bN = (L + 1) % 3;
+    const uint32_t* src = ROOT ? a.idx[0] : a.idx[(L + 1) & 1];   // the parents' order (level L-1; the root's slice is where k_prep wrote it)
+    uint32_t* dst = a.idx[L & 1];                                   // the children's
+    const uint8_t* bk_src = v.bk[(L + 1) & 1];
+    uint8_t* bk_dst = v.bk[L & 1];
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+    const bool shaper = !LEVEL_DEDICATED || w > 0;                            // this thread carries shapes
+    const int sw = LEVEL_DEDICATED ? w - 1 : w;                               // its wave among the shape waves
+    const uint32_t stid = LEVEL_DEDICATED ? threadIdx.x - 64u : threadIdx.x;   // its number among the 256 shape threads
+    const unsigned long long lt = lanemask_lt();
+    LEVEL_STAMP(0);
+    // (the first tile's record is requested before the housekeeping stores: its round trip hides behind them)
+    uint4 tm_first = make_uint4(NONE, 0u, 0u, 0u);
+    if (blockIdx.x < v.n_tiles) tm_first = v.tile_map[ROOT ? bC : bP][blockIdx.x];
+
+    // ---- reset what the NEXT level accumulates into
+    {
+        const uint32_t gt = blockIdx.x * (uint32_t)LEVEL_THREADS + threadIdx.x, gs = gridDim.x * (uint32_t)LEVEL_THREADS;
+        for (uint32_t i = gt; i < v.n_tiles; i += gs) v.tile_map[bN][i] = make_uint4(NONE, 0u, 0u, 0u);
+        for (uint32_t i = gt; i < v.n_tiles * (uint32_t)NUM_BUCKETS; i += gs) v.tile_cnt[bN][i] = 0u;
+        constexpr uint32_t NK = NUM_BUCKETS * STAT_KEYS;
+        const uint32_t ns = v.n_slots * (uint32_t)STAT_REP;
+        for (uint32_t i = gt; i < ns * NK; i += gs) {
+            const uint32_t e = i / NK, j = i % NK;
+            v.stats[bN][e].k[j] = key_is_min((int)(j % STAT_KEYS)) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
+        }
+        for (uint32_t i = gt; i < ns * (uint32_t)NUM_BUCKETS; i += gs) v.stats[bN][i / NUM_BUCKETS].cnt[i % NUM_BUCKETS] = 0u;
+    }
+
+    __shared__ Key sk[2][BIN_REP][NUM_BUCKETS * STAT_KEYS];
+    __shared__ uint32_t sc[2][BIN_REP][NUM_BUCKETS];
+    __shared__ uint32_t tcnt[LEVEL_TC_REP][NUM_BUCKETS][LEVEL_TGT][NUM_BUCKETS];   // [replica][bucket at L-1][target tile][bucket at L]
+    __shared__ uint32_t run0[NUM_BUCKETS], wsum[4][NUM_BUCKETS], wcnt[4][LEVEL_PT][NUM_BUCKETS];
+    __shared__ LevelChild<T> ch[2];
+    __shared__ LevelSel<T> sel;
+    __shared__ ItemStats<T> s_merged;
+    __shared__ Key s_sah[72];
+    const int rp = (int)(stid & (BIN_REP - 1)), rt = (int)(stid & (LEVEL_TC_REP - 1));
+
+    for (uint32_t g = blockIdx.x; g < v.n_tiles; g += gridDim.x) {
+        // one load tells the tile's workgroup all it needs to start: the item's slot (statistics, record), slice and size
+        const uint4 tm = g == blockIdx.x ? tm_first : v.tile_map[ROOT ? bC : bP][g];
+        const uint32_t slotP = tm.x;
+        if (slotP == NONE) continue;   // workgroup-uniform
+        LEVEL_STAMP(1);
+        const uint32_t start = tm.y, count = tm.z;
+        const Item<T>* P = &v.item[ROOT ? 0 : ((L + 1) & 1)][slotP];
+        const uint32_t tile0P = start / (uint32_t)TILE + slotP;
+        const uint32_t tl = g - tile0P, ntl = (count + TILE - 1) / TILE;
+        const uint32_t p0 = start + tl * TILE;
+        const uint32_t pend = min(start + count, p0 + (uint32_t)TILE);
+
+        // ---- wave 0 starts with what the selection waits for (P's statistic replicas: lane j owns keys j, j + 64; P's bounds):
+        // memory returns in order, so these must be in flight before anything else this wave asks for
+        Key rk[2][STAT_REP];
+        uint32_t rc[STAT_REP];
+        T PA[6], PC[6];
+        if (!ROOT && w == 0) {
+            const ItemStats<T>* rep = &v.stats[bP][(size_t)slotP * STAT_REP];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int j = lane + 64 * h;
+#pragma unroll
+                for (int r = 0; r < STAT_REP; r++) rk[h][r] = j < NUM_BUCKETS * STAT_KEYS ? rep[r].k[j] : (Key)0;
+            }
+#pragma unroll
+            for (int r = 0; r < STAT_REP; r++) rc[r] = lane < NUM_BUCKETS ? rep[r].cnt[lane] : 0u;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { PA[k] = P->A[k]; PC[k] = P->C[k]; }
+        }
+        // ---- loads that depend on the tile only: the shapes' indices and buckets at L-1 ...
+        uint32_t sh[LEVEL_PT];
+        int bo[LEVEL_PT];
+        T bx[LEVEL_PT][6];
+#pragma unroll
+        for (int u = 0; u < LEVEL_PT; u++) {
+            const uint32_t p = p0 + (uint32_t)u * 256u + stid;
+            const bool valid = shaper && p < pend;
+            sh[u] = valid ? src[p] : NONE;
+            bo[u] = !valid ? 7 : (ROOT ? 0 : (int)bk_src[p]);
+        }
+        // ... and the bucket counts of P's tiles (consumed further down) → offset of (this tile, bucket b) inside P's slice =
+        // shapes of P in buckets < b + shapes of bucket b in P's earlier tiles
+        constexpr int TCV = 2;   // tiles per thread held in registers before they are consumed (more are fetched in a loop)
+        uint32_t tcv[TCV][NUM_BUCKETS];
+        const uint32_t* tc = v.tile_cnt[bP] + (size_t)tile0P * NUM_BUCKETS;
+        if (!ROOT) {
+#pragma unroll
+            for (int i = 0; i < TCV; i++) {
+                const uint32_t j = stid + 256u * (uint32_t)i;
+#pragma unroll
+                for (int b = 0; b < NUM_BUCKETS; b++) tcv[i][b] = (shaper && j < ntl) ? tc[(size_t)j * NUM_BUCKETS + b] : 0u;
+            }
+        }
+        if (ROOT) {
+            if (threadIdx.x == 0) {
+                T C[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) C[k] = P->C[k];
+                level_child_derive<T>(&ch[0], C, start, count, a.mid_max, v.slot_div);
+                ch[1].start = start + count; ch[1].count = 0; ch[1].kind = 0; ch[1].slot = 0; ch[1].tile0 = 0;
+                sel.nl = count; sel.no_winner = 0;
+            }
+            if (threadIdx.x < NUM_BUCKETS) run0[threadIdx.x] = 0;
+        } else if (w == 0) {
+            // the selection of P (every tile's workgroup repeats it): replicas merged (joins are exact, counts are integers).
+            // Wave 0 does this FIRST — its other loads are in flight, everybody else waits for the outcome.
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int j = lane + 64 * h;
+                if (j < NUM_BUCKETS * STAT_KEYS) {
+                    const bool mn = key_is_min(j % STAT_KEYS);
+                    Key x = rk[h][0];
+#pragma unroll
+                    for (int r = 1; r < STAT_REP; r++) { const Key u = rk[h][r]; x = mn ? (u < x ? u : x) : (u > x ? u : x); }
+                    s_merged.k[j] = x;
+                }
+            }
+            if (lane < NUM_BUCKETS) {
+                uint32_t c = 0;
+#pragma unroll
+                for (int r = 0; r < STAT_REP; r++) c += rc[r];
+                s_merged.cnt[lane] = c;
+            }
+            const int ax = largest_axis(PC);
+            const bool degen = (PC[3 + ax] - PC[ax]) < Tr::eps();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            LEVEL_STAMP(7);
+            sah_select_wave<T>(&s_merged, PA, degen, &sel, s_sah, lane);
+#ifdef BVH_LEVEL_PROFILE
+            if (L == BVH_LEVEL_PROFILE && threadIdx.x == 0 && blockIdx.x < 1024) g_level_prof[8 * blockIdx.x + 3] = wall_clock64();   // (slot 3: selection done)
+#endif
+            if (lane < 2) {   // lane 0: left child, lane 1: right child
+                const uint32_t nl = sel.nl;
+                T CC[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) CC[k] = lane ? sel.CR[k] : sel.CL[k];
+                level_child_derive<T>(&ch[lane], CC, lane ? start + nl : start, lane ? count - nl : nl, a.mid_max, v.slot_div);
+            }
+        } else {
+            // the other waves prepare the LDS accumulators meanwhile
+            constexpr int NT3 = LEVEL_THREADS - 64;
+            const int t3 = (int)threadIdx.x - 64;
+            for (int j = t3; j < 2 * BIN_REP * NUM_BUCKETS * STAT_KEYS; j += NT3)
+                (&sk[0][0][0])[j] = key_is_min(j % STAT_KEYS) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
+            for (int j = t3; j < 2 * BIN_REP * NUM_BUCKETS; j += NT3) (&sc[0][0][0])[j] = 0u;
+            for (int j = t3; j < LEVEL_TC_REP * NUM_BUCKETS * LEVEL_TGT * NUM_BUCKETS; j += NT3) (&tcnt[0][0][0][0])[j] = 0u;
+        }
+        if (ROOT) {   // (no selection: every wave shares the preparation)
+            for (int j = threadIdx.x; j < 2 * BIN_REP * NUM_BUCKETS * STAT_KEYS; j += LEVEL_THREADS)
+                (&sk[0][0][0])[j] = key_is_min(j % STAT_KEYS) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
+            for (int j = threadIdx.x; j < 2 * BIN_REP * NUM_BUCKETS; j += LEVEL_THREADS) (&sc[0][0][0])[j] = 0u;
+            for (int j = threadIdx.x; j < LEVEL_TC_REP * NUM_BUCKETS * LEVEL_TGT * NUM_BUCKETS; j += LEVEL_THREADS) (&tcnt[0][0][0][0])[j] = 0u;
+        }
+        // the shapes' AABBs (their indices have arrived by now)
+#pragma unroll
+        for (int u = 0; u < LEVEL_PT; u++) {
+            if (sh[u] != NONE) {
+                const T* bp = a.aabbs + 6 * (size_t)sh[u];
+#pragma unroll
+                for (int k = 0; k < 6; k++) bx[u][k] = bp[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 6; k++) bx[u][k] = (T)0;
+            }
+        }
+        if (!ROOT && shaper) {
+            uint32_t before[NUM_BUCKETS], all[NUM_BUCKETS];
+#pragma unroll
+            for (int b = 0; b < NUM_BUCKETS; b++) { before[b] = 0; all[b] = 0; }
+#pragma unroll
+            for (int i = 0; i < TCV; i++) {
+                const uint32_t j = stid + 256u * (uint32_t)i;
+#pragma unroll
+                for (int b = 0; b < NUM_BUCKETS; b++) { all[b] += tcv[i][b]; before[b] += j < tl ? tcv[i][b] : 0u; }
+            }
+            for (uint32_t j = stid + 256u * TCV; j < ntl; j += 256) {   // (items of more than 512 tiles: huge scenes' top levels)
+#pragma unroll
+                for (int b = 0; b < NUM_BUCKETS; b++) {
+                    const uint32_t x = tc[(size_t)j * NUM_BUCKETS + b];
+                    all[b] += x;
+                    before[b] += j < tl ? x : 0u;
+                }
+            }
+            uint32_t acc = 0;
+#pragma unroll
+            for (int b = 0; b < NUM_BUCKETS; b++) {
+                const uint32_t mine = wave_sum_u32(acc + before[b]);
+                acc += all[b];
+                if (lane == 0) wsum[sw][b] = mine;
+            }
+        }
+        // ranks inside the tile: ballots per 256-shape round, counts per (wave, round, bucket) through LDS
+        uint32_t rank[LEVEL_PT];
+#pragma unroll
+        for (int u = 0; u < LEVEL_PT; u++) rank[u] = 0;
+        if (!ROOT && shaper) {
+#pragma unroll
+            for (int u = 0; u < LEVEL_PT; u++) {
+                rank[u] = 0;
+#pragma unroll
+                for (int bb = 0; bb < NUM_BUCKETS; bb++) {
+                    const unsigned long long m = __ballot(bo[u] == bb);
+                    if (bo[u] == bb) rank[u] = (uint32_t)__popcll(m & lt);
+                    if (lane == 0) wcnt[sw][u][bb] = (uint32_t)__popcll(m);
+                }
+            }
+        }
+        LEVEL_STAMP(2);
+        __syncthreads();
+        if (!ROOT && threadIdx.x < NUM_BUCKETS) run0[threadIdx.x] = wsum[0][threadIdx.x] + wsum[1][threadIdx.x] + wsum[2][threadIdx.x] + wsum[3][threadIdx.x];
+        if (!ROOT) __syncthreads();
+        const uint32_t nl = sel.nl;
+        // ---- the tile's shapes: stable bucket-major move (bvh_node.rs:250-272) + bucket / statistics for the next split
+#pragma unroll
+        for (int u = 0; u < LEVEL_PT; u++) {
+            if (sh[u] == NONE) continue;
+            const uint32_t p = p0 + (uint32_t)u * 256u + stid;
+            const int b = bo[u];
+            uint32_t off;
+            if (ROOT) {
+                off = p - start;
+            } else {
+                off = run0[b] + rank[u];
+                for (int uu = 0; uu < u; uu++) off += wcnt[0][uu][b] + wcnt[1][uu][b] + wcnt[2][uu][b] + wcnt[3][uu][b];   // earlier rounds
+                for (int ww = 0; ww < sw; ww++) off += wcnt[ww][u][b];                                                     // earlier waves of this round
+                dst[start + off] = sh[u];
+            }
+            const int side = off >= nl ? 1 : 0;
+            const LevelChild<T>& c = ch[side];
+            if (c.kind == 3u) {
+                T cen[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) cen[k] = center1(bx[u][k], bx[u][3 + k]);
+                const uint32_t q = start + off;
+                int nb;
+                if (c.degen) nb = (q - c.start) < c.half ? 0 : 1;          // halves in the child's order (:117)
+                else nb = bucket_of(cen[c.ax], c.cmin, c.ext);             // :210-217
+                bk_dst[q] = (uint8_t)nb;
+                Key* kk = &sk[side][rp][nb * STAT_KEYS];                   // Bucket::add_aabb (utils.rs:81-85)
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    atomicMin(&kk[k], Tr::key(bx[u][k]));
+                    atomicMax(&kk[3 + k], Tr::key(bx[u][3 + k]));
+                    const Key kc = Tr::key(cen[k]);
+                    atomicMin(&kk[6 + k], kc);
+                    atomicMax(&kk[9 + k], kc);
+                }
+                atomicAdd(&sc[side][rp][nb], 1u);
+                // which of the (at most LEVEL_TGT) child tiles this (parent tile, bucket) run reaches: relative to the run's first shape
+                const uint32_t off_first = ROOT ? (p0 - start) : run0[b];
+                const int side_first = off_first >= nl ? 1 : 0;
+                const uint32_t kt = (q - c.start) / (uint32_t)TILE;
+                const uint32_t kt_first = (start + off_first - ch[side_first].start) / (uint32_t)TILE;
+                const uint32_t tgt = side != side_first ? 2u + kt : kt - kt_first;
+                atomicAdd(&tcnt[rt][b][tgt][nb], 1u);
+            }
+        }
+        __syncthreads();
+        LEVEL_STAMP(4);
+        // ---- merge into the children's statistics (replica = this tile's number in P, like k_bin) and tile counts
+        for (int e = threadIdx.x; e < 2 * NUM_BUCKETS * STAT_KEYS; e += LEVEL_THREADS) {
+            const int side = e / (NUM_BUCKETS * STAT_KEYS), j = e % (NUM_BUCKETS * STAT_KEYS);
+            if (ch[side].kind != 3u) continue;
+            uint32_t cn = 0;
+#pragma unroll
+            for (int r = 0; r < BIN_REP; r++) cn += sc[side][r][j / STAT_KEYS];
+            if (!cn) continue;
+            Key x = sk[side][0][j];
+            const bool mn = key_is_min(j % STAT_KEYS);
+#pragma unroll
+            for (int r = 1; r < BIN_REP; r++) { const Key u = sk[side][r][j]; x = mn ? (u < x ? u : x) : (u > x ? u : x); }
+            ItemStats<T>* gs = &v.stats[bC][(size_t)ch[side].slot * STAT_REP + (tl & (STAT_REP - 1))];
+            if (mn) atomicMin(&gs->k[j], x);
+            else atomicMax(&gs->k[j], x);
+            if (j % STAT_KEYS == 0) atomicAdd(&gs->cnt[j / STAT_KEYS], cn);
+        }
+        for (int e = threadIdx.x; e < NUM_BUCKETS * LEVEL_TGT * NUM_BUCKETS; e += LEVEL_THREADS) {
+            const int b = e / (LEVEL_TGT * NUM_BUCKETS), tgt = (e / NUM_BUCKETS) % LEVEL_TGT, nb = e % NUM_BUCKETS;
+            uint32_t cn = 0;
+#pragma unroll
+            for (int r = 0; r < LEVEL_TC_REP; r++) cn += tcnt[r][b][tgt][nb];
+            if (!cn) continue;
+            const uint32_t off_first = ROOT ? (p0 - start) : run0[b];
+            const int side_first = off_first >= nl ? 1 : 0;
+            const int side = tgt >= 2 ? 1 : side_first;
+            const uint32_t kt_first = (start + off_first - ch[side_first].start) / (uint32_t)TILE;
+            const uint32_t kt = tgt >= 2 ? (uint32_t)tgt - 2u : kt_first + (uint32_t)tgt;
+            atomicAdd(&v.tile_cnt[bC][(size_t)(ch[side].tile0 + kt) * NUM_BUCKETS + nb], cn);
+        }
+        LEVEL_STAMP(5);
+        // ---- tile 0 of P: P's BvhNode (bvh_node.rs:145-151) and the children's work items
+        if (!ROOT && tl == 0 && w == 0) {
+            const uint32_t ni = P->ni, heap = P->heap;
+            const uint32_t li = ni + 1;                 // :140
+            const uint32_t ri = li + (2 * nl - 1);      // :138,142
+            if (sel.no_winner && lane == 0) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_EMPTY_SPLIT);
+            if (lane == 0) {
+                typename Tr::Node* nd = &a.nodes[ni];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    nd->l_min[k] = sel.AL[k]; nd->l_max[k] = sel.AL[3 + k];
+                    nd->r_min[k] = sel.AR[k]; nd->r_max[k] = sel.AR[3 + k];
+                }
+                nd->parent = P->parent; nd->l = li; nd->r = ri; nd->shape = NONE;
+                a.node_start[ni] = start;
+                a.node_count[ni] = count;
+                a.node_slot[ni] = (uint16_t)heap;
+            }
+            // queue slots of the children that leave this tier: lanes 0 / 1 reserve them at the same time
+            const uint32_t mykind = ch[lane & 1].kind;
+            uint32_t qslot = 0;
+            if (lane < 2) {
+                if (mykind == 0u) qslot = atomicAdd(&a.ctr[CTR_SMALL], 1u);
+                else if (mykind == 1u) qslot = atomicAdd(&a.ctr[CTR_MID2], 1u);
+                else atomicAdd(&a.ctr[CTR_LEVEL0 + 2 * lvl_slot(L)], 1u);   // the host only asks whether the level is empty
+            }
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const LevelChild<T>& c = ch[side];
+                const uint32_t cq = __shfl(qslot, side);
+                Item<T>* it = c.kind == 0u ? &a.small[cq] : (c.kind == 1u ? &a.mid2[cq] : &v.item[L & 1][c.slot]);
+                if (lane == 0) {
+                    it->ni = side ? ri : li; it->parent = ni; it->start = c.start; it->count = c.count;
+                    it->tile_base = c.tile0; it->parity = (uint32_t)(L & 1); it->heap = heap_child(heap, (uint32_t)side); it->_r1 = 0;
+                }
+                if (lane < 6) { it->A[lane] = side ? sel.AR[lane] : sel.AL[lane]; it->C[lane] = side ? sel.CR[lane] : sel.CL[lane]; }
+                if (c.kind == 3u) {
+                    const uint32_t cnt_t = (c.count + TILE - 1) / TILE;
+                    for (uint32_t j = lane; j < cnt_t; j += WAVE) v.tile_map[bC][c.tile0 + j] = make_uint4(c.slot, c.start, c.count, 0u);
+                }
+            }
+        }
+        LEVEL_STAMP(6);
+        __syncthreads();
+    }
+}
+#ifdef BVH_LEVEL_PROFILE
+void debug_level_prof(unsigned long long* out, size_t n) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_level_prof), sizeof(unsigned long long) * n);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Wave-level SEGMENTED inclusive scans of the 12 bound values (aabb min3 max3, centroid min3 max3) with join as the
@@ -1260,6 +1806,23 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
 // level.  The synchronous entry points run one after the other; the *_async entry points of the C ABI return after the
 // enqueue and leave the finalize to bvhgpu_tree_wait / bvhgpu_hits_wait.
 // ------------------------------------------------------------------------------------------------
+// sizes and offsets of the rotating arrays of the one-launch-per-level tier inside t->lvbuf
+template <typename T> struct LevelLayout {
+    size_t n_slots, n_tiles, sz_tile_item, sz_tile_cnt, sz_stats, off_tile_item, off_tile_cnt, off_stats, bytes;
+    LevelLayout(size_t n, size_t mid_max) {
+        n_slots = n / (mid_max + 1) + 2;
+        n_tiles = n / TILE + n_slots + 4;
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        sz_tile_item = up(n_tiles * 16);
+        sz_tile_cnt = up(n_tiles * NUM_BUCKETS * 4);
+        sz_stats = up(n_slots * STAT_REP * sizeof(ItemStats<T>));
+        off_tile_item = 0;
+        off_tile_cnt = off_tile_item + 3 * sz_tile_item;
+        off_stats = off_tile_cnt + 3 * sz_tile_cnt;
+        bytes = off_stats + 3 * sz_stats;
+    }
+};
+
 template <typename T> static BuildArgs<T> make_args(bvhgpu_tree* t, const T* src) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
@@ -1287,12 +1850,23 @@ template <typename T> static BuildArgs<T> make_args(bvhgpu_tree* t, const T* src
     a.n = (uint32_t)t->n;
     const bool small_scene = t->n <= MID_SCENE_SPLIT;
     a.mid_max = (uint32_t)(small_scene ? MidSmallScene<T>::MAXN : MidLargeScene<T>::MAXN);
+    // level tier with one launch per level (LevelArgs): carved out of t->lvbuf by level_layout()
+    const LevelLayout<T> ly(t->n, a.mid_max);
+    a.lv.slot_div = a.mid_max + 1u; a.lv.n_slots = (uint32_t)ly.n_slots; a.lv.n_tiles = (uint32_t)ly.n_tiles;
+    char* base = reinterpret_cast<char*>(t->lvbuf.p);
+    for (int i = 0; i < 3; i++) {
+        a.lv.tile_map[i] = base ? reinterpret_cast<uint4*>(base + ly.off_tile_item + i * ly.sz_tile_item) : nullptr;
+        a.lv.tile_cnt[i] = base ? reinterpret_cast<uint32_t*>(base + ly.off_tile_cnt + i * ly.sz_tile_cnt) : nullptr;
+        a.lv.stats[i] = base ? reinterpret_cast<ItemStats<T>*>(base + ly.off_stats + i * ly.sz_stats) : nullptr;
+    }
+    a.lv.item[0] = a.big[0]; a.lv.item[1] = a.big[1];
+    a.lv.bk[0] = a.bk; a.lv.bk[1] = a.bk ? a.bk + t->n : nullptr;
     return a;
 }
 
 template <typename T> struct BuildGrid {
     size_t max_big, max_mid2, max_tiles;
-    int tile_grid, sel_grid, mid2_grid, small_grid;
+    int tile_grid, sel_grid, mid2_grid, small_grid, level_grid;
     BuildGrid(const bvhgpu_tree* t, size_t mid_max) {
         const size_t n = t->n;
         max_big = n / (mid_max + 1) + 2;       // simultaneously active nodes with > mid_max shapes
@@ -1302,11 +1876,22 @@ template <typename T> struct BuildGrid {
         sel_grid = (int)std::min<size_t>((max_big + 3) / 4, 1024);
         mid2_grid = (int)std::min<size_t>(max_mid2, (size_t)t->ctx->n_cu * 4);
         small_grid = (int)std::min<size_t>((n + 3) / 4, (size_t)t->ctx->n_cu * 8);
+        level_grid = (int)std::min<size_t>(LevelLayout<T>(n, mid_max).n_tiles, 2048);
     }
 };
 
+// One level-synchronous pass: after pass L (counted from 0) the items of level L are split and their children queued.
+//   two launches per level (BVHGPU_TUNE_BUILD_LEVEL_LAUNCHES = 2): k_bin(L), k_split(L);
+//   one launch per level (default): the root is binned by k_level<ROOT> ahead of pass 0, pass L = k_level(L + 1), which splits
+//   level L and bins level L + 1 in the same launch.
+template <typename T> static bool level_fused(const bvhgpu_tree* t) { return t->ctx->tune[BVHGPU_TUNE_BUILD_LEVEL_LAUNCHES] != 2; }
 template <typename T> static void run_level(bvhgpu_tree* t, const BuildArgs<T>& a, const BuildGrid<T>& g, int L) {
     hipStream_t st = t->ctx->stream;
+    if (level_fused<T>(t)) {
+        if (L == 0) hipLaunchKernelGGL((k_level<T, true>), dim3(g.level_grid), dim3(LEVEL_THREADS), 0, st, a, 0);
+        hipLaunchKernelGGL((k_level<T, false>), dim3(g.level_grid), dim3(LEVEL_THREADS), 0, st, a, L + 1);
+        return;
+    }
     hipLaunchKernelGGL(k_bin<T>, dim3(g.tile_grid), dim3(256), 0, st, a, L);
     hipLaunchKernelGGL(k_split<T>, dim3(g.sel_grid + g.tile_grid), dim3(256), 0, st, a, L, (uint32_t)g.sel_grid);
 }
@@ -1348,7 +1933,8 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     t->wslot_node.reserve(WIDE_SLOTS * 4);
     t->idx[0].reserve(n * 4);
     t->idx[1].reserve(n * 4);
-    t->bk.reserve(n);
+    t->bk.reserve(2 * n);   // (the one-launch-per-level tier keeps the buckets of two consecutive levels)
+    t->lvbuf.reserve(LevelLayout<T>(n, MID_MAX).bytes);
     for (int i = 0; i < 2; i++) {
         t->big[i].reserve(g.max_big * sizeof(Item<T>));
         t->stats[i].reserve(g.max_big * STAT_REP * sizeof(ItemStats<T>));
@@ -1369,7 +1955,7 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
 #endif
     const int prep_grid = (int)std::min<size_t>((n + BVH_PREP_PER_WG - 1) / BVH_PREP_PER_WG, (size_t)PREP_MAX_WG);   // 256 / 512 / 1024 / 2048 shapes per workgroup measured
     hipLaunchKernelGGL(k_prep<T>, dim3(prep_grid), dim3(256), 0, st, a);   // + aabbs copy + input validation
-    hipLaunchKernelGGL(k_root<T>, dim3(1), dim3(256), 0, st, a, (uint32_t)prep_grid);
+    hipLaunchKernelGGL(k_root<T>, dim3(1), dim3(256), 0, st, a, (uint32_t)prep_grid, level_fused<T>(t) ? 1 : 0);
 
     // Optimistic schedule with no host round trip: enough level-synchronous passes for a balanced
     // tree, then the workgroup tier over everything queued so far, then the wave tier.  ONE readback

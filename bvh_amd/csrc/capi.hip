@@ -58,7 +58,7 @@ void copy_out(bvhgpu_ctx* ctx, void* dst, const void* src_dev, size_t bytes, int
 void free_tree_buffers(bvhgpu_tree* t) {
     t->aabbs.release(); t->nodes.release(); t->node_start.release(); t->node_count.release();
     t->shape_node.release(); t->flat.release(); t->trav.release(); t->slot_entry.release(); t->node_slot.release(); t->tris.release();
-    t->idx[0].release(); t->idx[1].release(); t->bk.release();
+    t->idx[0].release(); t->idx[1].release(); t->bk.release(); t->lvbuf.release();
     t->big[0].release(); t->big[1].release(); t->mid2.release(); t->small.release();
     t->stats[0].release(); t->stats[1].release();
     t->tile_item[0].release(); t->tile_item[1].release(); t->tile_cnt.release(); t->ctr.release(); t->refit_seg.release();
@@ -347,6 +347,9 @@ int do_nearest(bvhgpu_tree* t, const T* points, size_t n, int mem, int kind, uin
 
 #ifdef BVH_PROFILE_MID
 namespace bvhgpu { void debug_mid_prof(unsigned long long* out, bool reset); }
+#endif
+#ifdef BVH_LEVEL_PROFILE
+namespace bvhgpu { void debug_level_prof(unsigned long long* out, size_t n); }
 #endif
 #ifdef BVH_WIDE_PROFILE
 namespace bvhgpu { void debug_wide_prof(unsigned long long* out, size_t n); }
@@ -873,6 +876,9 @@ int bvhgpu_get_tuning(const bvhgpu_ctx* ctx, int knob, int* value) {
     return BVHGPU_OK;
 }
 
+#ifdef BVH_LEVEL_PROFILE
+void bvhgpu_debug_level_prof(unsigned long long* out, size_t n) { bvhgpu::debug_level_prof(out, n); }
+#endif
 #ifdef BVH_WIDE_PROFILE
 void bvhgpu_debug_wide_prof(unsigned long long* out, size_t n) { bvhgpu::debug_wide_prof(out, n); }
 #endif

@@ -93,7 +93,8 @@ struct bvhgpu_tree {
     bvhgpu::DevBuf node_slot;   // n_nodes * u16: LDS slot of the node's traversal entry (SLOT_NONE = not resident)
     // build scratch (kept for rebuild)
     bvhgpu::DevBuf idx[2];      // n * u32 ping-pong permutation
-    bvhgpu::DevBuf bk;          // n * u8 bucket per position
+    bvhgpu::DevBuf bk;          // 2 n * u8 bucket per position (two consecutive levels)
+    bvhgpu::DevBuf lvbuf;       // level tier, one launch per level: rotating tile maps / tile counts / statistics (build.hip LevelLayout)
     bvhgpu::DevBuf big[2];      // Item queues of the level-synchronous tier
     bvhgpu::DevBuf mid2;        // Item queue of the workgroup tier (65..1024 shapes)
     bvhgpu::DevBuf small;       // Item queue of the wave-subtree tier

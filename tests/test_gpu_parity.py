@@ -185,6 +185,42 @@ def test_parity_unbalanced_deep_tree(eng, orc):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("launches", [0, 2])
+def test_level_tier_schedules_same_tree(eng, orc, launches, dtype):
+    """The level tier as one launch per level (k_level: split of level L-1 and binning of level L fused, default) and as two
+    (k_bin, k_split) must both reproduce the oracle's node array: balanced scene, the unbalanced deep tree (host-continued
+    level loop), sizes around the tier's hand-over, a scene with colliding centroids (degenerate halving in the level tier)."""
+    from bvh_amd import Bvh, Context, testbase as tb
+    from bvh_amd._lib import TUNE_BUILD_LEVEL_LAUNCHES
+    ctx = Context(0)
+    ctx.set_tuning(TUNE_BUILD_LEVEL_LAUNCHES, launches)
+    rng = np.random.default_rng(5)
+    scenes = []
+    _, cubes = tb.create_n_cubes(2500)
+    scenes.append(cubes.astype(dtype))
+    n = 12000
+    x = np.float32(1.004) ** np.arange(n, dtype=np.float32)
+    lo = np.stack([x, np.zeros(n, np.float32), np.zeros(n, np.float32)], axis=1)
+    scenes.append(np.concatenate([lo, lo + np.float32(0.5)], axis=1).astype(dtype))
+    for m in (769, 770, 1537, 1538, 3077, 6000):
+        lo = rng.uniform(-50, 50, size=(m, 3))
+        scenes.append(np.concatenate([lo, lo + rng.uniform(0, 3, size=(m, 3))], axis=1).astype(dtype))
+    same = np.tile(np.array([[1, 2, 3, 4, 5, 6]], dtype), (5000, 1))          # every centroid equal: halving all the way down
+    scenes.append(same)
+    half = np.concatenate([same[:2500], cubes[:3000].astype(dtype)])           # a degenerate cluster inside a normal scene
+    scenes.append(half)
+    bvh = None
+    for aabbs in scenes:
+        ot = orc.build(aabbs)
+        bvh = Bvh.from_aabbs(aabbs, ctx) if bvh is None else bvh.rebuild(aabbs)
+        assert bvh.nodes.tobytes() == ot.nodes.tobytes(), (launches, len(aabbs))
+        assert np.array_equal(bvh.shape_nodes, ot.shape_node)
+    # the same tree object rebuilt with a scene it has a level hint for
+    bvh.rebuild(scenes[0]); bvh.rebuild(scenes[0])
+    assert bvh.nodes.tobytes() == orc.build(scenes[0]).nodes.tobytes()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("n", [4095, 4096, 4097, 8193, 30000])
 def test_parity_mid_tier_boundaries(eng, orc, n, dtype):
     """sizes around MID_MAX = 4096 (workgroup tier) with clustered data so sub-node sizes vary widely."""

@@ -1,0 +1,37 @@
+"""developer tool: phase stamps inside k_level at one level.  Build first:
+   python bvh_amd/build_ext.py --variant /root/repo/tools/libbvh_levelprof.so BVH_LEVEL_PROFILE=<level>
+   then on the GPU box: python tools/level_prof.py"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["BVH_AMD_SO"] = os.path.join(ROOT, "tools", "libbvh_levelprof.so")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from bvh_amd import Bvh, Context, _lib, testbase as tb  # noqa: E402
+
+lib = _lib.load()
+dev = torch.device("cuda", 0)
+ctx = Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
+_, aabbs = tb.create_n_cubes(10_000, tb.default_bounds())
+a = torch.from_numpy(aabbs).to(dev)
+bvh = Bvh.from_aabbs(a, ctx)
+for _ in range(5):
+    bvh.rebuild(a)
+n = 8 * 1024
+out = (C.c_ulonglong * n)()
+lib.bvhgpu_debug_level_prof.argtypes = [C.c_void_p, C.c_size_t]
+lib.bvhgpu_debug_level_prof(out, n)
+p = np.array(out[:], dtype=np.float64).reshape(-1, 8)
+live = p[p[:, 1] > 0]
+idle = p[(p[:, 0] > 0) & (p[:, 1] == 0)]
+t0 = p[p[:, 0] > 0][:, 0].min()
+us = lambda x: (x - t0) / 100.0  # noqa: E731
+names = ["kernel entry", "tile map read", "wave 0 at the barrier (ranks done)", "selection done", "shapes done", "flush done", "end", "statistics merged (selection starts)"]
+print(f"workgroups with a tile {len(live)}, without {len(idle)}")
+for i, nme in enumerate(names):
+    col = us(live[:, i])
+    print(f"{nme:58s} mean {col.mean():7.2f}  min {col.min():7.2f}  max {col.max():7.2f} us")
