@@ -116,7 +116,8 @@ template <typename T> struct BuildArgs {
     uint32_t* tile_item[2];
     uint32_t* tile_cnt;
     uint32_t* ctr;
-    typename Traits<T>::Key* rootkeys;   // [gridDim of k_prep][12]: every workgroup's bounds; the last one to arrive joins them
+    typename Traits<T>::Key* rootkeys;   // [gridDim of k_prep][12]: every workgroup's bounds (joined by k_root / k_level<ROOT>)
+    uint32_t prep_wgs;                   // gridDim of k_prep
     uint32_t n;
 };
 
@@ -146,6 +147,8 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T>
         const uint32_t nc = a.lv.n_tiles * (uint32_t)NUM_BUCKETS;
         for (uint32_t i = gt; i < 3u * nc; i += gs) a.lv.tile_cnt[i / nc][i % nc] = 0u;
     }
+    if (a.lv.tile_map[0] && blockIdx.x == 0 && threadIdx.x < WAVE)   // ... and the root's statistic replicas (k_level<ROOT> adds to them)
+        for (int r = 0; r < STAT_REP; r++) init_stats<T>(&a.lv.stats[0][r], (int)threadIdx.x);
     if (blockIdx.x == 0) {   // the LDS slot tables of the previous tree (filled again by flatten)
         for (uint32_t i = threadIdx.x; i < a.n_slots; i += blockDim.x) a.slot_entry[i] = NONE;
         for (uint32_t i = threadIdx.x; i < WIDE_SLOTS; i += blockDim.x) a.wslot_node[i] = NONE;
@@ -691,6 +694,12 @@ template <typename T> __global__ __launch_bounds__(256) void k_split(BuildArgs<T
 //   the children's work items (level tier: LevelArgs arrays; workgroup / wave tier: their queues, as before).
 // ROOT: level 0 has no parent — the root item (k_root) is binned in place.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lane_bcast_rt(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double lane_bcast_rt(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 template <typename T> struct LevelSel {
     uint32_t nl, no_winner;
     T AL[6], CL[6], AR[6], CR[6];
@@ -749,7 +758,7 @@ __device__ __forceinline__ void sah_select_wave(const ItemStats<T>* st, const T*
     int best = -1;   // no winner (NaN/inf costs): the reference keeps min_bucket = 0 and EMPTY child bounds (:225-230)
 #pragma unroll
     for (int sp = 0; sp < NUM_BUCKETS - 1; sp++) {
-        const T c = __shfl(cost, sp);
+        const T c = lane_bcast_rt(cost, sp);   // (v_readlane: no LDS round trip)
         const bool take = degen ? (sp == 0) : (c < min_cost);   // strict <, first wins (:239)
         if (take) { min_cost = c; best = sp; }
     }
@@ -851,7 +860,40 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
     LEVEL_STAMP(0);
     // (the first tile's record is requested before the housekeeping stores: its round trip hides behind them)
     uint4 tm_first = make_uint4(NONE, 0u, 0u, 0u);
-    if (blockIdx.x < v.n_tiles) tm_first = v.tile_map[ROOT ? bC : bP][blockIdx.x];
+    if (!ROOT && blockIdx.x < v.n_tiles) tm_first = v.tile_map[bP][blockIdx.x];
+    // ROOT: the scene bounds (k_prep left one row of 12 keys per workgroup) → the root item, in every workgroup; tile g of
+    // the root is simply positions [g TILE, (g+1) TILE)
+    __shared__ Key s_rootk[STAT_KEYS];
+    if (ROOT) {
+        if (threadIdx.x < STAT_KEYS) s_rootk[threadIdx.x] = key_is_min(threadIdx.x) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < a.prep_wgs * (uint32_t)STAT_KEYS; e += LEVEL_THREADS) {   // rows x keys, coalesced
+            const Key x = a.rootkeys[e];
+            const int j = (int)(e % (uint32_t)STAT_KEYS);
+            if (key_is_min(j)) atomicMin(&s_rootk[j], x);
+            else atomicMax(&s_rootk[j], x);
+        }
+        __syncthreads();
+        bool bad = (a.ctr[CTR_FLAGS] & BUILD_FLAG_NONFINITE) != 0u;
+        // finite boxes whose centroid extent overflows: (c - cmin) / ext is NaN for some shape → the reference's panic (k_root)
+#pragma unroll
+        for (int k = 0; k < 3; k++) bad = bad || !(fabs(Tr::unkey(s_rootk[9 + k]) - Tr::unkey(s_rootk[6 + k])) < Tr::inf());
+        if (bad) {   // invalid input: nothing is queued, every later kernel of the optimistic schedule finds nothing to do
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_NONFINITE);
+            return;
+        }
+        const uint32_t root_tiles = (a.n + TILE - 1) / TILE;
+        if (blockIdx.x == 0) {   // the record and tile map the next level reads
+            Item<T>* it = &v.item[0][0];
+            if (threadIdx.x == 0) {
+                it->ni = 0; it->parent = 0; it->start = 0; it->count = a.n; it->tile_base = 0; it->parity = 0; it->heap = 1u; it->_r1 = 0;
+                a.ctr[CTR_LEVEL0] = 1u;
+            }
+            if (threadIdx.x < 6) { it->A[threadIdx.x] = Tr::unkey(s_rootk[threadIdx.x]); it->C[threadIdx.x] = Tr::unkey(s_rootk[6 + threadIdx.x]); }
+            for (uint32_t j = threadIdx.x; j < root_tiles; j += LEVEL_THREADS) v.tile_map[0][j] = make_uint4(0u, 0u, a.n, 0u);
+        }
+        if (blockIdx.x < root_tiles) tm_first = make_uint4(0u, 0u, a.n, 0u);
+    }
 
     // ---- reset what the NEXT level accumulates into
     {
@@ -879,7 +921,7 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
 
     for (uint32_t g = blockIdx.x; g < v.n_tiles; g += gridDim.x) {
         // one load tells the tile's workgroup all it needs to start: the item's slot (statistics, record), slice and size
-        const uint4 tm = g == blockIdx.x ? tm_first : v.tile_map[ROOT ? bC : bP][g];
+        const uint4 tm = g == blockIdx.x ? tm_first : (ROOT ? make_uint4(g < (a.n + TILE - 1) / TILE ? 0u : NONE, 0u, a.n, 0u) : v.tile_map[bP][g]);
         const uint32_t slotP = tm.x;
         if (slotP == NONE) continue;   // workgroup-uniform
         LEVEL_STAMP(1);
@@ -922,21 +964,23 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
         // ... and the bucket counts of P's tiles (consumed further down) → offset of (this tile, bucket b) inside P's slice =
         // shapes of P in buckets < b + shapes of bucket b in P's earlier tiles
         constexpr int TCV = 2;   // tiles per thread held in registers before they are consumed (more are fetched in a loop)
+        constexpr int NCT = LEVEL_THREADS - 64;             // the selection wave takes no part in this
+        const uint32_t ctid = threadIdx.x - 64u;
         uint32_t tcv[TCV][NUM_BUCKETS];
         const uint32_t* tc = v.tile_cnt[bP] + (size_t)tile0P * NUM_BUCKETS;
         if (!ROOT) {
 #pragma unroll
             for (int i = 0; i < TCV; i++) {
-                const uint32_t j = stid + 256u * (uint32_t)i;
+                const uint32_t j = ctid + (uint32_t)NCT * (uint32_t)i;
 #pragma unroll
-                for (int b = 0; b < NUM_BUCKETS; b++) tcv[i][b] = (shaper && j < ntl) ? tc[(size_t)j * NUM_BUCKETS + b] : 0u;
+                for (int b = 0; b < NUM_BUCKETS; b++) tcv[i][b] = (w > 0 && j < ntl) ? tc[(size_t)j * NUM_BUCKETS + b] : 0u;
             }
         }
         if (ROOT) {
             if (threadIdx.x == 0) {
                 T C[6];
 #pragma unroll
-                for (int k = 0; k < 6; k++) C[k] = P->C[k];
+                for (int k = 0; k < 6; k++) C[k] = Tr::unkey(s_rootk[6 + k]);
                 level_child_derive<T>(&ch[0], C, start, count, a.mid_max, v.slot_div);
                 ch[1].start = start + count; ch[1].count = 0; ch[1].kind = 0; ch[1].slot = 0; ch[1].tile0 = 0;
                 sel.nl = count; sel.no_winner = 0;
@@ -1006,17 +1050,17 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
                 for (int k = 0; k < 6; k++) bx[u][k] = (T)0;
             }
         }
-        if (!ROOT && shaper) {
+        if (!ROOT && w > 0) {
             uint32_t before[NUM_BUCKETS], all[NUM_BUCKETS];
 #pragma unroll
             for (int b = 0; b < NUM_BUCKETS; b++) { before[b] = 0; all[b] = 0; }
 #pragma unroll
             for (int i = 0; i < TCV; i++) {
-                const uint32_t j = stid + 256u * (uint32_t)i;
+                const uint32_t j = ctid + (uint32_t)NCT * (uint32_t)i;
 #pragma unroll
                 for (int b = 0; b < NUM_BUCKETS; b++) { all[b] += tcv[i][b]; before[b] += j < tl ? tcv[i][b] : 0u; }
             }
-            for (uint32_t j = stid + 256u * TCV; j < ntl; j += 256) {   // (items of more than 512 tiles: huge scenes' top levels)
+            for (uint32_t j = ctid + (uint32_t)NCT * TCV; j < ntl; j += NCT) {   // (items of more than 384 tiles: huge scenes' top levels)
 #pragma unroll
                 for (int b = 0; b < NUM_BUCKETS; b++) {
                     const uint32_t x = tc[(size_t)j * NUM_BUCKETS + b];
@@ -1029,7 +1073,7 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
             for (int b = 0; b < NUM_BUCKETS; b++) {
                 const uint32_t mine = wave_sum_u32(acc + before[b]);
                 acc += all[b];
-                if (lane == 0) wsum[sw][b] = mine;
+                if (lane == 0) wsum[w - 1][b] = mine;
             }
         }
         // ranks inside the tile: ballots per 256-shape round, counts per (wave, round, bucket) through LDS
@@ -1050,7 +1094,12 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
         }
         LEVEL_STAMP(2);
         __syncthreads();
-        if (!ROOT && threadIdx.x < NUM_BUCKETS) run0[threadIdx.x] = wsum[0][threadIdx.x] + wsum[1][threadIdx.x] + wsum[2][threadIdx.x] + wsum[3][threadIdx.x];
+        if (!ROOT && threadIdx.x < NUM_BUCKETS) {
+            uint32_t r0 = 0;
+#pragma unroll
+            for (int ww = 0; ww < LEVEL_THREADS / 64 - 1; ww++) r0 += wsum[ww][threadIdx.x];
+            run0[threadIdx.x] = r0;
+        }
         if (!ROOT) __syncthreads();
         const uint32_t nl = sel.nl;
         // ---- the tile's shapes: stable bucket-major move (bvh_node.rs:250-272) + bucket / statistics for the next split
@@ -1848,6 +1897,7 @@ template <typename T> static BuildArgs<T> make_args(bvhgpu_tree* t, const T* src
     a.ctr = t->ctr.as<uint32_t>();
     a.rootkeys = reinterpret_cast<Key*>(reinterpret_cast<char*>(t->ctr.p) + ROOTKEY_OFF);
     a.n = (uint32_t)t->n;
+    a.prep_wgs = 0;
     const bool small_scene = t->n <= MID_SCENE_SPLIT;
     a.mid_max = (uint32_t)(small_scene ? MidSmallScene<T>::MAXN : MidLargeScene<T>::MAXN);
     // level tier with one launch per level (LevelArgs): carved out of t->lvbuf by level_layout()
@@ -1946,7 +1996,7 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     if (t->ctr.reserve(ROOTKEY_OFF + (size_t)PREP_MAX_WG * STAT_KEYS * sizeof(Key))) t->ctr_ready = false;   // a fresh buffer has not been zeroed by the previous build
     if (!t->pin) BVH_HIP(hipHostMalloc(&t->pin, ROOTKEY_OFF, hipHostMallocDefault));
 
-    const BuildArgs<T> a = make_args<T>(t, aabbs_dev);
+    BuildArgs<T> a = make_args<T>(t, aabbs_dev);
     // counters and root keys were reset at the end of the previous build of this tree (off the critical path)
     if (!t->ctr_ready) hipLaunchKernelGGL(k_init<T>, dim3(1), dim3(256), 0, st, a);
     t->ctr_ready = false;
@@ -1954,8 +2004,10 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
 #define BVH_PREP_PER_WG 1024
 #endif
     const int prep_grid = (int)std::min<size_t>((n + BVH_PREP_PER_WG - 1) / BVH_PREP_PER_WG, (size_t)PREP_MAX_WG);   // 256 / 512 / 1024 / 2048 shapes per workgroup measured
+    a.prep_wgs = (uint32_t)prep_grid;
     hipLaunchKernelGGL(k_prep<T>, dim3(prep_grid), dim3(256), 0, st, a);   // + aabbs copy + input validation
-    hipLaunchKernelGGL(k_root<T>, dim3(1), dim3(256), 0, st, a, (uint32_t)prep_grid, level_fused<T>(t) ? 1 : 0);
+    // the root item: by the level tier's first launch itself (one launch per level), else by a one-workgroup launch
+    if (!(level_fused<T>(t) && n > (size_t)MID_MAX)) hipLaunchKernelGGL(k_root<T>, dim3(1), dim3(256), 0, st, a, (uint32_t)prep_grid, 0);
 
     // Optimistic schedule with no host round trip: enough level-synchronous passes for a balanced
     // tree, then the workgroup tier over everything queued so far, then the wave tier.  ONE readback
