@@ -122,13 +122,14 @@ struct bvhgpu_hits {
     bvhgpu::DevBuf closest;  // n_rays * 3 T (CLOSEST)
     bvhgpu::DevBuf closest_prim;  // n_rays u32
     bvhgpu::DevBuf blocksums;
-    bvhgpu::DevBuf bsum64;    // wide walk: hits per 64-ray block (k_scan_final's input instead of a reduce pass)
+    bvhgpu::DevBuf bsum64;    // wide walk: two sets of hits per scan block (k_scan_final's input instead of a reduce pass), kept zero
     bvhgpu::DevBuf ctr;      // [0] pool count (u64) [1] visited [2] leaf_visits [3] device_steps [4] ray ticket
     bvhgpu::DevBuf heap_dist, heap_node;  // best-first traversal: the part of the lanes' heaps that does not fit in LDS
     uint32_t heap_cap = 48;  // ... entries per lane (doubles when a batch overflows it)
     size_t pool_cap = 0;
     bool ctr_clean = false;  // the counters were zeroed behind the previous call's readback
     int ctr_set = 0;         // which of the two counter sets the next batch uses
+    int bsum_set = 0;        // likewise for the wide walk's scan-block sums
     // wide walk
     bvhgpu::DevBuf wcounts;   // n_rays+1 u32: hit count | item mask << 28, all-zero between batches
     bvhgpu::DevBuf ray_mask;  // n_rays u16: items of the ray that reported hits (valid for rays with hits)

@@ -105,7 +105,14 @@ __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node*
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     const typename Tr::Node nd = nodes[i];
-    if (wide && nd.shape == NONE && nd.l < n_nodes && nd.r < n_nodes) flatten_wide_node<T>(nodes, nd, i, node_slot, wide, wslot_node, n_nodes, n_shapes);
+    // wide nodes: the walk only ever enters nodes an even number of levels below the root (it steps from a node to its
+    // grandchildren, items start 2 or 4 levels down), so odd levels get none — as far as the level is known: heap numbers
+    // saturate 16 levels down, below that every inner node gets one
+    if (wide && nd.shape == NONE && nd.l < n_nodes && nd.r < n_nodes) {
+        const uint32_t h = node_slot[i];
+        const bool odd_level = h != SLOT_NONE && h >= 1u && (((31 - __clz((int)h)) & 1) != 0);
+        if (!odd_level) flatten_wide_node<T>(nodes, nd, i, node_slot, wide, wslot_node, n_nodes, n_shapes);
+    }
     if (n_nodes == 1) {
         // single-shape tree: the root is a leaf and emits one leaf entry (flat_bvh.rs:129-141); its
         // traversal entry tests the shape's own AABB (flat_bvh.rs:411-418)

@@ -72,7 +72,7 @@ template <typename T> struct WalkOut {
     uint32_t* closest_prim;      // per ray shape index or NONE
     uint32_t* item_cnt;          // wide walk with several items per ray: hits of item (ray, j), written only when non-zero
     uint32_t* ray_items;         // ... and per ray the set of j that wrote one (kept all-zero between batches like counts)
-    uint32_t* bsum64;         // wide walk: hits per 64-ray block, left by the workgroup that owns the block (or NULL: k_scan_reduce does the sums)
+    uint32_t* bsum64;         // wide walk: hits per SCAN_BLOCK rays, added up by the workgroups as they finish (a zeroed set; NULL: k_scan_reduce does the sums)
 };
 
 // ---- Ray::intersects_triangle (ray_impl.rs:154-213), Möller–Trumbore with back-face culling.  Same
@@ -1036,7 +1036,10 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     walk_epilogue<T, MODE>(w, pc, lane, false, 0, 0, 0, 0);
     if (MODE != MODE_CLOSEST && w.bsum64) {   // every wave of the workgroup gets here: all items of its rays have retired
         __syncthreads();
-        for (uint32_t b = tid; b < my_blocks; b += bd) w.bsum64[b * gridDim.x + blockIdx.x] = s_bsum[b];
+        // one atomic per 64-ray block that has hits, on the sum of its scan block (workgroups finish at different times and a
+        // scan block's 16 sums come from 16 workgroups: nothing like the per-item atomics that were tried first)
+        for (uint32_t b = tid; b < my_blocks; b += bd)
+            if (s_bsum[b]) atomicAdd(&w.bsum64[(b * gridDim.x + blockIdx.x) / (uint32_t)(SCAN_BLOCK / 64)], s_bsum[b]);
     }
 #ifdef BVH_WIDE_PROFILE
     if (lane == 0) {
@@ -1107,7 +1110,8 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__
                                                     unsigned long long* __restrict__ total,
                                                     uint32_t* __restrict__ offsets, uint32_t* __restrict__ ray_items,
                                                     uint16_t* __restrict__ ray_mask, unsigned long long* __restrict__ host_page,
-                                                    unsigned long long* __restrict__ other_ctr, const uint32_t* __restrict__ bsum64) {
+                                                    unsigned long long* __restrict__ other_ctr, const uint32_t* __restrict__ bsum64,
+                                                    uint32_t* __restrict__ other_bsum, uint32_t bsum_cap) {
     __shared__ uint32_t ws[4];
     __shared__ unsigned long long wb[4];
     const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
@@ -1117,12 +1121,11 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__
         before = blocksums[blockIdx.x];
     } else {
         unsigned long long part = 0;
-        if (bsum64) {   // the walk left one sum per 64 rays: SCAN_BLOCK / 64 of them (one 64-byte line) per scan block
-            const uint4* q = reinterpret_cast<const uint4*>(bsum64);
-            for (uint32_t j = threadIdx.x; j < blockIdx.x * (SCAN_BLOCK / 256u); j += 256) {
-                const uint4 v4 = q[j];
-                part += (unsigned long long)v4.x + v4.y + v4.z + v4.w;
-            }
+        if (bsum64) {   // the walk left the sums (u32) in this batch's set; the other set is zeroed here for the next batch
+            for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256) part += bsum64[j];
+            if (threadIdx.x == 0) other_bsum[blockIdx.x] = 0u;
+            if (blockIdx.x == gridDim.x - 1)   // (a previous, larger batch may have left more behind)
+                for (uint32_t j = gridDim.x + threadIdx.x; j < bsum_cap; j += 256) other_bsum[j] = 0u;
         } else {
             for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256) part += blocksums[j];
         }
@@ -1479,6 +1482,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     }
     const unsigned long long cap = h->pool_cap;
     uint32_t* counts;
+    uint32_t* bsum_other = nullptr;
     if (use_wide) {   // per-ray words kept all-zero between batches (k_scan_final puts the zeros back)
         if (h->wcounts.reserve((n_rays + 1) * 4)) h->wcounts_clean = false;
         if (!h->wcounts_clean) BVH_HIP(hipMemsetAsync(h->wcounts.p, 0, h->wcounts.cap, st));
@@ -1498,8 +1502,11 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
             const size_t grid = std::min<size_t>(std::max<size_t>(full, 1), (size_t)ctx->n_cu * g.wg_per_cu);   // launch_wide: the same
             const size_t n_blocks = (n_rays + 63) / 64;
             if (nb <= SCAN_FUSED_MAX_BLOCKS && (n_blocks + grid - 1) / grid <= WIDE_BSUM_MAX) {
-                h->bsum64.reserve((n_blocks + 16) * 4);
-                w.bsum64 = h->bsum64.as<uint32_t>();
+                // two sets of SCAN_FUSED_MAX_BLOCKS sums, used alternately like the counter sets (k_scan_final zeroes the other one)
+                if (h->bsum64.reserve(2 * SCAN_FUSED_MAX_BLOCKS * 4)) BVH_HIP(hipMemsetAsync(h->bsum64.p, 0, h->bsum64.cap, st));
+                w.bsum64 = h->bsum64.as<uint32_t>() + (size_t)SCAN_FUSED_MAX_BLOCKS * (h->bsum_set & 1);
+                bsum_other = h->bsum64.as<uint32_t>() + (size_t)SCAN_FUSED_MAX_BLOCKS * ((h->bsum_set & 1) ^ 1);
+                h->bsum_set ^= 1;   // (this batch's k_scan_final zeroes the other set: the next batch's)
             }
         }
     } else {
@@ -1522,10 +1529,10 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         if (nb > SCAN_FUSED_MAX_BLOCKS) {
             hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, bs, nb, ctr + 3);
             hipLaunchKernelGGL((k_scan_final<KD, true>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, ritems, rmask,
-                               (unsigned long long*)nullptr, (unsigned long long*)nullptr, (const uint32_t*)nullptr);
+                               (unsigned long long*)nullptr, (unsigned long long*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
         } else {
             hipLaunchKernelGGL((k_scan_final<KD, false>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, ritems, rmask, pin, ctr_other,
-                               (const uint32_t*)w.bsum64);
+                               (const uint32_t*)w.bsum64, bsum_other, (uint32_t)SCAN_FUSED_MAX_BLOCKS);
         }
     };
     if (kind == COUNT_MASKED) scan(std::integral_constant<int, COUNT_MASKED>{});
