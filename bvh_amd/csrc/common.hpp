@@ -261,6 +261,18 @@ __device__ __forceinline__ bool slab_hit_finite<float>(const float o[3], const f
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmx) : "v"(b0), "v"(b1), "v"(b2));
     return (tmx >= tmn) & (tmx >= 0.0f);   // tmx >= max(tmn, 0)
 }
+// the same test, also returning how long the ray stays inside the box (scheduling heuristics only)
+template <typename T>
+__device__ __forceinline__ bool slab_hit_finite_len(const T o[3], const T inv[3], const T mn[3], const T mx[3], T& len) {
+    T l0 = (mn[0] - o[0]) * inv[0], h0 = (mx[0] - o[0]) * inv[0];
+    T l1 = (mn[1] - o[1]) * inv[1], h1 = (mx[1] - o[1]) * inv[1];
+    T l2 = (mn[2] - o[2]) * inv[2], h2 = (mx[2] - o[2]) * inv[2];
+    T tmn = fmax(fmax(fmin(l0, h0), fmin(l1, h1)), fmin(l2, h2));
+    T tmx = fmin(fmin(fmax(l0, h0), fmax(l1, h1)), fmax(l2, h2));
+    const T t0 = fmax(tmn, (T)0);
+    len = tmx - t0;
+    return tmx >= t0;
+}
 template <typename T> __device__ __forceinline__ bool ray_is_finite(const T o[3], const T inv[3]) {
     bool f = true;
 #pragma unroll

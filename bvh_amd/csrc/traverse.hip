@@ -772,9 +772,13 @@ __device__ __forceinline__ uint32_t wide_hits(const T o[3], const T inv[3], cons
 
 // The 4^L item subtrees of a tree: box + reference, in pre-order (j = 4 * slot at wide level 1 + slot at wide level 2).  Every
 // workgroup that needs them derives them itself from the root's wide node (and its four children's): two dependent loads.
+#ifndef BVH_WIDE_LONG_FRAC
+#define BVH_WIDE_LONG_FRAC 0.2   // of the box diagonal; measured on configs[1]: none 127 / 0.1 125 / 0.2 121 / 0.3 123.5 / 0.5 126.5 us
+#endif
 template <typename T> struct ItemTable {
     T box[16][6];
     uint32_t ref[16];
+    T half_diag[16];   // scheduling only: an item whose ray stays inside the box for more than this is walked early (long walk expected)
 };
 template <typename T, int ITEMS_LOG4>
 __device__ __forceinline__ void item_table_build(const WideNode<T>* __restrict__ wide, ItemTable<T>* tb, uint32_t tid) {
@@ -804,6 +808,8 @@ __device__ __forceinline__ void item_table_build(const WideNode<T>* __restrict__
 #pragma unroll
         for (int a = 0; a < 6; a++) tb->box[tid][a] = b[a];
         tb->ref[tid] = ref;
+        const T dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+        tb->half_diag[tid] = (T)BVH_WIDE_LONG_FRAC * sqrt(dx * dx + dy * dy + dz * dz);
     }
 }
 // LDS slot (4-ary heap number) of item j's subtree root
@@ -831,6 +837,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     extern __shared__ __attribute__((aligned(16))) uint4 wsmem[];
     uint32_t& s_next = *reinterpret_cast<uint32_t*>(wsmem);
     uint32_t& s_nlist = *(reinterpret_cast<uint32_t*>(wsmem) + 1);
+    uint32_t& s_nback = *(reinterpret_cast<uint32_t*>(wsmem) + 2);
     uint32_t* s_item_ref = reinterpret_cast<uint32_t*>(wsmem + 1);           // 16 references (64 bytes)
     uint4* nodes = wsmem + 5;
     uint32_t* s_stack = reinterpret_cast<uint32_t*>(nodes + (size_t)CH * K);
@@ -855,7 +862,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     // the BASELINE stream's 10 000 hits on one cache line, 128 → 162 µs.)
     __shared__ uint32_t s_bsum[WIDE_BSUM_MAX];
     if (w.bsum64) for (uint32_t b = tid; b < WIDE_BSUM_MAX; b += bd) s_bsum[b] = 0u;
-    if (tid == 0) { s_next = 0u; s_nlist = 0u; }
+    if (tid == 0) { s_next = 0u; s_nlist = 0u; s_nback = 0u; }
     for (uint32_t q = tid; q < K; q += bd) {
         const uint32_t node = wslot_node[q];
         if (node != NONE) {
@@ -882,44 +889,56 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
         list = list_all + (size_t)blockIdx.x * per_wg * ITEMS;
         for (uint32_t l0 = 0; l0 < my_rays; l0 += bd) {   // workgroup-uniform
             const uint32_t r = l0 + tid < my_rays ? ray_of(l0 + tid) : n_rays;
-            uint32_t mask = 0;
+            uint32_t mask = 0, longm = 0;
             if (r < n_rays) {
                 const typename Traits<T>::Ray* rp = rays + r;
                 const T o[3] = {rp->o[0], rp->o[1], rp->o[2]}, inv[3] = {rp->inv[0], rp->inv[1], rp->inv[2]};
                 if (!ray_is_finite<T>(o, inv)) {
-                    mask = 1u << WIDE_ITEM_WHOLE;
+                    mask = 1u << WIDE_ITEM_WHOLE; longm = mask;
                 } else {
 #pragma unroll 4
                     for (uint32_t j = 0; j < ITEMS; j++) {   // the boxes are workgroup-uniform: LDS broadcast reads
                         const T mn[3] = {tb.box[j][0], tb.box[j][1], tb.box[j][2]}, mx[3] = {tb.box[j][3], tb.box[j][4], tb.box[j][5]};
-                        mask |= slab_hit_finite<T>(o, inv, mn, mx) ? (1u << j) : 0u;
+                        T len;
+                        const bool hit = slab_hit_finite_len<T>(o, inv, mn, mx, len);
+                        mask |= hit ? (1u << j) : 0u;
+                        longm |= (hit && len > tb.half_diag[j]) ? (1u << j) : 0u;
                     }
                 }
             }
-            // wave-level compaction (a ray's items stay together, in j order), one LDS atomic per wave
-            const uint32_t mine = (uint32_t)__popc(mask);
-            uint32_t incl = mine;
+            // wave-level compaction, one LDS atomic per wave and end of the list: items whose ray stays long inside their
+            // subtree's box (long walks expected) fill the list from the front, the others from the back — the walk draws from
+            // the front, so that the longest chains start first instead of setting the end of the launch
+            const uint32_t cap = per_wg * ITEMS;
 #pragma unroll
-            for (int d = 1; d < WAVE; d <<= 1) {
-                const uint32_t u = __shfl_up(incl, d);
-                if (lane >= d) incl += u;
-            }
-            const uint32_t total = __shfl(incl, WAVE - 1);
-            uint32_t base = 0;
-            if (lane == 0 && total) base = atomicAdd(&s_nlist, total);
-            base = __shfl(base, 0) + incl - mine;
-            uint32_t mm = mask;
-            while (mm) {
-                const uint32_t bit = (uint32_t)__ffs(mm) - 1u;
-                mm &= mm - 1u;
-                list[base++] = (r << WIDE_ITEM_BITS) | bit;
+            for (int side = 0; side < 2; side++) {
+                const uint32_t mm0 = side ? (mask & ~longm) : (mask & longm);
+                const uint32_t mine = (uint32_t)__popc(mm0);
+                uint32_t incl = mine;
+#pragma unroll
+                for (int d = 1; d < WAVE; d <<= 1) {
+                    const uint32_t u = __shfl_up(incl, d);
+                    if (lane >= d) incl += u;
+                }
+                const uint32_t total = __shfl(incl, WAVE - 1);
+                uint32_t base = 0;
+                if (lane == 0 && total) base = atomicAdd(side ? &s_nback : &s_nlist, total);
+                base = __shfl(base, 0) + incl - mine;
+                uint32_t mm = mm0;
+                while (mm) {
+                    const uint32_t bit = (uint32_t)__ffs(mm) - 1u;
+                    mm &= mm - 1u;
+                    list[side ? cap - 1u - base : base] = (r << WIDE_ITEM_BITS) | bit;
+                    base++;
+                }
             }
         }
         __threadfence_block();
     }
     __syncthreads();
     const uint32_t wg_begin = 0u;
-    const uint32_t wg_end = ITEMS_LOG4 == 0 ? my_rays : s_nlist;
+    const uint32_t n_front = s_nlist;
+    const uint32_t wg_end = ITEMS_LOG4 == 0 ? my_rays : n_front + s_nback;
 #ifdef BVH_WIDE_PROFILE
     const unsigned long long prof_t1 = wall_clock64();
 #endif
@@ -984,7 +1003,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                             item = NONE;                         // padding of the batch's last 64-ray block
                         }
                     } else {
-                        item = list[mine];
+                        item = list[mine < n_front ? mine : per_wg * ITEMS - 1u - (mine - n_front)];
                         const uint32_t j = item & ((1u << WIDE_ITEM_BITS) - 1u);
                         ray.load(rays, item >> WIDE_ITEM_BITS);
                         cur = j == WIDE_ITEM_WHOLE ? (WIDE_INNER | WIDE_RESIDENT | 0u) : s_item_ref[j];
