@@ -325,11 +325,11 @@ def run_workload(wl, args, env, steps, warmup, detailed):
         bbytes = (32 if elem == 4 else 56) * levels * n + (2 * n - 1) * (64 if elem == 4 else 112)   # SURVEY §8d build bytes
         fbytes = (2 * n - 1) * (64 if elem == 4 else 112) + (3 * n - 2) * flat_sz
         out["roofline_build"] = {
-            "kernels": "k_prep, (k_bin, k_split) x levels, k_mid, k_small, k_flatten, k_wide", "bound": "hbm",
+            "kernels": "k_prep, k_level x (levels + 1), k_mid, k_small, k_flatten", "bound": "hbm",
             "algorithmic_bytes": int(bbytes + fbytes), "ms": round(phases["build_ms"] + phases["flatten_ms"], 4),
             "achieved": round((bbytes + fbytes) / ((phases["build_ms"] + phases["flatten_ms"]) * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round((bbytes + fbytes) / ((phases["build_ms"] + phases["flatten_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "note": "a chain of ~20 dependent launches over a cache-resident working set: latency-bound, not bandwidth-bound "
+            "note": "a chain of ~14 dependent launches over a cache-resident working set: latency-bound, not bandwidth-bound "
                     f"(SURVEY §8d: sum over levels of live shapes = {levels:.1f} x N)",
         }
         out["build_levels"] = bvh.build_levels
