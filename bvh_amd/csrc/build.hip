@@ -707,26 +707,27 @@ template <typename T> struct LevelSel {
 // sah_select by ONE WAVE with the work spread over its lanes (the serial form above is ~1 400 instructions on the critical
 // path of a level; this is ~200): lanes (b, k) build the running prefix / suffix joins of the AABB keys, lanes 0..4 price the
 // five candidate splits — each with exactly the operations of bvh_node.rs:231-238 —, every lane then replays the strict-<
-// first-wins scan over the five costs (:239-247), lanes 0..5 assemble the children's bounds.  st, out, scratch: LDS.
+// first-wins scan over the five costs (:239-247), lanes 0..5 assemble the children's bounds.  stk, stc, out, scratch: LDS.
 template <typename T>
-__device__ __forceinline__ void sah_select_wave(const ItemStats<T>* st, const T* A, bool degen, LevelSel<T>* out,
+__device__ __forceinline__ void sah_select_wave(const typename Traits<T>::Key* stk /* 6 x 12 keys */, const uint32_t* stc /* 6 counts */,
+                                                const T* A, bool degen, LevelSel<T>* out,
                                                 typename Traits<T>::Key* scratch /* 72 keys */, int lane) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
     if (lane < 36) {
         const int b = lane / 6, k = lane % 6;
         const bool mn = k < 3;
-        Key p = st->k[k];
+        Key p = stk[k];
 #pragma unroll
         for (int bb = 1; bb < NUM_BUCKETS; bb++) {
-            const Key x = st->k[bb * STAT_KEYS + k];
+            const Key x = stk[bb * STAT_KEYS + k];
             const Key j = mn ? (x < p ? x : p) : (x > p ? x : p);
             p = bb <= b ? j : p;
         }
-        Key q = st->k[(NUM_BUCKETS - 1) * STAT_KEYS + k];
+        Key q = stk[(NUM_BUCKETS - 1) * STAT_KEYS + k];
 #pragma unroll
         for (int bb = NUM_BUCKETS - 2; bb >= 0; bb--) {
-            const Key x = st->k[bb * STAT_KEYS + k];
+            const Key x = stk[bb * STAT_KEYS + k];
             const Key j = mn ? (x < q ? x : q) : (x > q ? x : q);
             q = bb >= b ? j : q;
         }
@@ -738,7 +739,7 @@ __device__ __forceinline__ void sah_select_wave(const ItemStats<T>* st, const T*
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     uint32_t cnt[NUM_BUCKETS], total = 0;
 #pragma unroll
-    for (int b = 0; b < NUM_BUCKETS; b++) { cnt[b] = st->cnt[b]; total += cnt[b]; }
+    for (int b = 0; b < NUM_BUCKETS; b++) { cnt[b] = stc[b]; total += cnt[b]; }
     T cost = Tr::inf();
     if (lane < NUM_BUCKETS - 1) {
         const int sp = lane;
@@ -775,7 +776,7 @@ __device__ __forceinline__ void sah_select_wave(const ItemStats<T>* st, const T*
             Key kl = mn ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF, kr = kl;
 #pragma unroll
             for (int b = 0; b < NUM_BUCKETS; b++) {
-                const Key x = st->k[b * STAT_KEYS + 6 + k];
+                const Key x = stk[b * STAT_KEYS + 6 + k];
                 const Key jl = mn ? (x < kl ? x : kl) : (x > kl ? x : kl);
                 const Key jr = mn ? (x < kr ? x : kr) : (x > kr ? x : kr);
                 kl = b <= best ? jl : kl;
@@ -1012,7 +1013,7 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             LEVEL_STAMP(7);
-            sah_select_wave<T>(&s_merged, PA, degen, &sel, s_sah, lane);
+            sah_select_wave<T>(s_merged.k, s_merged.cnt, PA, degen, &sel, s_sah, lane);
 #ifdef BVH_LEVEL_PROFILE
             if (L == BVH_LEVEL_PROFILE && threadIdx.x == 0 && blockIdx.x < 1024) g_level_prof[8 * blockIdx.x + 3] = wall_clock64();   // (slot 3: selection done)
 #endif
@@ -1363,6 +1364,9 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
     __shared__ uint8_t s_seg[MAXN];
     __shared__ MidSub<T> s_sub[2][MAXSUB];
     __shared__ Key s_keys[MAXSUB * NUM_BUCKETS * STAT_KEYS];
+    __shared__ LevelSel<T> s_sel[MAXSUB];                     // phase 4a's outcome per sub-node
+    __shared__ uint32_t s_cin[MAXSUB][NUM_BUCKETS];
+    __shared__ Key s_sahscr[MID_THREADS / WAVE][72];
     __shared__ unsigned long long s_wlo[MID_THREADS / WAVE];
     __shared__ uint32_t s_whi[MID_THREADS / WAVE];
     __shared__ uint32_t s_nsub;
@@ -1576,20 +1580,32 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
             }
             __syncthreads();
             MID_T(3);
-            // ---- phase 4: select (wave 0; lane s owns sub-node s)
+            // ---- phase 4a: the SAH selections, one sub-node per wave at a time, each spread over the wave's lanes (lane s of wave 0
+            //      running the serial form for sub-node s took 2.9 µs per level whatever the number of sub-nodes)
+            for (uint32_t sn = (uint32_t)wv; sn < nsub; sn += MID_THREADS / WAVE) {
+                const MidSub<T>* m = &s_sub[cur][sn];
+                if (lane < NUM_BUCKETS) s_cin[sn][lane] = m->base[lane + 1] - m->base[lane];
+                T A[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) A[k] = m->A[k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                sah_select_wave<T>(s_keys + sn * NUM_BUCKETS * STAT_KEYS, s_cin[sn], A, m->degen != 0, &s_sel[sn], s_sahscr[wv], lane);
+            }
+            __syncthreads();
+            // ---- phase 4b: nodes and children (wave 0; lane s owns sub-node s)
             if (wv == 0) {
                 const bool has = (uint32_t)lane < nsub;
                 MidSub<T>* m = &s_sub[cur][has ? lane : 0];
-                uint32_t cnt[NUM_BUCKETS];
                 T AL[6], CL[6], AR[6], CR[6];
                 uint32_t nl = 1, cl = 0, cr = 0;
                 if (has) {
-                    uint32_t cin[NUM_BUCKETS];
+                    const LevelSel<T>* sl = &s_sel[lane];
+                    nl = sl->nl;
 #pragma unroll
-                    for (int b = 0; b < NUM_BUCKETS; b++) cin[b] = m->base[b + 1] - m->base[b];
-                    bool no_winner;
-                    nl = sah_select<T>(s_keys + lane * NUM_BUCKETS * STAT_KEYS, cin, m->A, m->degen != 0, cnt, AL, CL, AR, CR, no_winner);
-                    if (no_winner) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_EMPTY_SPLIT);
+                    for (int k = 0; k < 6; k++) { AL[k] = sl->AL[k]; CL[k] = sl->CL[k]; AR[k] = sl->AR[k]; CR[k] = sl->CR[k]; }
+                    if (sl->no_winner) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_EMPTY_SPLIT);
                     cl = nl; cr = m->count - nl;
                     const uint32_t ni = m->ni, li = ni + 1, ri = li + (2 * nl - 1);  // bvh_node.rs:138-142
                     typename Tr::Node* nd = &a.nodes[ni];
