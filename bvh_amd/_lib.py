@@ -138,7 +138,7 @@ SYMBOLS = [
 TUNE_TRAVERSE_VARIANT = 0
 TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_TRAVERSE_LDS_SLOTS, TUNE_TRAVERSE_LDS_THREADS, TUNE_TRAVERSE_SPLIT = 3, 4, 5, 6
 TUNE_WIDE_ITEMS_LOG4, TUNE_WIDE_STACK_LDS, TUNE_WIDE_WG_PER_CU, TUNE_WIDE_THREADS, TUNE_WIDE_SLOTS = 1, 2, 7, 8, 9
-TUNE_BUILD_LEVEL_LAUNCHES = 10   # builder, level tier: 0 one launch per level (default), 2 k_bin + k_split per level
+TUNE_BUILD_LEVEL_LAUNCHES = 10   # builder, level tier: 1 one launch per level, 2 k_bin + k_split per level, 0 (default) by scene size
 ABI_VERSION = 2
 
 _lib = None

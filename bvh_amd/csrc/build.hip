@@ -1947,10 +1947,16 @@ template <typename T> struct BuildGrid {
 };
 
 // One level-synchronous pass: after pass L (counted from 0) the items of level L are split and their children queued.
-//   two launches per level (BVHGPU_TUNE_BUILD_LEVEL_LAUNCHES = 2): k_bin(L), k_split(L);
-//   one launch per level (default): the root is binned by k_level<ROOT> ahead of pass 0, pass L = k_level(L + 1), which splits
+//   two launches per level (scenes above MID_SCENE_SPLIT shapes; BVHGPU_TUNE_BUILD_LEVEL_LAUNCHES = 2): k_bin(L), k_split(L);
+//   one launch per level (smaller scenes; = 1): the root is binned by k_level<ROOT> ahead of pass 0, pass L = k_level(L + 1), which splits
 //   level L and bins level L + 1 in the same launch.
-template <typename T> static bool level_fused(const bvhgpu_tree* t) { return t->ctx->tune[BVHGPU_TUNE_BUILD_LEVEL_LAUNCHES] != 2; }
+// Which schedule: the fused launch shortens the dependent chain (what small scenes are bound by: 0.200 against 0.220 ms at
+// 120 k shapes) and does more work per shape (selection per tile, three rotating accumulator sets, binning inside the rewrite:
+// 0.374 against 0.349 ms at 360 k, 10.5 against 8.4 ms at 12 M) — so it is used up to MID_SCENE_SPLIT shapes.
+template <typename T> static bool level_fused(const bvhgpu_tree* t) {
+    const int v = t->ctx->tune[BVHGPU_TUNE_BUILD_LEVEL_LAUNCHES];
+    return v == 1 || (v != 2 && t->n <= MID_SCENE_SPLIT);
+}
 template <typename T> static void run_level(bvhgpu_tree* t, const BuildArgs<T>& a, const BuildGrid<T>& g, int L) {
     hipStream_t st = t->ctx->stream;
     if (level_fused<T>(t)) {

@@ -315,8 +315,9 @@ typedef enum {
     BVHGPU_TUNE_WIDE_WG_PER_CU = 7,        /* variant 3: workgroups sharing a CU's LDS (default 0 = 2) */
     BVHGPU_TUNE_WIDE_THREADS = 8,          /* variant 3: workgroup size (default 0 = per type: f32 1024, f64 512) */
     BVHGPU_TUNE_WIDE_SLOTS = 9,            /* variant 3: cap on the top-of-tree wide nodes kept in LDS (default 0 = what fits) */
-    BVHGPU_TUNE_BUILD_LEVEL_LAUNCHES = 10, /* builder, level tier: 0 (default) one launch per tree level (k_level: split of level L-1 and binning of
-                                              level L fused, the selection recomputed per tile); 2 = two launches per level (k_bin, k_split) */
+    BVHGPU_TUNE_BUILD_LEVEL_LAUNCHES = 10, /* builder, level tier: 1 = one launch per tree level (k_level: split of level L-1 and binning of level L fused,
+                                              the selection recomputed per tile: the shorter chain, more work per shape); 2 = two launches per level
+                                              (k_bin, k_split); 0 (default) = by scene size: 1 up to 250 000 shapes, 2 above */
     BVHGPU_TUNE_COUNT = 12
 } bvhgpu_tune;
 int bvhgpu_set_tuning(bvhgpu_ctx *ctx, int knob, int value);
