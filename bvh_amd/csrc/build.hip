@@ -48,9 +48,15 @@ constexpr uint32_t BUILD_FLAG_EMPTY_SPLIT = 2u;  // some node had no winning SAH
 // At 120 k there is about one such node per CU and the tier is a latency chain (more threads per node help); from a few hundred
 // thousand triangles on there are several per CU and it is throughput (fewer, fatter workgroups and one level-tier pass less help).
 // Hence two instantiations, chosen by the shape count at launch (BuildArgs::mid_max is the level tier's hand-over size).
+#ifndef BVH_MID_SMALL_MAXN
+#define BVH_MID_SMALL_MAXN 768
+#endif
+#ifndef BVH_MID_SMALL_THREADS
+#define BVH_MID_SMALL_THREADS 384
+#endif
 template <typename T> struct MidSmallScene {   // up to MID_SCENE_SPLIT shapes
-    static constexpr int MAXN = 768;
-    static constexpr int THREADS = 384;
+    static constexpr int MAXN = BVH_MID_SMALL_MAXN;
+    static constexpr int THREADS = BVH_MID_SMALL_THREADS;
     static constexpr int HANDOFF = SMALL_MAX;
 };
 template <typename T> struct MidLargeScene {
