@@ -836,7 +836,7 @@ void bvhgpu_hits_destroy(bvhgpu_hits* h) {
     if (!h) return;
     if (h->ctx) { (void)hipSetDevice(h->ctx->device); (void)hipStreamSynchronize(h->ctx->stream); }
     h->counts.release(); h->offsets.release(); h->pool.release(); h->pool_t.release();
-    h->indices.release(); h->tslice.release(); h->blocksums.release(); h->bsum64.release(); h->ctr.release();
+    h->indices.release(); h->tslice.release(); h->blocksums.release(); h->scan_sums.release(); h->ctr.release();
     h->isect.release(); h->closest.release(); h->closest_prim.release();
     h->heap_dist.release(); h->heap_node.release();
     h->wcounts.release(); h->ray_mask.release(); h->item_cnt.release(); h->wstack.release(); h->ray_items.release(); h->witems.release();

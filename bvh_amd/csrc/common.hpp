@@ -273,6 +273,25 @@ __device__ __forceinline__ bool slab_hit_finite_len(const T o[3], const T inv[3]
     len = tmx - t0;
     return tmx >= t0;
 }
+template <>
+__device__ __forceinline__ bool slab_hit_finite_len<float>(const float o[3], const float inv[3], const float mn[3], const float mx[3],
+                                                           float& len) {
+    float l0 = (mn[0] - o[0]) * inv[0], h0 = (mx[0] - o[0]) * inv[0];
+    float l1 = (mn[1] - o[1]) * inv[1], h1 = (mx[1] - o[1]) * inv[1];
+    float l2 = (mn[2] - o[2]) * inv[2], h2 = (mx[2] - o[2]) * inv[2];
+    float a0, a1, a2, b0, b1, b2, tmn, tmx, t0;
+    asm("v_min_f32 %0, %1, %2" : "=v"(a0) : "v"(l0), "v"(h0));
+    asm("v_max_f32 %0, %1, %2" : "=v"(b0) : "v"(l0), "v"(h0));
+    asm("v_min_f32 %0, %1, %2" : "=v"(a1) : "v"(l1), "v"(h1));
+    asm("v_max_f32 %0, %1, %2" : "=v"(b1) : "v"(l1), "v"(h1));
+    asm("v_min_f32 %0, %1, %2" : "=v"(a2) : "v"(l2), "v"(h2));
+    asm("v_max_f32 %0, %1, %2" : "=v"(b2) : "v"(l2), "v"(h2));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmn) : "v"(a0), "v"(a1), "v"(a2));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmx) : "v"(b0), "v"(b1), "v"(b2));
+    asm("v_max_f32 %0, 0, %1" : "=v"(t0) : "v"(tmn));
+    len = tmx - t0;
+    return tmx >= t0;
+}
 template <typename T> __device__ __forceinline__ bool ray_is_finite(const T o[3], const T inv[3]) {
     bool f = true;
 #pragma unroll

@@ -122,7 +122,7 @@ struct bvhgpu_hits {
     bvhgpu::DevBuf closest;  // n_rays * 3 T (CLOSEST)
     bvhgpu::DevBuf closest_prim;  // n_rays u32
     bvhgpu::DevBuf blocksums;
-    bvhgpu::DevBuf bsum64;    // wide walk: two sets of hits per scan block (k_scan_final's input instead of a reduce pass), kept zero
+    bvhgpu::DevBuf scan_sums;    // wide walk: two sets of hits per scan block (k_scan_final's input instead of a reduce pass), kept zero
     bvhgpu::DevBuf ctr;      // [0] pool count (u64) [1] visited [2] leaf_visits [3] device_steps [4] ray ticket
     bvhgpu::DevBuf heap_dist, heap_node;  // best-first traversal: the part of the lanes' heaps that does not fit in LDS
     uint32_t heap_cap = 48;  // ... entries per lane (doubles when a batch overflows it)

@@ -72,7 +72,7 @@ template <typename T> struct WalkOut {
     uint32_t* closest_prim;      // per ray shape index or NONE
     uint32_t* item_cnt;          // wide walk with several items per ray: hits of item (ray, j), written only when non-zero
     uint32_t* ray_items;         // ... and per ray the set of j that wrote one (kept all-zero between batches like counts)
-    uint32_t* bsum64;         // wide walk: hits per SCAN_BLOCK rays, added up by the workgroups as they finish (a zeroed set; NULL: k_scan_reduce does the sums)
+    uint32_t* scan_sums;         // wide walk: hits per SCAN_BLOCK rays, added up by the workgroups as they finish (a zeroed set; NULL: k_scan_reduce does the sums)
 };
 
 // ---- Ray::intersects_triangle (ray_impl.rs:154-213), Möller–Trumbore with back-face culling.  Same
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     // the end — the CSR scan then needs no reduce pass over the counts.  (LDS atomics: adding straight into global sums put
     // the BASELINE stream's 10 000 hits on one cache line, 128 → 162 µs.)
     __shared__ uint32_t s_bsum[WIDE_BSUM_MAX];
-    if (w.bsum64) for (uint32_t b = tid; b < WIDE_BSUM_MAX; b += bd) s_bsum[b] = 0u;
+    if (w.scan_sums) for (uint32_t b = tid; b < WIDE_BSUM_MAX; b += bd) s_bsum[b] = 0u;
     if (tid == 0) { s_next = 0u; s_nlist = 0u; s_nback = 0u; }
     for (uint32_t q = tid; q < K; q += bd) {
         const uint32_t node = wslot_node[q];
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                         atomicOr(&w.ray_items[r], 1u << jj);
                         w.item_cnt[((size_t)r << (2 * ITEMS_LOG4)) + jj] = ray.cnt;
                     }
-                    if (w.bsum64) atomicAdd(&s_bsum[((r >> 6) - blockIdx.x) / gridDim.x], ray.cnt);
+                    if (w.scan_sums) atomicAdd(&s_bsum[((r >> 6) - blockIdx.x) / gridDim.x], ray.cnt);
                 }
                 item = NONE;
             }
@@ -1053,12 +1053,12 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     }
     if (__any(ovf) && lane == 0) atomicOr(overflow, 4u);
     walk_epilogue<T, MODE>(w, pc, lane, false, 0, 0, 0, 0);
-    if (MODE != MODE_CLOSEST && w.bsum64) {   // every wave of the workgroup gets here: all items of its rays have retired
+    if (MODE != MODE_CLOSEST && w.scan_sums) {   // every wave of the workgroup gets here: all items of its rays have retired
         __syncthreads();
         // one atomic per 64-ray block that has hits, on the sum of its scan block (workgroups finish at different times and a
         // scan block's 16 sums come from 16 workgroups: nothing like the per-item atomics that were tried first)
         for (uint32_t b = tid; b < my_blocks; b += bd)
-            if (s_bsum[b]) atomicAdd(&w.bsum64[(b * gridDim.x + blockIdx.x) / (uint32_t)(SCAN_BLOCK / 64)], s_bsum[b]);
+            if (s_bsum[b]) atomicAdd(&w.scan_sums[(b * gridDim.x + blockIdx.x) / (uint32_t)(SCAN_BLOCK / 64)], s_bsum[b]);
     }
 #ifdef BVH_WIDE_PROFILE
     if (lane == 0) {
@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__
                                                     unsigned long long* __restrict__ total,
                                                     uint32_t* __restrict__ offsets, uint32_t* __restrict__ ray_items,
                                                     uint16_t* __restrict__ ray_mask, unsigned long long* __restrict__ host_page,
-                                                    unsigned long long* __restrict__ other_ctr, const uint32_t* __restrict__ bsum64,
+                                                    unsigned long long* __restrict__ other_ctr, const uint32_t* __restrict__ scan_sums,
                                                     uint32_t* __restrict__ other_bsum, uint32_t bsum_cap) {
     __shared__ uint32_t ws[4];
     __shared__ unsigned long long wb[4];
@@ -1140,8 +1140,8 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t* __restrict__
         before = blocksums[blockIdx.x];
     } else {
         unsigned long long part = 0;
-        if (bsum64) {   // the walk left the sums (u32) in this batch's set; the other set is zeroed here for the next batch
-            for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256) part += bsum64[j];
+        if (scan_sums) {   // the walk left the sums (u32) in this batch's set; the other set is zeroed here for the next batch
+            for (uint32_t j = threadIdx.x; j < blockIdx.x; j += 256) part += scan_sums[j];
             if (threadIdx.x == 0) other_bsum[blockIdx.x] = 0u;
             if (blockIdx.x == gridDim.x - 1)   // (a previous, larger batch may have left more behind)
                 for (uint32_t j = gridDim.x + threadIdx.x; j < bsum_cap; j += 256) other_bsum[j] = 0u;
@@ -1407,7 +1407,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
 
     WalkOut<T> w;
     w.counts = nullptr; w.pool = nullptr; w.pool_v = nullptr; w.pool_cap = 0; w.ctr = ctr;
-    w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr; w.item_cnt = nullptr; w.ray_items = nullptr; w.bsum64 = nullptr;
+    w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr; w.item_cnt = nullptr; w.ray_items = nullptr; w.scan_sums = nullptr;
 
     uint32_t* ovf_flag = reinterpret_cast<uint32_t*>(ctr + 7);   // bit 0 ordered-iterator stack, bit 1 heap workspace, bit 2 wide-walk stack
     const bool best_first = ordered && (flags & BVHGPU_TRAVERSE_BEST_FIRST) != 0;
@@ -1522,9 +1522,9 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
             const size_t n_blocks = (n_rays + 63) / 64;
             if (nb <= SCAN_FUSED_MAX_BLOCKS && (n_blocks + grid - 1) / grid <= WIDE_BSUM_MAX) {
                 // two sets of SCAN_FUSED_MAX_BLOCKS sums, used alternately like the counter sets (k_scan_final zeroes the other one)
-                if (h->bsum64.reserve(2 * SCAN_FUSED_MAX_BLOCKS * 4)) BVH_HIP(hipMemsetAsync(h->bsum64.p, 0, h->bsum64.cap, st));
-                w.bsum64 = h->bsum64.as<uint32_t>() + (size_t)SCAN_FUSED_MAX_BLOCKS * (h->bsum_set & 1);
-                bsum_other = h->bsum64.as<uint32_t>() + (size_t)SCAN_FUSED_MAX_BLOCKS * ((h->bsum_set & 1) ^ 1);
+                if (h->scan_sums.reserve(2 * SCAN_FUSED_MAX_BLOCKS * 4)) BVH_HIP(hipMemsetAsync(h->scan_sums.p, 0, h->scan_sums.cap, st));
+                w.scan_sums = h->scan_sums.as<uint32_t>() + (size_t)SCAN_FUSED_MAX_BLOCKS * (h->bsum_set & 1);
+                bsum_other = h->scan_sums.as<uint32_t>() + (size_t)SCAN_FUSED_MAX_BLOCKS * ((h->bsum_set & 1) ^ 1);
                 h->bsum_set ^= 1;   // (this batch's k_scan_final zeroes the other set: the next batch's)
             }
         }
@@ -1544,14 +1544,14 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     const int kind = use_wide ? COUNT_MASKED : (split_at ? COUNT_PAIR : COUNT_PLAIN);
     auto scan = [&](auto kind_tag) {
         constexpr int KD = decltype(kind_tag)::value;
-        if (!w.bsum64) hipLaunchKernelGGL(k_scan_reduce<KD>, dim3(nb), dim3(256), 0, st, counts, nr, bs);
+        if (!w.scan_sums) hipLaunchKernelGGL(k_scan_reduce<KD>, dim3(nb), dim3(256), 0, st, counts, nr, bs);
         if (nb > SCAN_FUSED_MAX_BLOCKS) {
             hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, bs, nb, ctr + 3);
             hipLaunchKernelGGL((k_scan_final<KD, true>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, ritems, rmask,
                                (unsigned long long*)nullptr, (unsigned long long*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
         } else {
             hipLaunchKernelGGL((k_scan_final<KD, false>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, ritems, rmask, pin, ctr_other,
-                               (const uint32_t*)w.bsum64, bsum_other, (uint32_t)SCAN_FUSED_MAX_BLOCKS);
+                               (const uint32_t*)w.scan_sums, bsum_other, (uint32_t)SCAN_FUSED_MAX_BLOCKS);
         }
     };
     if (kind == COUNT_MASKED) scan(std::integral_constant<int, COUNT_MASKED>{});
