@@ -1248,53 +1248,55 @@ void debug_level_prof(unsigned long long* out, size_t n) {
 // value: row_bcast:15 / :31 upwards, v_readlane of lanes 48 / 32 / 16 downwards.  A lane only ever joins a partner of
 // its own run.  `span`: an upper bound (power of two) on the length of the live runs: the steps beyond are skipped.
 // ------------------------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ void join12(T (&a)[STAT_KEYS], const T (&b)[STAT_KEYS]) {
+// N values, in groups of six: three minima, three maxima (N = 12: the statistic keys' order)
+template <typename T, int N> __device__ __forceinline__ void join12(T (&a)[N], const T (&b)[N]) {
+    static_assert(N % 6 == 0, "min3 max3 groups");
 #pragma unroll
-    for (int k = 0; k < STAT_KEYS; k++) a[k] = key_is_min(k) ? join_min(a[k], b[k]) : join_max(a[k], b[k]);
+    for (int k = 0; k < N; k++) a[k] = (k % 6) < 3 ? join_min(a[k], b[k]) : join_max(a[k], b[k]);
 }
-template <typename T, int D> __device__ __forceinline__ void seg_prefix_step(T (&P)[STAT_KEYS], int lane, int lo) {
-    T u[STAT_KEYS];
+template <typename T, int D, int N> __device__ __forceinline__ void seg_prefix_step(T (&P)[N], int lane, int lo) {
+    T u[N];
 #pragma unroll
-    for (int k = 0; k < STAT_KEYS; k++) u[k] = dpp_fetch<0x110 + D>(P[k]);
-    if (lane - D >= lo) join12(P, u);
+    for (int k = 0; k < N; k++) u[k] = dpp_fetch<0x110 + D>(P[k]);
+    if (lane - D >= lo) join12<T, N>(P, u);
 }
-template <typename T, int D> __device__ __forceinline__ void seg_suffix_step(T (&S)[STAT_KEYS], int lane, int hi) {
-    T u[STAT_KEYS];
+template <typename T, int D, int N> __device__ __forceinline__ void seg_suffix_step(T (&S)[N], int lane, int hi) {
+    T u[N];
 #pragma unroll
-    for (int k = 0; k < STAT_KEYS; k++) u[k] = dpp_fetch<0x100 + D>(S[k]);
-    if (lane + D < hi) join12(S, u);
+    for (int k = 0; k < N; k++) u[k] = dpp_fetch<0x100 + D>(S[k]);
+    if (lane + D < hi) join12<T, N>(S, u);
 }
-template <typename T> __device__ __forceinline__ void seg_prefix_scan(T (&P)[STAT_KEYS], int lane, int lo, int span) {
-    if (span > 1) seg_prefix_step<T, 1>(P, lane, lo);
-    if (span > 2) seg_prefix_step<T, 2>(P, lane, lo);
-    if (span > 4) seg_prefix_step<T, 4>(P, lane, lo);
-    if (span > 8) seg_prefix_step<T, 8>(P, lane, lo);
+template <typename T, int N> __device__ __forceinline__ void seg_prefix_scan(T (&P)[N], int lane, int lo, int span) {
+    if (span > 1) seg_prefix_step<T, 1, N>(P, lane, lo);
+    if (span > 2) seg_prefix_step<T, 2, N>(P, lane, lo);
+    if (span > 4) seg_prefix_step<T, 4, N>(P, lane, lo);
+    if (span > 8) seg_prefix_step<T, 8, N>(P, lane, lo);
     const int row0 = lane & ~15;   // first lane of this lane's row
     if (__any(lo < row0)) {        // a run that began in an earlier row takes the finished prefix of the row below
-        T u[STAT_KEYS];
+        T u[N];
 #pragma unroll
-        for (int k = 0; k < STAT_KEYS; k++) u[k] = dpp_fetch<0x142, 0xA>(P[k]);   // rows 1 and 3 from lanes 15 / 47
-        if ((lane & 16) && lo < row0) join12(P, u);
+        for (int k = 0; k < N; k++) u[k] = dpp_fetch<0x142, 0xA>(P[k]);   // rows 1 and 3 from lanes 15 / 47
+        if ((lane & 16) && lo < row0) join12<T, N>(P, u);
 #pragma unroll
-        for (int k = 0; k < STAT_KEYS; k++) u[k] = dpp_fetch<0x143, 0xC>(P[k]);   // rows 2 and 3 from lane 31 (complete by now)
-        if (lane >= 32 && lo < 32) join12(P, u);
+        for (int k = 0; k < N; k++) u[k] = dpp_fetch<0x143, 0xC>(P[k]);   // rows 2 and 3 from lane 31 (complete by now)
+        if (lane >= 32 && lo < 32) join12<T, N>(P, u);
     }
 }
-template <typename T, int ROW> __device__ __forceinline__ void seg_suffix_carry(T (&S)[STAT_KEYS], int lane, int hi) {
-    T u[STAT_KEYS];
+template <typename T, int ROW, int N> __device__ __forceinline__ void seg_suffix_carry(T (&S)[N], int lane, int hi) {
+    T u[N];
 #pragma unroll
-    for (int k = 0; k < STAT_KEYS; k++) u[k] = lane_bcast<16 * (ROW + 1)>(S[k]);
-    if ((lane & ~15) == 16 * ROW && hi > 16 * (ROW + 1)) join12(S, u);
+    for (int k = 0; k < N; k++) u[k] = lane_bcast<16 * (ROW + 1)>(S[k]);
+    if ((lane & ~15) == 16 * ROW && hi > 16 * (ROW + 1)) join12<T, N>(S, u);
 }
-template <typename T> __device__ __forceinline__ void seg_suffix_scan(T (&S)[STAT_KEYS], int lane, int hi, int span) {
-    if (span > 1) seg_suffix_step<T, 1>(S, lane, hi);
-    if (span > 2) seg_suffix_step<T, 2>(S, lane, hi);
-    if (span > 4) seg_suffix_step<T, 4>(S, lane, hi);
-    if (span > 8) seg_suffix_step<T, 8>(S, lane, hi);
+template <typename T, int N> __device__ __forceinline__ void seg_suffix_scan(T (&S)[N], int lane, int hi, int span) {
+    if (span > 1) seg_suffix_step<T, 1, N>(S, lane, hi);
+    if (span > 2) seg_suffix_step<T, 2, N>(S, lane, hi);
+    if (span > 4) seg_suffix_step<T, 4, N>(S, lane, hi);
+    if (span > 8) seg_suffix_step<T, 8, N>(S, lane, hi);
     if (__any(hi > (lane & ~15) + 16)) {   // top row first: a run that continues into the next row takes that row's first lane
-        seg_suffix_carry<T, 2>(S, lane, hi);
-        seg_suffix_carry<T, 1>(S, lane, hi);
-        seg_suffix_carry<T, 0>(S, lane, hi);
+        seg_suffix_carry<T, 2, N>(S, lane, hi);
+        seg_suffix_carry<T, 1, N>(S, lane, hi);
+        seg_suffix_carry<T, 0, N>(S, lane, hi);
     }
 }
 
@@ -1564,7 +1566,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
                 {
                     const int len = lane - chain0;   // lanes of this lane's chain below it
                     const int span = __any(len >= 8) ? 16 : (__any(len >= 4) ? 8 : (__any(len >= 2) ? 4 : (__any(len >= 1) ? 2 : 1)));
-                    seg_prefix_scan<T>(sv, lane, chain0, span);
+                    seg_prefix_scan<T, STAT_KEYS>(sv, lane, chain0, span);
                 }
                 // the first run of a multi-run thread ends here: join the carry of the previous lane, flush
                 {
@@ -1793,16 +1795,14 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
 
         // ---- segmented inclusive prefix (P) and suffix (S) joins of AABB and centroid bounds over the lanes of the segment
         //      (seg_prefix_scan / seg_suffix_scan above: DPP inside a row, one-lane carries across rows)
-        T P[12], S[12];
+        // (the AABBs only: the children's centroid bounds are reduced over the NEW segments once the split is known — 18
+        //  scanned values and 18 fetches per level instead of 24 and 24)
+        T P[6], S[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) { P[k] = box[k]; S[k] = box[k]; }
-#pragma unroll
-        for (int k = 0; k < 3; k++) { P[6 + k] = c[k]; P[9 + k] = c[k]; S[6 + k] = c[k]; S[9 + k] = c[k]; }
-        {
-            const int span = __any(!done && segn > 8) ? 16 : (__any(!done && segn > 4) ? 8 : (__any(!done && segn > 2) ? 4 : (__any(!done && segn > 1) ? 2 : 1)));
-            seg_prefix_scan<T>(P, lane, lo, span);
-            seg_suffix_scan<T>(S, lane, hi, span);
-        }
+        const int span = __any(!done && segn > 8) ? 16 : (__any(!done && segn > 4) ? 8 : (__any(!done && segn > 2) ? 4 : (__any(!done && segn > 1) ? 2 : 1)));
+        seg_prefix_scan<T, 6>(P, lane, lo, span);
+        seg_suffix_scan<T, 6>(S, lane, hi, span);
         // ---- SAH cost of the 5 candidates (:231-247): L = prefix at the last lane of bucket <= s,
         //      R = suffix at the first lane of bucket > s
         const T saP = surface_area(P), saS = surface_area(S);
@@ -1836,13 +1836,19 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
         T AL[6], AR[6], Cn[6];
         const bool left = lane < q;
         {
-            T kl[12], kr[12];
 #pragma unroll
-            for (int k = 0; k < 12; k++) kl[k] = lane_fetch(P[k], ql4);
+            for (int k = 0; k < 6; k++) AL[k] = lane_fetch(P[k], ql4);
 #pragma unroll
-            for (int k = 0; k < 12; k++) kr[k] = lane_fetch(S[k], qr4);
+            for (int k = 0; k < 6; k++) AR[k] = lane_fetch(S[k], qr4);
+            // centroid bounds of the lane's child = join over its new segment [nlo, nhi): prefix scan + the last lane's value
+            const int nlo = done ? lane : (left ? lo : q), nhi = done ? lane + 1 : (left ? q : hi);
+            T Cq[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) { AL[k] = kl[k]; AR[k] = kr[k]; Cn[k] = left ? kl[6 + k] : kr[6 + k]; }
+            for (int k = 0; k < 3; k++) { Cq[k] = c[k]; Cq[3 + k] = c[k]; }
+            seg_prefix_scan<T, 6>(Cq, lane, nlo, span);
+            const int last4 = min(max(nhi - 1, 0), 63) << 2;
+#pragma unroll
+            for (int k = 0; k < 6; k++) Cn[k] = lane_fetch(Cq[k], last4);
         }
         if (!taken) { box_empty(AL); box_empty(AR); box_empty(Cn); }
         if (!done && !taken && lane == lo) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_EMPTY_SPLIT);
