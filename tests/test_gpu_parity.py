@@ -1013,6 +1013,18 @@ def test_fuzz_all_queries(eng, orc, seed):
         assert np.allclose(ts, ots, rtol=1e-5 if dtype == np.float32 else 1e-12, atol=0)
     toff, tidx = orc.traverse_tree(ot.nodes, aabbs, rays)               # Bvh::traverse == FlatBvh::traverse
     assert np.array_equal(toff, ooff) and np.array_equal(tidx, oidx)
+    # the large-batch walk (four grandchildren per step, rays cut into items) on the same small batch, and the two level-tier
+    # schedules of the builder alternating with the seed
+    from bvh_amd import Context
+    from bvh_amd._lib import TUNE_BUILD_LEVEL_LAUNCHES, TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_WIDE_ITEMS_LOG4
+    wctx = Context(0)
+    wctx.set_tuning(TUNE_TRAVERSE_LDS_MIN_RAYS, 0)
+    wctx.set_tuning(TUNE_WIDE_ITEMS_LOG4, (seed // 2) % 3)
+    wctx.set_tuning(TUNE_BUILD_LEVEL_LAUNCHES, 1 + seed % 2)
+    wb = eng.Bvh.from_aabbs(aabbs, wctx)
+    assert wb.nodes.tobytes() == ot.nodes.tobytes()
+    woff, widx, _, _ = wb.flatten().traverse_batch(eng.RayBatch(len(rays), dtype, host=np.ascontiguousarray(rays)))
+    assert np.array_equal(woff, ooff) and np.array_equal(widx, oidx)
     oisect, oclosest, oprim = orc.triangle_stage(tri, rays, ooff, oidx)
     _, _, isect, _ = flat.intersect_triangles(rb)
     cl, prim, _ = flat.closest_hits(rb)
