@@ -1931,7 +1931,7 @@ template <typename T> static BuildArgs<T> make_args(bvhgpu_tree* t, const T* src
     // level tier with one launch per level (LevelArgs): carved out of t->lvbuf by level_layout()
     const LevelLayout<T> ly(t->n, a.mid_max);
     a.lv.slot_div = a.mid_max + 1u; a.lv.n_slots = (uint32_t)ly.n_slots; a.lv.n_tiles = (uint32_t)ly.n_tiles;
-    char* base = reinterpret_cast<char*>(t->lvbuf.p);
+    char* base = t->lvbuf.cap >= ly.bytes ? reinterpret_cast<char*>(t->lvbuf.p) : nullptr;   // (only sized when that schedule is used)
     for (int i = 0; i < 3; i++) {
         a.lv.tile_map[i] = base ? reinterpret_cast<uint4*>(base + ly.off_tile_item + i * ly.sz_tile_item) : nullptr;
         a.lv.tile_cnt[i] = base ? reinterpret_cast<uint32_t*>(base + ly.off_tile_cnt + i * ly.sz_tile_cnt) : nullptr;
@@ -2018,7 +2018,7 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     t->idx[0].reserve(n * 4);
     t->idx[1].reserve(n * 4);
     t->bk.reserve(2 * n);   // (the one-launch-per-level tier keeps the buckets of two consecutive levels)
-    t->lvbuf.reserve(LevelLayout<T>(n, MID_MAX).bytes);
+    if (level_fused<T>(t) && n > (size_t)MID_MAX) t->lvbuf.reserve(LevelLayout<T>(n, MID_MAX).bytes);
     for (int i = 0; i < 2; i++) {
         t->big[i].reserve(g.max_big * sizeof(Item<T>));
         t->stats[i].reserve(g.max_big * STAT_REP * sizeof(ItemStats<T>));
