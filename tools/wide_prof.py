@@ -45,3 +45,11 @@ wg_end = end.reshape(-1, 16).max(axis=1) if len(end) % 16 == 0 else end
 wg_pro = pro.reshape(-1, 16).max(axis=1) if len(pro) % 16 == 0 else pro
 print(f"per subtree (wg % 16) end: " + " ".join(f"{wg_end[j::16].mean():.0f}" for j in range(16)))
 print(f"workgroup end   : mean {wg_end.mean():7.2f}  min {wg_end.min():7.2f}  max {wg_end.max():7.2f} us")
+
+if len(wg_end) >= 512:
+    print("workgroup end by workgroup range (mean / max): " + "  ".join(f"[{a}:{a + 64}) {wg_end[a:a + 64].mean():.0f}/{wg_end[a:a + 64].max():.0f}" for a in range(0, 512, 64)))
+    wg_steps = steps.reshape(-1, 16).mean(axis=1)
+    print("prologue end by range: " + "  ".join(f"[{a}:{a + 64}) {wg_pro[a:a + 64].mean():.1f}" for a in range(0, 512, 64)))
+    print("mean wave-steps by range: " + "  ".join(f"[{a}:{a + 64}) {wg_steps[a:a + 64].mean():.1f}" for a in range(0, 512, 64)))
+    order = np.argsort(wg_end)
+    print("slowest workgroups:", order[-12:][::-1].tolist(), " fastest:", order[:8].tolist())
