@@ -109,6 +109,30 @@ def test_async_step_matches_sync(eng, orc):
     assert lanes[0][1].nodes.tobytes() == ot.nodes.tobytes()
 
 
+def test_result_object_across_batch_sizes(eng, orc):
+    """One result object through batches of very different sizes: the wide walk keeps its per-ray words, the scan-block sums
+    (two sets, used alternately) and the counter sets zero BETWEEN batches instead of clearing them — a batch above 2 M rays
+    takes the path with a reduce pass and a publishing launch in between."""
+    import torch
+    from bvh_amd import Bvh, Context, RayBatch, testbase as tb
+    from bvh_amd._lib import RAY_F32
+    from bvh_amd.api import _Hits
+    ctx = Context(0)
+    bounds = tb.default_bounds()
+    _, aabbs = tb.create_n_cubes(3000)
+    bvh = Bvh.from_aabbs(torch.from_numpy(aabbs).cuda(), ctx)
+    bvh.flatten_in_place()
+    oflat = orc.flatten(orc.build(aabbs).nodes)
+    hits = _Hits(ctx)
+    for R in (100_000, 2_300_000, 120_000, 40_000, 100_000, 20_000, 100_000):
+        buf = torch.empty(R * RAY_F32.itemsize, dtype=torch.uint8, device="cuda")
+        rays = RayBatch.generate(3, R, bounds, buf, np.float32, ctx)
+        st = bvh.traverse_async(rays, hits).wait()
+        off, idx = hits.fetch(R)
+        ooff, oidx, _, _ = orc.traverse_flat(oflat, aabbs, orc.create_rays(3, R), threads=orc.max_threads())
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx) and st["hits"] == len(oidx), R
+
+
 def test_async_step_unbalanced_tree_and_bad_input(eng, orc):
     """What the optimistic asynchronous launch cannot know is settled at the wait: an unbalanced tree is finished and the
     batch replayed; invalid input surfaces as the status the synchronous call would have returned."""
