@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("BVH_AMD_SO") or os.path.join(HERE, "libbvh_mi355x.so")  # BVH_AMD_SO: developer profiling builds only
 
-OK, INVALID_ARG, HIP_ERROR, OOM, OVERFLOW, NO_DEVICE, DTYPE_MISMATCH, NOT_FLATTENED, RCCL_ERROR = range(9)
+OK, INVALID_ARG, HIP_ERROR, OOM, OVERFLOW, NO_DEVICE, DTYPE_MISMATCH, NOT_FLATTENED, RCCL_ERROR, REBROADCAST = range(10)
 COMM_ID_BYTES = 128
 BCAST_TRIANGLES = 1
 F32, F64 = 0, 1
@@ -139,7 +139,7 @@ TUNE_TRAVERSE_VARIANT = 0
 TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_TRAVERSE_LDS_SLOTS, TUNE_TRAVERSE_LDS_THREADS, TUNE_TRAVERSE_SPLIT = 3, 4, 5, 6
 TUNE_WIDE_ITEMS_LOG4, TUNE_WIDE_STACK_LDS, TUNE_WIDE_WG_PER_CU, TUNE_WIDE_THREADS, TUNE_WIDE_SLOTS = 1, 2, 7, 8, 9
 TUNE_BUILD_LEVEL_LAUNCHES = 10   # builder, level tier: 1 one launch per level, 2 k_bin + k_split per level, 0 (default) by scene size
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 

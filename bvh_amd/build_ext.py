@@ -40,9 +40,7 @@ def is_stale() -> bool:
 
 def build_variant(out: str, defines, verbose: bool = True) -> str:
     """developer builds with extra -D flags (instrumentation, tuning sweeps) into another file; load with BVH_AMD_SO=<out>"""
-    rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
-    cmd = [hipcc()] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES] + \
-          [f"-L{rocm_lib}", "-lrccl", f"-Wl,-rpath,{rocm_lib}"]
+    cmd = [hipcc()] + FLAGS + [f"-D{d}" for d in defines] + ["-o", out] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)
@@ -52,10 +50,9 @@ def build_variant(out: str, defines, verbose: bool = True) -> str:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return OUT
-    # librccl: the multi-GPU broadcast of the C ABI (comm.hip).  PyTorch-ROCm bundles its own librccl.so with the same soname
-    # (librccl.so.1): when torch is imported first (bvh_amd/_lib.py does that) the loader reuses that copy, like libamdhip64.
-    rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
-    cmd = [hipcc()] + FLAGS + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES] + [f"-L{rocm_lib}", "-lrccl", f"-Wl,-rpath,{rocm_lib}"]
+    # RCCL (the multi-GPU broadcast of the C ABI, comm.hip) is NOT linked: comm.hip dlopen()s librccl.so.1 on first use — a copy the
+    # process already holds (PyTorch-ROCm bundles one) is shared, single-GPU consumers need none.  <rccl/rccl.h> is used for types only.
+    cmd = [hipcc()] + FLAGS + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES] + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)

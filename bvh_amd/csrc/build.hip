@@ -1995,7 +1995,8 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     using Key = typename Tr::Key;
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
-    t->built = false; t->flattened = false; t->pending_build = false; t->exact_only = false; t->redone = false;
+    t->built = false; t->flattened = false; t->pending_build = false; t->exact_only = false; t->pending_recv = false;
+    t->gen++;   // results enqueued from here on belong to this build (bvhgpu_hits_wait compares generations)
     if (n != t->n) t->has_tris = false;   // one triangle per shape: a different shape count invalidates the vertex array
     t->n = n; t->n_nodes = n ? 2 * n - 1 : 0;
     t->n_flat = n >= 2 ? 3 * n - 2 : n;
@@ -2061,7 +2062,12 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     run_lower_tiers<T>(t, a, g, 0u, 0u);
     // counters: readback through the pinned page + reset for the next build, by the flatten kernel when there is one
     // (optimistic too: redone if the build turns out to be unfinished) and by a launch of their own otherwise
-    if (flatten_after && n >= 1) flatten_tree<T>(t, a.ctr, reinterpret_cast<uint32_t*>(t->pin), (uint32_t)(ROOTKEY_OFF / 4));
+    // (the same block leaves a status word in HBM — build flags + "level queue not empty" — for a broadcast that is enqueued
+    //  before the host has looked at the counters: comm.hip bvhgpu_bcast_known)
+    t->bstat.reserve(64);
+    if (flatten_after && n >= 1)
+        flatten_tree<T>(t, a.ctr, reinterpret_cast<uint32_t*>(t->pin), (uint32_t)(ROOTKEY_OFF / 4), t->bstat.as<uint32_t>(), (uint32_t)CTR_FLAGS,
+                        n > (size_t)MID_MAX ? (uint32_t)(CTR_LEVEL0 + 2 * lvl_slot(level)) : (uint32_t)CTR_FLAGS);
     else hipLaunchKernelGGL(k_publish_build<T>, dim3(1), dim3(256), 0, st, a, reinterpret_cast<uint32_t*>(t->pin));
     t->ctr_ready = true;
     t->pending_build = true; t->pend_level = level; t->pend_flatten = flatten_after;
@@ -2106,7 +2112,7 @@ template <typename T> void build_finalize(bvhgpu_tree* t) {
         }
         BVH_HIP(hipStreamSynchronize(st));
         BVH_HIP(hipGetLastError());
-        t->redone = true;   // whoever traversed the optimistic result must do it again
+        t->redone_gen = t->gen;   // whoever traversed the optimistic result of this generation must do it again
     }
     // diagnostic: number of level-synchronous passes that had work
     int used = level;
@@ -2120,7 +2126,6 @@ template <typename T> void build_finalize(bvhgpu_tree* t) {
 template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after) {
     build_enqueue<T>(t, aabbs_dev, n, flatten_after);
     build_finalize<T>(t);
-    t->redone = false;
 }
 
 #ifdef BVH_PROFILE_MID

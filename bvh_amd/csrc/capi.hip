@@ -27,6 +27,18 @@ template <typename F> int guarded(bvhgpu_ctx* ctx, F&& f) {
         if (e.what && std::strcmp(e.what, "NONFINITE") == 0)
             return fail(ctx, BVHGPU_INVALID_ARG, "shape AABBs contain NaN or infinity (or their centroid extent overflows): the reference panics on "
                                                  "such input (bvh_node.rs:214-217, to_usize().unwrap()); nothing was built");
+        if (e.what && std::strcmp(e.what, "REBROADCAST") == 0)
+            return fail(ctx, BVHGPU_REBROADCAST, "the tree was broadcast before its build was finalized and the build then needed the slow path (unbalanced tree): "
+                                                 "this rank's tree and results are complete, the peers' are not — every rank calls bvhgpu_bcast_known again");
+        if (e.what && std::strcmp(e.what, "RECV_REBROADCAST") == 0)
+            return fail(ctx, BVHGPU_REBROADCAST, "the root broadcast its tree before the build was finalized and the build was not complete: nothing usable was "
+                                                 "received — every rank calls bvhgpu_bcast_known again");
+        if (e.what && std::strcmp(e.what, "RECV_INVALID") == 0)
+            return fail(ctx, BVHGPU_INVALID_ARG, "the broadcast's root reported that it had no valid tree to send (its own call returned the reason); nothing was received");
+        if (e.what && std::strcmp(e.what, "RECV_GARBLED") == 0)
+            return fail(ctx, BVHGPU_RCCL_ERROR, "the broadcast header did not arrive intact");
+        if (e.what && std::strcmp(e.what, "STALE_TREE") == 0)
+            return fail(ctx, BVHGPU_INVALID_ARG, "the tree changed before the asynchronous batch was completed");
         if (e.what && std::strcmp(e.what, "ORDERED_DEPTH") == 0)
             return fail(ctx, BVHGPU_OVERFLOW, "tree deeper than the ordered iterator's 32-entry stack (child_distance_traverse.rs:36)");
         if (e.err == hipErrorOutOfMemory) return fail(ctx, BVHGPU_OOM, buf);
@@ -63,17 +75,73 @@ void free_tree_buffers(bvhgpu_tree* t) {
     t->stats[0].release(); t->stats[1].release();
     t->tile_item[0].release(); t->tile_item[1].release(); t->tile_cnt.release(); t->ctr.release(); t->refit_seg.release();
     t->wide.release(); t->wslot_node.release();
+    t->bstat.release();
     if (t->pin) { (void)hipHostFree(t->pin); t->pin = nullptr; }
+    if (t->pin_recv) { (void)hipHostFree(t->pin_recv); t->pin_recv = nullptr; }
 }
 
-// an asynchronous build may still be in flight: wait for it and finish / validate it (build.hip build_finalize)
+// an asynchronous build may still be in flight: wait for it and finish / validate it (build.hip build_finalize); likewise a
+// broadcast that was received on the stream (comm.hip recv_finalize: its status header tells whether the root's tree was good)
 void ensure_built(bvhgpu_tree* t) {
+    if (t->pending_recv) recv_finalize(t);
     if (!t->pending_build) return;
+    const bool sent_early = t->bcast_gen == t->gen;   // bvhgpu_bcast_known went out before this finalize (optimistic)
     if (t->dtype == BVHGPU_F32) build_finalize<float>(t); else build_finalize<double>(t);
+    if (sent_early && t->redone_gen == t->gen) throw HipFail{hipErrorNotReady, "REBROADCAST", __LINE__};
 }
 int settle(bvhgpu_tree* t) {   // entry points that look at a tree's state first complete its asynchronous build
-    if (!t->pending_build) return BVHGPU_OK;
+    if (!t->pending_build && !t->pending_recv) return BVHGPU_OK;
     return guarded(t->ctx, [&] { use_device(t->ctx); ensure_built(t); return (int)BVHGPU_OK; });
+}
+
+void detach_waiter(bvhgpu_hits* h) {
+    bvhgpu_tree* t = h->wait_tree;
+    h->wait_tree = nullptr;
+    if (!t) return;
+    for (size_t i = 0; i < t->waiters.size(); i++)
+        if (t->waiters[i] == h) { t->waiters[i] = t->waiters.back(); t->waiters.pop_back(); break; }
+}
+
+// Completes an asynchronous batch (the body of bvhgpu_hits_wait; throws).  Whether the optimistic walk is still good is
+// decided from what THIS result object recorded when it was enqueued — the tree's generation and whether that generation was
+// still unfinalized — not from the tree's state now: the build may have been finalized since by bvhgpu_tree_wait, by another
+// result object's wait, by a flatten / nearest / rebuild call, and a slow-path finalize (`redone_gen`) or a tree that must not be
+// walked wide (`exact_only`) invalidates every batch of that generation, whoever notices first.
+void finish_hits(bvhgpu_hits* h) {
+    if (!h->pend_async) return;
+    bvhgpu_ctx* ctx = h->ctx;
+    h->pend_async = false;
+    detach_waiter(h);
+    bvhgpu_tree* t = h->pend_tree;
+    BVH_HIP(hipStreamSynchronize(ctx->stream));
+    if (!t) return;   // empty batch
+    bool rebroadcast = false;
+    try { ensure_built(t); }
+    catch (const HipFail& e) { if (e.what && std::strcmp(e.what, "REBROADCAST") == 0) rebroadcast = true; else throw; }
+    bool replay = h->pend_on_pending && h->pend_gen == t->gen && (t->redone_gen == h->pend_gen || (h->pend_wide && t->exact_only));
+    if (h->pend_gen != t->gen) throw HipFail{hipErrorInvalidValue, "STALE_TREE", __LINE__};   // (rebuild / import settle the waiters first: unreachable)
+    const void* rays = h->pend_rays;
+    for (;;) {
+        if (!replay && traverse_check(h)) break;
+        replay = false;
+        if (h->dtype == BVHGPU_F32) traverse_enqueue<float>(t, static_cast<const bvhgpu_ray_f32*>(rays), h->n_rays, h->flags, h);
+        else traverse_enqueue<double>(t, static_cast<const bvhgpu_ray_f64*>(rays), h->n_rays, h->flags, h);
+        BVH_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (rebroadcast) throw HipFail{hipErrorNotReady, "REBROADCAST", __LINE__};   // this rank's result is complete; the peers' trees are not
+}
+// Before a tree's arrays are overwritten or freed (rebuild, refit, import, broadcast receive, destroy): the asynchronous batches
+// that were enqueued on it are completed first, so that a replay never runs on the wrong tree and no result object keeps a
+// dangling pointer.  A failure is kept in the result object and returned by its own bvhgpu_hits_wait.
+void settle_waiters(bvhgpu_tree* t) {
+    while (!t->waiters.empty()) {
+        bvhgpu_hits* h = t->waiters.back();
+        bvhgpu_ctx* hc = h->ctx;
+        const std::string keep = hc ? hc->err : std::string();
+        const int rc = guarded(hc, [&] { use_device(hc); finish_hits(h); return (int)BVHGPU_OK; });
+        if (rc != BVHGPU_OK) { h->deferred_rc = rc; h->deferred_err = hc ? hc->err : std::string(); if (hc) hc->err = keep; }
+        if (!t->waiters.empty() && t->waiters.back() == h) { h->wait_tree = nullptr; t->waiters.pop_back(); }   // (defensive: always detached by now)
+    }
 }
 
 constexpr size_t MAX_SHAPES = (0xFFFFFFFFull - 1) / 3;  // flat indices are u32 (flat_bvh.rs:136)
@@ -84,7 +152,9 @@ template <typename T> int do_build(bvhgpu_tree* t, const T* aabbs, size_t n, int
     if (n > MAX_SHAPES) return fail(ctx, BVHGPU_OVERFLOW, "too many shapes for u32 flat indices");
     if (mem != BVHGPU_HOST && mem != BVHGPU_DEVICE) return fail(ctx, BVHGPU_INVALID_ARG, "bad mem kind");
     use_device(ctx);
-    ensure_built(t);   // a previous asynchronous build of this tree
+    try { ensure_built(t); }   // a previous asynchronous build of this tree (its outcome no longer matters: everything is rebuilt)
+    catch (const HipFail& e) { if (!e.what || (std::strcmp(e.what, "REBROADCAST") != 0 && std::strcmp(e.what, "NONFINITE") != 0 && std::strncmp(e.what, "RECV_", 5) != 0)) throw; }
+    settle_waiters(t);
     if (ctx->timing) BVH_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     const T* dev = aabbs;
     if (n && mem == BVHGPU_HOST) {  // upload straight into the tree's own copy
@@ -102,7 +172,9 @@ template <typename T> int do_build(bvhgpu_tree* t, const T* aabbs, size_t n, int
 // the shapes moved: same topology, boxes recomputed (refit.hip)
 template <typename T> int do_refit(bvhgpu_tree* t, const T* aabbs, size_t n, int mem) {
     bvhgpu_ctx* ctx = t->ctx;
+    use_device(ctx);
     ensure_built(t);
+    settle_waiters(t);
     if (!t->built) return fail(ctx, BVHGPU_INVALID_ARG, "refit needs a tree that was built here (imported scenes carry no BvhNode array)");
     if (n != t->n) return fail(ctx, BVHGPU_INVALID_ARG, "refit: the number of shapes differs from the tree's (build again)");
     if (n && !aabbs) return fail(ctx, BVHGPU_INVALID_ARG, "aabbs is NULL");
@@ -165,9 +237,11 @@ int do_traverse(bvhgpu_tree* tree, const typename Traits<T>::Ray* rays, size_t n
         const auto* dev = static_cast<const typename Traits<T>::Ray*>(
             to_device(ctx, rays, n_rays * sizeof(typename Traits<T>::Ray), mem, ctx->upload));
         if (async) {
-            h->force_binary = false; h->pend_attempts = 0;
+            h->force_binary = false; h->pend_attempts = 0; h->deferred_rc = 0;
+            h->pend_gen = tree->gen; h->pend_on_pending = tree->pending_build || tree->pending_recv;
             traverse_enqueue<T>(tree, dev, n_rays, flags, h);
             h->pend_async = true;
+            h->wait_tree = tree; tree->waiters.push_back(h);
         } else {
             traverse_batch<T>(tree, dev, n_rays, flags, h);
         }
@@ -379,6 +453,7 @@ const char* bvhgpu_status_string(int s) {
         case BVHGPU_DTYPE_MISMATCH: return "dtype mismatch";
         case BVHGPU_NOT_FLATTENED: return "tree not flattened";
         case BVHGPU_RCCL_ERROR: return "RCCL error";
+        case BVHGPU_REBROADCAST: return "broadcast again";
         default: return "unknown status";
     }
 }
@@ -500,34 +575,22 @@ int bvhgpu_traverse_async_f64(bvhgpu_tree* tree, const bvhgpu_ray_f64* rays, siz
 // finished when the walk ran, a tree the wide walk must not be used on, a hit pool / stack / heap that was too small.
 int bvhgpu_hits_wait(bvhgpu_hits* h) {
     if (!h || !h->ctx) return BVHGPU_INVALID_ARG;
-    if (!h->pend_async) return BVHGPU_OK;
     bvhgpu_ctx* ctx = h->ctx;
-    return guarded(ctx, [&] {
-        use_device(ctx);
-        h->pend_async = false;
-        bvhgpu_tree* t = h->pend_tree;
-        BVH_HIP(hipStreamSynchronize(ctx->stream));
-        if (!t) return (int)BVHGPU_OK;   // empty batch
-        bool replay = false;
-        if (t->pending_build) {
-            ensure_built(t);
-            replay = t->redone || (h->pend_wide && t->exact_only);
-            t->redone = false;
-        }
-        const void* rays = h->pend_rays;
-        for (;;) {
-            if (!replay && traverse_check(h)) return (int)BVHGPU_OK;
-            replay = false;
-            if (h->dtype == BVHGPU_F32) traverse_enqueue<float>(t, static_cast<const bvhgpu_ray_f32*>(rays), h->n_rays, h->flags, h);
-            else traverse_enqueue<double>(t, static_cast<const bvhgpu_ray_f64*>(rays), h->n_rays, h->flags, h);
-            BVH_HIP(hipStreamSynchronize(ctx->stream));
-        }
-    });
+    if (!h->pend_async) {   // nothing in flight — or completed meanwhile on behalf of a rebuild / destroy of its tree
+        const int rc = h->deferred_rc;
+        if (rc != BVHGPU_OK) { ctx->err = h->deferred_err; h->deferred_rc = 0; }
+        return rc;
+    }
+    return guarded(ctx, [&] { use_device(ctx); finish_hits(h); return (int)BVHGPU_OK; });
 }
 
 void bvhgpu_tree_destroy(bvhgpu_tree* t) {
     if (!t) return;
     if (t->ctx) { (void)hipSetDevice(t->ctx->device); (void)hipStreamSynchronize(t->ctx->stream); }
+    if (!t->waiters.empty()) {   // asynchronous batches still refer to this tree: complete them while it exists
+        (void)settle(t);
+        settle_waiters(t);
+    }
     free_tree_buffers(t);
     delete t;
 }
@@ -610,8 +673,10 @@ int bvhgpu_tree_from_flat_f64(bvhgpu_ctx* ctx, const bvhgpu_flat_f64* flat, size
 }
 
 // ---- scene blob: header | traversal array | shape AABBs | top-of-tree slot table ----
-struct SceneHeader { uint32_t magic, dtype; uint64_t n, n_trav; uint32_t unfolded, _pad; uint64_t trav_bytes, aabb_bytes, slot_bytes, tri_bytes; };
-static constexpr uint32_t SCENE_MAGIC = 0x42564835u;  // "BVH5"
+// exact_only: some split of the tree had no SAH winner (empty child bounds, bvh_node.rs:225-230), so a child box is not the join of its
+// grandchildren and the importer must not walk it wide (traverse.hip) — it travels with the tree
+struct SceneHeader { uint32_t magic, dtype; uint64_t n, n_trav; uint32_t unfolded, exact_only; uint64_t trav_bytes, aabb_bytes, slot_bytes, tri_bytes; };
+static constexpr uint32_t SCENE_MAGIC = 0x42564836u;  // "BVH6" (BVH5 + exact_only)
 static size_t slot_table_bytes(int dtype) { return (dtype == BVHGPU_F32 ? TopCfg<float>::SLOTS : TopCfg<double>::SLOTS) * 4; }
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -638,6 +703,7 @@ int bvhgpu_scene_export(bvhgpu_tree* t, void* dst, int mem) {
         std::memset(h, 0, 256);
         h->magic = SCENE_MAGIC; h->dtype = (uint32_t)t->dtype; h->n = t->n; h->n_trav = t->n_trav;
         h->unfolded = t->unfolded ? 1u : 0u;
+        h->exact_only = t->exact_only ? 1u : 0u;
         h->trav_bytes = t->n_trav * tsz; h->aabb_bytes = t->n * 6 * ssz;
         h->slot_bytes = t->slot_entry.p ? slot_table_bytes(t->dtype) : 0;
         h->tri_bytes = t->has_tris ? t->n * 9 * ssz : 0;
@@ -657,8 +723,10 @@ int bvhgpu_scene_import(bvhgpu_ctx* ctx, const void* src, size_t nbytes, int mem
     if (!ctx || !out || !src) return fail(ctx, BVHGPU_INVALID_ARG, "NULL argument");
     if (nbytes < 256) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob too small");
     bvhgpu_tree* given = *out;
-    if (given && (given->built || given->ctx != ctx))
+    if (given && given->ctx == ctx && (given->pending_build || given->pending_recv)) (void)settle(given);   // whatever was in flight is replaced
+    if (given && (given->built || given->pending_build || given->ctx != ctx))
         return fail(ctx, BVHGPU_INVALID_ARG, "*out must be NULL or a tree from bvhgpu_scene_import on this ctx");
+    if (given) settle_waiters(given);
     bvhgpu_tree* t = given ? given : new bvhgpu_tree();
     t->ctx = ctx;
     int rc = guarded(ctx, [&] {
@@ -667,7 +735,7 @@ int bvhgpu_scene_import(bvhgpu_ctx* ctx, const void* src, size_t nbytes, int mem
         const char* s = static_cast<const char*>(src);
         BVH_HIP(hipMemcpyAsync(h, s, 256, mem == BVHGPU_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyHostToHost, ctx->stream));
         BVH_HIP(hipStreamSynchronize(ctx->stream));
-        if (h->magic != SCENE_MAGIC || h->dtype > 1) return fail(ctx, BVHGPU_INVALID_ARG, "not a bvhgpu scene blob");
+        if (h->magic != SCENE_MAGIC || h->dtype > 1 || h->exact_only > 1 || h->unfolded > 1) return fail(ctx, BVHGPU_INVALID_ARG, "not a bvhgpu scene blob (or one of another ABI version)");
         // the header is untrusted: every section size must be what (n, n_trav, dtype) imply, and the sum must fit the blob
         const SceneHeader hd = *h;   // (the pinned page is reused below)
         const uint64_t tsz = hd.dtype == BVHGPU_F32 ? sizeof(TravNode<float>) : sizeof(TravNode<double>);
@@ -697,8 +765,10 @@ int bvhgpu_scene_import(bvhgpu_ctx* ctx, const void* src, size_t nbytes, int mem
         t->dtype = (int)hd.dtype; t->n = hd.n; t->n_trav = hd.n_trav; t->n_nodes = 0; t->n_flat = 0;
         t->unfolded = hd.unfolded != 0;
         t->has_tris = gb != 0;
-        t->built = false; t->flattened = true; t->exact_only = false;
-        if (t->dtype == BVHGPU_F32) wide_from_trav<float>(t); else wide_from_trav<double>(t);
+        t->built = false; t->flattened = true; t->exact_only = hd.exact_only != 0;
+        t->pending_build = false; t->pending_recv = false; t->gen++;
+        if (t->exact_only) t->has_wide = false;   // (never walked wide: no wide nodes needed)
+        else if (t->dtype == BVHGPU_F32) wide_from_trav<float>(t); else wide_from_trav<double>(t);
         if (mem != BVHGPU_DEVICE) BVH_HIP(hipStreamSynchronize(ctx->stream));
         return (int)BVHGPU_OK;
     });
@@ -782,6 +852,7 @@ int bvhgpu_tree_set_triangles_f64(bvhgpu_tree* t, const double* verts, size_t n,
 int bvhgpu_hits_fetch_triangles(bvhgpu_hits* h, void* isect, int mem) {
     if (!h || !h->ctx) return BVHGPU_INVALID_ARG;
     bvhgpu_ctx* ctx = h->ctx;
+    if (h->pend_async) return fail(ctx, BVHGPU_INVALID_ARG, "the result object holds an asynchronous batch that has not been completed: call bvhgpu_hits_wait first");
     if (!(h->flags & BVHGPU_TRAVERSE_TRIANGLES)) return fail(ctx, BVHGPU_INVALID_ARG, "traverse was run without BVHGPU_TRAVERSE_TRIANGLES");
     return guarded(ctx, [&] {
         use_device(ctx);
@@ -792,6 +863,7 @@ int bvhgpu_hits_fetch_triangles(bvhgpu_hits* h, void* isect, int mem) {
 int bvhgpu_hits_fetch_closest(bvhgpu_hits* h, void* isect, uint32_t* shape, int mem) {
     if (!h || !h->ctx) return BVHGPU_INVALID_ARG;
     bvhgpu_ctx* ctx = h->ctx;
+    if (h->pend_async) return fail(ctx, BVHGPU_INVALID_ARG, "the result object holds an asynchronous batch that has not been completed: call bvhgpu_hits_wait first");
     if (!(h->flags & BVHGPU_TRAVERSE_CLOSEST)) return fail(ctx, BVHGPU_INVALID_ARG, "traverse was run without BVHGPU_TRAVERSE_CLOSEST");
     return guarded(ctx, [&] {
         use_device(ctx);
@@ -803,6 +875,7 @@ int bvhgpu_hits_fetch_closest(bvhgpu_hits* h, void* isect, uint32_t* shape, int 
 
 int bvhgpu_hits_info(const bvhgpu_hits* h, size_t* n_rays, uint64_t* total, bvhgpu_traverse_stats* stats) {
     if (!h) return BVHGPU_INVALID_ARG;
+    if (h->pend_async) return fail(h->ctx, BVHGPU_INVALID_ARG, "the result object holds an asynchronous batch that has not been completed: call bvhgpu_hits_wait first");
     if (n_rays) *n_rays = h->n_rays;
     if (total) *total = h->total;
     if (stats) *stats = h->stats;
@@ -812,6 +885,7 @@ int bvhgpu_hits_info(const bvhgpu_hits* h, size_t* n_rays, uint64_t* total, bvhg
 int bvhgpu_hits_fetch(bvhgpu_hits* h, uint32_t* offsets, uint32_t* indices, void* tslice, int mem) {
     if (!h || !h->ctx) return BVHGPU_INVALID_ARG;
     bvhgpu_ctx* ctx = h->ctx;
+    if (h->pend_async) return fail(ctx, BVHGPU_INVALID_ARG, "the result object holds an asynchronous batch that has not been completed: call bvhgpu_hits_wait first");
     if (tslice && !(h->flags & BVHGPU_TRAVERSE_T_SLICE)) return fail(ctx, BVHGPU_INVALID_ARG, "traverse was run without BVHGPU_TRAVERSE_T_SLICE");
     if (h->flags & BVHGPU_TRAVERSE_CLOSEST) return fail(ctx, BVHGPU_INVALID_ARG, "CLOSEST produces no CSR: use bvhgpu_hits_fetch_closest");
     return guarded(ctx, [&] {
@@ -825,6 +899,7 @@ int bvhgpu_hits_fetch(bvhgpu_hits* h, uint32_t* offsets, uint32_t* indices, void
 
 int bvhgpu_hits_device(const bvhgpu_hits* h, const uint32_t** offsets, const uint32_t** indices, const void** tslice) {
     if (!h) return BVHGPU_INVALID_ARG;
+    if (h->pend_async) return fail(h->ctx, BVHGPU_INVALID_ARG, "the result object holds an asynchronous batch that has not been completed: call bvhgpu_hits_wait first");
     if (h->flags & BVHGPU_TRAVERSE_CLOSEST) return fail(h->ctx, BVHGPU_INVALID_ARG, "CLOSEST produces no CSR");
     if (offsets) *offsets = h->offsets.as<uint32_t>();
     if (indices) *indices = h->indices.as<uint32_t>();
@@ -835,6 +910,7 @@ int bvhgpu_hits_device(const bvhgpu_hits* h, const uint32_t** offsets, const uin
 void bvhgpu_hits_destroy(bvhgpu_hits* h) {
     if (!h) return;
     if (h->ctx) { (void)hipSetDevice(h->ctx->device); (void)hipStreamSynchronize(h->ctx->stream); }
+    detach_waiter(h);   // an asynchronous batch that is never waited for: its tree forgets it
     h->counts.release(); h->offsets.release(); h->pool.release(); h->pool_t.release();
     h->indices.release(); h->tslice.release(); h->blocksums.release(); h->scan_sums.release(); h->ctr.release();
     h->isect.release(); h->closest.release(); h->closest_prim.release();

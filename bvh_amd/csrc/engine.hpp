@@ -37,13 +37,16 @@ struct DevBuf {
 
 }  // namespace bvhgpu
 
+struct bvhgpu_comm;
+struct bvhgpu_hits;
+
 struct bvhgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
     int n_cu = 256;
-    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0, 0};  // bvhgpu_set_tuning defaults
+    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0};  // bvhgpu_set_tuning defaults
     // timing
     bool timing = false;
     hipEvent_t ev[8] = {};
@@ -68,7 +71,16 @@ struct bvhgpu_tree {
     bool ctr_ready = false; // build counters / root keys were reset by the previous build
     bool pending_build = false;  // build_enqueue ran, build_finalize has not (asynchronous entry points)
     bool pend_flatten = false;   // ... and the flatten was enqueued behind it
-    bool redone = false;         // build_finalize had to finish the tree on the slow path: results enqueued meanwhile are stale
+    uint64_t gen = 0;            // generation of the tree's contents: every build_enqueue / scene import / broadcast receive starts a new one
+    uint64_t redone_gen = 0;     // the generation whose build_finalize had to finish the tree on the slow path (0: none): batches that
+                                 // were enqueued on that generation before the finalize walked an unfinished tree and are replayed by
+                                 // bvhgpu_hits_wait — by EVERY result object that recorded it, whoever finalized the build first
+    uint64_t bcast_gen = 0;      // the generation that bvhgpu_bcast_known sent before its build was finalized (comm.hip)
+    bool pending_recv = false;   // a broadcast was received on the stream; its status header (t->pin_recv) has not been looked at yet
+    void* pin_recv = nullptr;    // 64 B of pinned host memory: the received broadcast header
+    bvhgpu_comm* recv_comm = nullptr;
+    bvhgpu::DevBuf bstat;        // 64 B: build status word for the device-side broadcast header (written by k_flatten's publishing block)
+    std::vector<bvhgpu_hits*> waiters;   // asynchronous batches enqueued on this tree that bvhgpu_hits_wait has not completed yet
     bool exact_only = false;     // some split had no SAH winner (empty child bounds): a child box is not the join of its
                                  // grandchildren, so traversal must test every ancestor (binary walk only)
     int pend_level = 0;
@@ -146,6 +158,12 @@ struct bvhgpu_hits {
     const void* pend_rays = nullptr;
     bool pend_wide = false, pend_unfolded = false, pend_async = false;
     int pend_attempts = 0;
+    // asynchronous batches: what bvhgpu_hits_wait needs to decide whether the optimistic walk has to be replayed
+    bvhgpu_tree* wait_tree = nullptr;   // the tree whose `waiters` list holds this object (NULL: none)
+    uint64_t pend_gen = 0;              // generation of the tree the batch was enqueued on
+    bool pend_on_pending = false;       // ... and that generation was not finalized yet at that moment
+    int deferred_rc = 0;                // status of a completion that ran on behalf of another call (rebuild / destroy of the tree)
+    std::string deferred_err;
 };
 
 namespace bvhgpu {
@@ -156,8 +174,14 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
 template <typename T> void build_finalize(bvhgpu_tree* t);
 // flatten.hip
 // pub_*: also publish + reset the builder's counters (build_enqueue's last launch); see k_flatten
-template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr = nullptr, uint32_t* pub_host = nullptr, uint32_t pub_words = 0);
+// bstat (with pub_*): device-side status word = pub_ctr[flags_idx] | (pub_ctr[level_idx] != 0 ? BSTAT_UNFINISHED : 0), level_idx == flags_idx: no level tier
+template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr = nullptr, uint32_t* pub_host = nullptr, uint32_t pub_words = 0,
+                                        uint32_t* bstat = nullptr, uint32_t flags_idx = 0, uint32_t level_idx = 0);
+constexpr uint32_t BSTAT_NONFINITE = 1u, BSTAT_EMPTY_SPLIT = 2u;   // = build.hip BUILD_FLAG_*
+constexpr uint32_t BSTAT_UNFINISHED = 0x100u;                      // the optimistic schedule left nodes in the level queue
 template <typename T> void wide_from_trav(bvhgpu_tree* t);   // wide nodes + their LDS slot table from trav + slot_entry
+// comm.hip: completes a broadcast that was received on the stream (reads the status header; throws RECV_* on a bad one)
+void recv_finalize(bvhgpu_tree* t);
 // refit.hip
 template <typename T> void refit_tree(bvhgpu_tree* t, const T* aabbs_dev);
 // traverse.hip

@@ -93,12 +93,17 @@ __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node*
                                                  typename Traits<T>::Flat* __restrict__ flat, TravNode<T>* __restrict__ trav,
                                                  WideNode<T>* __restrict__ wide, uint32_t* __restrict__ wslot_node,
                                                  uint32_t n_nodes, uint32_t n_shapes, uint32_t* __restrict__ pub_ctr,
-                                                 uint32_t* __restrict__ pub_host, uint32_t pub_words) {
+                                                 uint32_t* __restrict__ pub_host, uint32_t pub_words, uint32_t* __restrict__ bstat,
+                                                 uint32_t flags_idx, uint32_t level_idx) {
     using Tr = Traits<T>;
     // build + flatten in one enqueue: this launch is the last of the chain, so its first workgroup also stores the builder's
     // counters in the tree's pinned host page and zeroes them for the next build (nothing in this kernel reads them) —
     // a launch of its own for that cost 4.4 µs of the step
     if (pub_ctr && blockIdx.x == 0) {
+        if (bstat) {   // the same facts for a broadcast header composed on the device (comm.hip): flags, unfinished level queue
+            if (threadIdx.x == 0) bstat[0] = pub_ctr[flags_idx] | ((level_idx != flags_idx && pub_ctr[level_idx] != 0u) ? BSTAT_UNFINISHED : 0u);
+            __syncthreads();   // (read before the counters are zeroed below)
+        }
         for (uint32_t k = threadIdx.x; k < pub_words; k += blockDim.x) { pub_host[k] = pub_ctr[k]; pub_ctr[k] = 0; }
         __threadfence_system();
     }
@@ -258,7 +263,8 @@ template <typename T> void wide_from_trav(bvhgpu_tree* t) {
 template void wide_from_trav<float>(bvhgpu_tree*);
 template void wide_from_trav<double>(bvhgpu_tree*);
 
-template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr, uint32_t* pub_host, uint32_t pub_words) {
+template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr, uint32_t* pub_host, uint32_t pub_words, uint32_t* bstat,
+                                        uint32_t flags_idx, uint32_t level_idx) {
     using Tr = Traits<T>;
     if (t->n == 0) { t->flattened = true; return; }
     t->flat.reserve(t->n_flat * sizeof(typename Tr::Flat));
@@ -273,13 +279,13 @@ template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr, uint3
                        t->aabbs.as<T>(), t->node_slot.as<uint16_t>(), t->slot_entry.as<uint32_t>(),
                        t->flat.as<typename Tr::Flat>(),
                        t->trav.as<TravNode<T>>(), with_wide ? t->wide.as<WideNode<T>>() : nullptr, t->wslot_node.as<uint32_t>(), nn,
-                       (uint32_t)t->n, pub_ctr, pub_host, pub_words);
+                       (uint32_t)t->n, pub_ctr, pub_host, pub_words, bstat, flags_idx, level_idx);
     BVH_HIP(hipGetLastError());
     t->has_wide = with_wide;
     t->flattened = true;
 }
 
-template void flatten_tree<float>(bvhgpu_tree*, uint32_t*, uint32_t*, uint32_t);
-template void flatten_tree<double>(bvhgpu_tree*, uint32_t*, uint32_t*, uint32_t);
+template void flatten_tree<float>(bvhgpu_tree*, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t);
+template void flatten_tree<double>(bvhgpu_tree*, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t);
 
 }  // namespace bvhgpu

@@ -12,7 +12,7 @@ The older transport — export a scene blob, broadcast it with torch.distributed
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 from . import _lib
 from ._lib import check
@@ -89,6 +89,56 @@ class Communicator:
         h = C.c_void_p(arr[0])
         check(lib.bvhgpu_tree_info(h, C.byref(dt), None, None, None), self.ctx._h)
         return FlatBvh(self.ctx, h, "f32" if dt.value == _lib.F32 else "f64")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().bvhgpu_comm_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LocalCommunicator:
+    """bvhgpu_comm over several ctxs of ONE process (bvhgpu_comm_init_all = ncclCommInitAll): ctx i is rank i.  `bcast`
+    takes one tree per ctx — the root's is the source, a peer's entry is None or a FlatBvh an earlier bcast returned — and
+    returns the list of trees (peers: FlatBvh).  What a C++ / Rust host that drives all GPUs of a node from one thread uses."""
+
+    def __init__(self, ctxs: Sequence):
+        lib = _lib.load()
+        self.ctxs = list(ctxs)
+        arr = (C.c_void_p * len(self.ctxs))(*[c._h for c in self.ctxs])
+        h = C.c_void_p()
+        check(lib.bvhgpu_comm_init_all(arr, len(self.ctxs), C.byref(h)), self.ctxs[0]._h)
+        self._h = h
+        self.nranks = len(self.ctxs)
+
+    def bcast(self, trees: Sequence, root: int = 0, dtype: Optional[str] = None, n_shapes: Optional[int] = None, triangles: bool = False,
+              raise_on_error: bool = True):
+        from .api import FlatBvh
+        lib = _lib.load()
+        arr = (C.c_void_p * self.nranks)(*[(t._t if t is not None else None) for t in trees])
+        if dtype is not None and n_shapes is not None:
+            rc = lib.bvhgpu_bcast_known(self._h, arr, int(root), _lib.F32 if dtype == "f32" else _lib.F64, int(n_shapes),
+                                        _lib.BCAST_TRIANGLES if triangles else 0)
+        else:
+            rc = lib.bvhgpu_bcast(self._h, arr, int(root))
+        out = []
+        for i, t in enumerate(trees):
+            if t is not None or not arr[i]:
+                out.append(t)
+                continue
+            dt = C.c_int()
+            h = C.c_void_p(arr[i])
+            lib.bvhgpu_tree_info(h, C.byref(dt), None, None, None)
+            out.append(FlatBvh(self.ctxs[i], h, "f32" if dt.value == _lib.F32 else "f64"))
+        self.last_status = rc
+        if rc != _lib.OK and raise_on_error:
+            check(rc, self.ctxs[min(max(root, 0), self.nranks - 1)]._h)
+        return out
 
     def close(self):
         if getattr(self, "_h", None):

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BVHGPU_ABI_VERSION 2
+#define BVHGPU_ABI_VERSION 3 /* 3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 11 */
 #define BVHGPU_NONE 0xFFFFFFFFu /* u32::MAX marker (flat_bvh.rs:51-53, :124, :137) */
 
 typedef enum {
@@ -50,7 +50,12 @@ typedef enum {
     BVHGPU_NO_DEVICE = 5,
     BVHGPU_DTYPE_MISMATCH = 6,
     BVHGPU_NOT_FLATTENED = 7,
-    BVHGPU_RCCL_ERROR = 8  /* an RCCL call of the multi-GPU broadcast failed (bvhgpu_last_error has ncclGetErrorString) */
+    BVHGPU_RCCL_ERROR = 8, /* an RCCL call of the multi-GPU broadcast failed (bvhgpu_last_error has ncclGetErrorString), or librccl
+                              could not be loaded (it is dlopen'ed on first use: single-GPU consumers do not need it) */
+    BVHGPU_REBROADCAST = 9 /* returned by a wait (bvhgpu_tree_wait / bvhgpu_hits_wait / any call that inspects the tree) on EVERY rank
+                              when bvhgpu_bcast_known sent a tree whose asynchronous build then turned out to need the slow path
+                              (unbalanced tree on a first build): the root's tree and results are complete, the peers received
+                              nothing usable — every rank calls bvhgpu_bcast_known again */
 } bvhgpu_status;
 
 typedef enum { BVHGPU_F32 = 0, BVHGPU_F64 = 1 } bvhgpu_dtype;
@@ -160,7 +165,13 @@ void bvhgpu_tree_destroy(bvhgpu_tree *tree);
  *                                  an unbalanced tree is finished level by level) and replays the batch if the optimistic
  *                                  launch was not enough (hit pool too small, tree not finished when the walk ran).  The
  *                                  statuses the synchronous calls would have returned are returned here.
- *   bvhgpu_tree_wait             the same for a tree alone.  Every other entry point that looks at a tree waits by itself. */
+ *   bvhgpu_tree_wait             the same for a tree alone.  Every other entry point that looks at a tree waits by itself.
+ * Lifetimes: the rays of an asynchronous batch must stay valid until its bvhgpu_hits_wait (a replay reads them again).  The tree
+ * may be waited for, traversed again, rebuilt or destroyed in any order: every result object remembers which generation of the tree
+ * it walked and whether that generation was still unfinalized, so its wait replays exactly when needed, whoever finalized the
+ * build first; a rebuild / refit / import / destroy of the tree first completes the batches still in flight on it (their own
+ * bvhgpu_hits_wait then returns what that completion found).  bvhgpu_hits_fetch* / _info / _device return BVHGPU_INVALID_ARG on a
+ * result object whose batch has not been waited for. */
 int bvhgpu_rebuild_flat_async_f32(bvhgpu_tree *tree, const float *aabbs, size_t n, int mem);
 int bvhgpu_rebuild_flat_async_f64(bvhgpu_tree *tree, const double *aabbs, size_t n, int mem);
 int bvhgpu_tree_wait(bvhgpu_tree *tree);
@@ -212,11 +223,18 @@ int bvhgpu_comm_init_rank(bvhgpu_ctx *ctx, int nranks, int rank, const void *id,
 int bvhgpu_comm_init_all(bvhgpu_ctx *const *ctxs, int ndev, bvhgpu_comm **out);
 int bvhgpu_comm_info(const bvhgpu_comm *comm, int *nranks, int *first_rank, int *n_local);
 void bvhgpu_comm_destroy(bvhgpu_comm *comm);
-/* peers learn type and size from a 64-byte header that travels first (one host round trip per rank) */
+/* peers learn type and size from a 64-byte header that travels first (one host round trip per rank).  If the root has no valid
+ * tree (NULL, not flattened, invalid input) it still sends the header: its own call returns the reason, the peers' calls return
+ * BVHGPU_INVALID_ARG — nobody is left waiting inside a collective. */
 int bvhgpu_bcast(bvhgpu_comm *comm, bvhgpu_tree **trees, int root);
 /* every rank already knows dtype and shape count (a frame loop over a scene of constant size): one group of broadcasts
- * enqueued on the ctxs' streams, no host round trip; `what`: BVHGPU_BCAST_TRIANGLES to send the vertices too.  The root's
- * tree must be a tree built (or received) here with exactly that dtype / shape count. */
+ * (status header + arrays) enqueued on the ctxs' streams, no host round trip on any rank; `what`: BVHGPU_BCAST_TRIANGLES to send
+ * the vertices too.  The root's tree must be a tree built (or received) here with exactly that dtype / shape count; it may
+ * still be building (bvhgpu_rebuild_flat_async_*): the header is then composed on the device from the build's own status.
+ * The peers' trees are usable on their streams at once (bvhgpu_traverse_async_*); the header is looked at when a peer's tree
+ * is first waited for: BVHGPU_INVALID_ARG = the root had nothing valid to send (the root's call or wait returned the reason),
+ * BVHGPU_REBROADCAST = see the status codes.  A received tree carries the root's `exact_only` property (a split without SAH
+ * winner, bvh_node.rs:225-230: no wide walk), as does a scene blob. */
 int bvhgpu_bcast_known(bvhgpu_comm *comm, bvhgpu_tree **trees, int root, int dtype, size_t n_shapes, unsigned what);
 
 /* ---- rays ---- */
@@ -318,7 +336,7 @@ typedef enum {
     BVHGPU_TUNE_BUILD_LEVEL_LAUNCHES = 10, /* builder, level tier: 1 = one launch per tree level (k_level: split of level L-1 and binning of level L fused,
                                               the selection recomputed per tile: the shorter chain, more work per shape); 2 = two launches per level
                                               (k_bin, k_split); 0 (default) = by scene size: 1 up to 250 000 shapes, 2 above */
-    BVHGPU_TUNE_COUNT = 12
+    BVHGPU_TUNE_COUNT = 11
 } bvhgpu_tune;
 int bvhgpu_set_tuning(bvhgpu_ctx *ctx, int knob, int value);
 int bvhgpu_get_tuning(const bvhgpu_ctx *ctx, int knob, int *value);

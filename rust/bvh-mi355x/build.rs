@@ -1,4 +1,4 @@
-// Link libbvh_mi355x.so (built by `python bvh_amd/build_ext.py`; needs libamdhip64.so.7 and librccl.so.1 at run time).
+// Link libbvh_mi355x.so (built by `python bvh_amd/build_ext.py`; needs libamdhip64.so.7 at run time; librccl.so.1 is dlopen'ed by the library only when a communicator is created).
 fn main() {
     let dir = std::env::var("BVH_MI355X_LIB_DIR")
         .expect("set BVH_MI355X_LIB_DIR to the directory that holds libbvh_mi355x.so (<repo>/bvh_amd)");

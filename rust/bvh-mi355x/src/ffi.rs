@@ -1,9 +1,9 @@
-//! Declarations of include/bvh_mi355x.h (ABI version 2), one for one.  Every function returns a `bvhgpu_status`
+//! Declarations of include/bvh_mi355x.h (ABI version 3), one for one.  Every function returns a `bvhgpu_status`
 //! (0 = OK) and never unwinds; `bvhgpu_last_error` gives the text of the last failure on a ctx.
 #![allow(non_camel_case_types, dead_code)]
 use core::ffi::{c_char, c_int, c_uint, c_void};
 
-pub const BVHGPU_ABI_VERSION: c_int = 2;
+pub const BVHGPU_ABI_VERSION: c_int = 3;
 pub const BVHGPU_NONE: u32 = u32::MAX; // flat_bvh.rs:51-53
 
 // bvhgpu_status
@@ -16,6 +16,7 @@ pub const BVHGPU_NO_DEVICE: c_int = 5;
 pub const BVHGPU_DTYPE_MISMATCH: c_int = 6;
 pub const BVHGPU_NOT_FLATTENED: c_int = 7;
 pub const BVHGPU_RCCL_ERROR: c_int = 8;
+pub const BVHGPU_REBROADCAST: c_int = 9;
 // bvhgpu_dtype / bvhgpu_mem
 pub const BVHGPU_F32: c_int = 0;
 pub const BVHGPU_F64: c_int = 1;

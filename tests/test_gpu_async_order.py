@@ -1,0 +1,148 @@
+"""an asynchronous batch must be replayed when the optimistic tree it walked turned out to be unfinished
+(or must not be walked wide) — whoever finalizes the build first.  Round 2 decided that from the tree's state at the moment of
+bvhgpu_hits_wait; a bvhgpu_tree_wait (or another result object's wait, a flatten, a rebuild) in between made the stale batch
+look final.  Round 3: every result object records the tree's generation and whether it was still unfinalized."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import bvh_amd
+    if bvh_amd.device_count() <= 0:
+        pytest.fail("GPU test selected but no HIP device is visible (no CPU fallback exists)")
+    return bvh_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import orc as o
+    return o
+
+
+def _chain(n, dtype=np.float32):
+    x = dtype(1.004) ** np.arange(n, dtype=dtype)
+    lo = np.stack([x, np.zeros(n, dtype), np.zeros(n, dtype)], axis=1)
+    return np.concatenate([lo, lo + dtype(0.5)], axis=1).astype(dtype)
+
+
+def _chain_rays(orc, m):
+    o = np.zeros((m, 3), np.float32); o[:, 0] = -1; o[:, 1] = np.linspace(0.01, 0.49, m); o[:, 2] = 0.25
+    d = np.tile(np.array([1, 0, 0], np.float32), (m, 1)); d[::3] = [1, 0.002, 0]
+    return orc.make_rays(o, d)
+
+
+def _setup(eng, orc, n=12000, m=20000):
+    import torch
+    from bvh_amd import Bvh, Context, RayBatch
+    ctx = Context(0)
+    chain = _chain(n)
+    rays_np = _chain_rays(orc, m)
+    rays_t = torch.from_numpy(rays_np.view(np.uint8).reshape(-1)).cuda()
+    rays = RayBatch.from_device(rays_t, len(rays_np), np.float32)
+    dev = torch.from_numpy(chain).cuda()
+    ooff, oidx, _, _ = orc.traverse_flat(orc.flatten(orc.build(chain).nodes), chain, rays_np, threads=orc.max_threads())
+    tree = Bvh.from_aabbs(_chain(100), ctx)      # no level hint for n shapes: the first asynchronous build takes the slow path
+    return ctx, tree, dev, rays, rays_t, ooff, oidx
+
+
+def test_tree_wait_before_hits_wait(eng, orc):
+    from bvh_amd.api import _Hits
+    ctx, tree, dev, rays, keep, ooff, oidx = _setup(eng, orc)
+    hits = _Hits(ctx)
+    tree.rebuild_async(dev)
+    tree.traverse_async(rays, hits)
+    tree.wait()                                   # finalizes the build on the slow path BEFORE the batch is waited for
+    assert tree.build_levels >= 5
+    st = hits.wait()
+    off, idx = hits.fetch(rays.n)
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx) and st["hits"] == len(oidx)
+
+
+def test_two_result_objects_on_one_pending_tree(eng, orc):
+    from bvh_amd.api import _Hits
+    ctx, tree, dev, rays, keep, ooff, oidx = _setup(eng, orc)
+    h1, h2 = _Hits(ctx), _Hits(ctx)
+    tree.rebuild_async(dev)
+    tree.traverse_async(rays, h1)
+    tree.traverse_async(rays, h2)
+    for h in (h1, h2):                            # the first wait finalizes (slow path); the second must still replay
+        st = h.wait()
+        off, idx = h.fetch(rays.n)
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx) and st["hits"] == len(oidx)
+    # a batch enqueued AFTER the finalize is final as it is
+    tree.traverse_async(rays, h1)
+    assert h1.wait()["hits"] == len(oidx)
+
+
+def test_rebuild_and_destroy_complete_batches_in_flight(eng, orc):
+    """The tree is rebuilt (then destroyed) while a batch on it has not been waited for: the batch is completed first — on the
+    tree it was enqueued on — and its own wait returns that result."""
+    import torch
+    from bvh_amd import testbase as tb
+    from bvh_amd.api import _Hits
+    ctx, tree, dev, rays, keep, ooff, oidx = _setup(eng, orc)
+    hits = _Hits(ctx)
+    tree.rebuild_async(dev)
+    tree.traverse_async(rays, hits)
+    _, other = tb.create_n_cubes(500)
+    tree.rebuild_async(torch.from_numpy(other).cuda())     # another scene into the same tree object
+    st = hits.wait()
+    off, idx = hits.fetch(rays.n)
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx) and st["hits"] == len(oidx)
+    tree.rebuild_async(dev)
+    tree.traverse_async(rays, hits)
+    tree.close()                                           # bvhgpu_tree_destroy with a batch in flight
+    st = hits.wait()
+    off, idx = hits.fetch(rays.n)
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+
+
+def test_fetch_before_wait_is_refused(eng, orc):
+    from bvh_amd._lib import INVALID_ARG, BvhGpuError
+    from bvh_amd.api import _Hits
+    ctx, tree, dev, rays, keep, ooff, oidx = _setup(eng, orc, n=3000)
+    hits = _Hits(ctx)
+    tree.rebuild_async(dev)
+    tree.traverse_async(rays, hits)
+    with pytest.raises(BvhGpuError) as e:
+        hits.fetch(rays.n)
+    assert e.value.status == INVALID_ARG
+    hits.wait()
+    hits.fetch(rays.n)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_exact_only_survives_scene_blob(eng, orc, dtype):
+    """A tree with a split that had no SAH winner (empty child bounds, bvh_node.rs:225-230) must not be walked wide; the
+    property now travels in the scene blob (round 2 dropped it: the importer walked wide and reported leaves the reference
+    never reaches)."""
+    import torch
+    from bvh_amd import Bvh, Context, FlatBvh, RayBatch
+    ctx = Context(0)
+    rng = np.random.default_rng(5)
+    big = dtype(1e19 if dtype == np.float32 else 1e154)
+    lo = (rng.uniform(-1, 1, size=(500, 3)) * big).astype(dtype)
+    far = np.concatenate([lo, lo + big * dtype(0.01)], axis=1)
+    m = 30_000                                             # above the large-batch threshold: the wide walk would be chosen
+    o = (rng.uniform(-1, 1, size=(m, 3)) * big).astype(dtype)
+    d = rng.normal(size=(m, 3)).astype(dtype)
+    rays_np = orc.make_rays(o, d, dtype)
+    ooff, oidx, _, _ = orc.traverse_flat(orc.flatten(orc.build(far).nodes), far, rays_np, threads=orc.max_threads())
+    assert len(oidx) > 0
+    bvh = Bvh.from_aabbs(far, ctx)
+    bvh.flatten_in_place()
+    rb = RayBatch(m, dtype, host=rays_np)
+    off, idx, _, _ = bvh.traverse_batch(rb)
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+    blob = torch.empty(bvh.scene_nbytes(), dtype=torch.uint8, device="cuda")
+    bvh.scene_export(blob)
+    imp = FlatBvh.scene_import(blob, blob.numel(), ctx)
+    off2, idx2, _, _ = imp.traverse_batch(rb)
+    assert np.array_equal(off2, ooff) and np.array_equal(idx2, oidx)
+    host_blob = blob.cpu().numpy()
+    imp2 = FlatBvh.scene_import(host_blob, len(host_blob), ctx)
+    off3, idx3, _, _ = imp2.traverse_batch(rb)
+    assert np.array_equal(off3, ooff) and np.array_equal(idx3, oidx)
