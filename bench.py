@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs sub-runs")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--extra-steps", type=int, default=20)
+    ap.add_argument("--parity-max-rays", type=int, default=200_000_000,
+                    help="rays of a batch diffed against the oracle (default: every ray of every config, 100 M included)")
     ap.add_argument("--pipeline-streams", type=int, default=2,
                     help="N=1, reported beside `value`: the same K steps kept in flight on this many HIP streams by ONE host "
                          "thread (bvhgpu_*_async); 0 = skip")
@@ -140,16 +142,26 @@ class Workload:
                 "step = Bvh::build_par + flatten + FlatBvh::traverse (CSR hit lists in HBM)")
 
 
-def newest_bound(kernel_prefix):
-    """profiles/*_bound.json of the newest profile round that holds PMC counters for this kernel"""
-    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bound.json")), reverse=True)   # newest round / version tag first (r2_v4 > r2_v1)
+def newest_bound(kernel_prefix, workload="cubes120k", dtype="f32", rays=1_000_000):
+    """profiles/*_bound.json of the newest profile round that holds PMC counters for this kernel ON THIS WORKLOAD (the counters
+    of a walk depend on the scene and the ray stream; files written before round 3 carry no workload tag and are configs[1] f32)"""
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bound.json")), reverse=True)   # newest round / version tag first (r3_… > r2_v8 > r2_v1)
     for f in found:
         try:
             j = json.load(open(f))
         except Exception:
             continue
+        if (j.get("workload", "cubes120k"), j.get("dtype", "f32")) != (workload, dtype):
+            continue
         for k in j.get("kernels", []):
             if k.get("kernel", "").startswith(kernel_prefix):
+                prof_rays = j.get("rays_per_launch", 1_000_000)
+                if prof_rays != rays:   # the same walk over another batch size: per-launch counters are per ray to first order
+                    k = dict(k)
+                    for c in ("hbm_bytes", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT"):
+                        if k.get(c) is not None:
+                            k[c] = k[c] * rays / prof_rays
+                    k["scaled_from_rays"] = prof_rays
                 return k, os.path.relpath(f, ROOT)
     return None, None
 
@@ -172,7 +184,7 @@ def run_workload(wl, args, env, steps, warmup, detailed):
     import torch
     import torch.distributed as dist
     from bvh_amd import Bvh, FlatBvh, dist as bdist
-    from bvh_amd._lib import TRAVERSE_COHERENT
+    from bvh_amd._lib import REBROADCAST, TRAVERSE_COHERENT, BvhGpuError
     rank, n_gpus, dev, ctx, comm = env["rank"], env["n_gpus"], env["dev"], env["ctx"], env["comm"]
     R, aabbs, rays = wl.R, wl.aabbs, wl.rays
 
@@ -194,14 +206,35 @@ def run_workload(wl, args, env, steps, warmup, detailed):
 
     def step():
         plan = state["plan"]
-        if plan == "bcast":            # Bvh::build_par + flatten on rank 0, ONE group of RCCL broadcasts out of the C ABI
-            if rank == 0:
-                bvh.rebuild(aabbs, flatten=True)
-                comm.bcast(bvh, 0, wl.dtype_name, wl.n_tri)
-                tree = bvh
-            else:
-                state["peer"] = tree = comm.bcast(state["peer"], 0, wl.dtype_name, wl.n_tri)
-        elif plan == "bcast-torch":    # fallback transport: scene blob over torch.distributed
+        flags = TRAVERSE_COHERENT if wl.coherent else 0
+        if plan == "bcast":
+            # the same asynchronous triple as on one GPU, with the exchange step in the middle and NO host synchronisation before the
+            # final wait on any rank: rank 0 enqueues Bvh::build_par + flatten, the broadcast out of the tree's own buffers
+            # (bvhgpu_bcast_known: the status header is composed on the device from the build's outcome) and its own walk; a peer
+            # enqueues the receive and its walk.  The wait is the end of the step; BVHGPU_REBROADCAST (an unbalanced tree on a first
+            # build: every rank sees it) repeats the exchange with the finished tree.
+            for attempt in range(3):
+                if rank == 0:
+                    if attempt == 0:
+                        bvh.rebuild_async(aabbs)
+                    comm.bcast(bvh, 0, wl.dtype_name, wl.n_tri)
+                    if attempt > 0:                      # rank 0's own batch was completed by the wait that raised
+                        return state["last_stats"]
+                    hits = bvh.traverse_async(rays, flags=flags)
+                else:
+                    state["peer"] = comm.bcast(state["peer"], 0, wl.dtype_name, wl.n_tri)
+                    hits = state["peer"].traverse_async(rays, flags=flags)
+                try:
+                    state["last_stats"] = hits.wait()
+                    return state["last_stats"]
+                except BvhGpuError as e:
+                    if e.status != REBROADCAST:
+                        raise
+                    state["rebroadcasts"] = state.get("rebroadcasts", 0) + 1
+                    if rank == 0:
+                        state["last_stats"] = hits.wait()   # (complete already: the wait that raised replayed it on the finished tree)
+            raise RuntimeError("the broadcast did not settle")
+        if plan == "bcast-torch":      # fallback transport: scene blob over torch.distributed (host round trips)
             if rank == 0:
                 bvh.rebuild(aabbs, flatten=True)
                 bvh.scene_export(blob)
@@ -209,12 +242,11 @@ def run_workload(wl, args, env, steps, warmup, detailed):
             if rank != 0:
                 state["peer"] = FlatBvh.scene_import(blob, blob.numel(), ctx, reuse=state["peer"])
             tree = bvh if rank == 0 else state["peer"]
-        else:
-            # FlatBvh::build (flat_bvh.rs:328-331) and FlatBvh::traverse enqueued back to back, ONE host round trip per step:
-            # the wait validates the build, completes the batch and is the end of the step (nothing of the next step is in flight)
-            bvh.rebuild_async(aabbs)
-            return bvh.traverse_async(rays, flags=TRAVERSE_COHERENT if wl.coherent else 0).wait()
-        return tree.traverse_batch(rays, fetch=False, coherent=wl.coherent)[3]   # FlatBvh::traverse, CSR stays in HBM
+            return tree.traverse_batch(rays, fetch=False, coherent=wl.coherent)[3]   # FlatBvh::traverse, CSR stays in HBM
+        # single / replicate: FlatBvh::build (flat_bvh.rs:328-331) and FlatBvh::traverse enqueued back to back, ONE host round trip
+        # per step: the wait validates the build, completes the batch and is the end of the step (nothing of the next step is in flight)
+        bvh.rebuild_async(aabbs)
+        return bvh.traverse_async(rays, flags=flags).wait()
 
     def barrier():
         if n_gpus > 1:
@@ -281,20 +313,23 @@ def run_workload(wl, args, env, steps, warmup, detailed):
         "describe": wl.describe(),
     }
     env["last"] = dict(bvh=bvh, tree=tree, stats=stats, phases=phases, builder=builder)
-    if not detailed:
-        return out
+    if state.get("rebroadcasts"):
+        out["rebroadcasts"] = state["rebroadcasts"]
 
-    # ---- roofline of the dominant kernel against its BINDING resource, and of the builder ----
+    # ---- roofline of the dominant kernel against its BINDING resource (every workload), and of the builder (headline only) ----
     elem = 4 if wl.dtype_name == "f32" else 8
     flat_sz = 36 if wl.dtype_name == "f32" else 64
     # per ray  Ray in + V*FlatNode + V_leaf*shape AABB + CSR out 4*(H+1)
     algo_bytes = R * wl.ray_size + V * flat_sz + VL * 6 * elem + 4 * (H + R)
     kern_s = phases["traverse_kernel_ms"] * 1e-3
-    big = R >= 16384 and not wl.coherent
-    kern_name = "bvhgpu::k_traverse_wide" if big else "bvhgpu::k_traverse<"
-    pmc, src = newest_bound(kern_name)
+    ctype = "float" if wl.dtype_name == "f32" else "double"
+    if R >= 16384:   # the wide walk; rays are cut into 16 items below ~2 M rays (traverse.hip `few_rays`), walked whole above
+        kern_name = f"bvhgpu::k_traverse_wide<{ctype}, 0, {2 if R < N_CU * 2048 * 4 else 0},"
+    else:
+        kern_name = f"bvhgpu::k_traverse<{ctype}, 0"
+    pmc, src = newest_bound(kern_name, wl.name, wl.dtype_name, R)
     roof = {
-        "kernel": kern_name.rstrip("<"), "kernel_ms": round(phases["traverse_kernel_ms"], 4),
+        "kernel": kern_name.rstrip("<,"), "kernel_ms": round(phases["traverse_kernel_ms"], 4),
         "algorithmic_bytes_per_launch": int(algo_bytes),
         "algorithmic_gbs": round(algo_bytes / kern_s / 1e9, 1),
         "algorithmic_note": "reference-algorithm bytes (SURVEY §8d) / kernel time; the working set is LDS- and cache-resident, so this "
@@ -311,57 +346,81 @@ def run_workload(wl, args, env, steps, warmup, detailed):
             "bound": bound, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": unit, "frac": round(fr[bound], 4),
             "traffic": pmc.get("hbm_bytes"), "hbm_frac": round(fr.get("hbm", 0), 4), "valu_frac": round(fr.get("valu", 0), 4),
             "lds_frac": round(fr.get("lds", 0), 4), "wait_frac": pmc.get("wait_frac"), "profile_kernel_us": pmc.get("avg_us"),
-            "source": f"{src}: separate rocprofv3 --pmc passes of this command (per-launch means; FETCH_SIZE doubled per "
+            "profile_rays_per_launch": pmc.get("scaled_from_rays", R),
+            "source": f"{src}: separate rocprofv3 --pmc passes of this workload (per-launch means; FETCH_SIZE doubled per "
                       "MI355X_MICROARCH.md) over the live HIP-event kernel time; peaks: 8 TB/s HBM, 1024 SIMDs x 2.4 GHz / 2 cycles per "
                       "wave64 VALU instruction, 256 CUs x 2.4 GHz LDS-array cycles",
         })
     else:
         roof.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                     "source": "no profiles/*_bound.json for this kernel yet (tools/profile_round.sh writes it)"})
+                     "source": "no profiles/*_bound.json for this kernel and workload yet (tools/profile_round.sh <tag> --workload … writes it)"})
     out["roofline"] = roof
+    if not detailed:
+        return out
     if builder:
-        n = wl.n_tri
-        levels = 17.9 if wl.name == "cubes120k" and args.cubes == 10_000 else float(np.log2(max(n, 2)))
-        bbytes = (32 if elem == 4 else 56) * levels * n + (2 * n - 1) * (64 if elem == 4 else 112)   # SURVEY §8d build bytes
-        fbytes = (2 * n - 1) * (64 if elem == 4 else 112) + (3 * n - 2) * flat_sz
-        out["roofline_build"] = {
-            "kernels": "k_prep, k_level x (levels + 1), k_mid, k_small, k_flatten", "bound": "hbm",
-            "algorithmic_bytes": int(bbytes + fbytes), "ms": round(phases["build_ms"] + phases["flatten_ms"], 4),
-            "achieved": round((bbytes + fbytes) / ((phases["build_ms"] + phases["flatten_ms"]) * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round((bbytes + fbytes) / ((phases["build_ms"] + phases["flatten_ms"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "note": "a chain of ~14 dependent launches over a cache-resident working set: latency-bound, not bandwidth-bound "
-                    f"(SURVEY §8d: sum over levels of live shapes = {levels:.1f} x N)",
-        }
+        out["roofline_build"] = build_roofline(wl, phases, None)
         out["build_levels"] = bvh.build_levels
     return out
 
 
-def check_parity(wl, env, orc, n_check):
-    """GPU CSR (default walk, fetched) and visit counters (binary walk) against the oracle on the first n_check rays of this
-    rank's batch; the oracle run is timed: it is also the traversal leg of cpu_baseline"""
+def build_roofline(wl, phases, levels):
+    """builder chain against the HBM roofline (SURVEY §8d build bytes); `levels` = mean leaf depth from the oracle's tree when the
+    parity leg ran (sum over the tree levels of the shapes still being partitioned / N), else log2 N"""
+    n = wl.n_tri
+    elem = 4 if wl.dtype_name == "f32" else 8
+    flat_sz = 36 if wl.dtype_name == "f32" else 64
+    lv = levels if levels else float(np.log2(max(n, 2)))
+    bbytes = (32 if elem == 4 else 56) * lv * n + (2 * n - 1) * (64 if elem == 4 else 112)
+    fbytes = (2 * n - 1) * (64 if elem == 4 else 112) + (3 * n - 2) * flat_sz
+    ms = phases["build_ms"] + phases["flatten_ms"]
+    return {
+        "kernels": "k_prep, k_level x (levels + 1), k_mid, k_small, k_flatten", "bound": "hbm",
+        "algorithmic_bytes": int(bbytes + fbytes), "ms": round(ms, 4),
+        "achieved": round((bbytes + fbytes) / (ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round((bbytes + fbytes) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        "levels_priced": round(lv, 2), "levels_source": "oracle tree_stats (mean leaf depth)" if levels else "log2 N (no parity leg)",
+        "note": "a chain of dependent launches over a cache-resident working set: latency-bound, not bandwidth-bound "
+                f"(SURVEY §8d: sum over levels of live shapes = {lv:.1f} x N)",
+    }
+
+
+def check_parity(wl, env, orc, n_check, chunk=1_000_000):
+    """The GPU result of this rank's WHOLE batch (CSR of the default walk fetched once; visit counters of the binary walk) against
+    the oracle on the first n_check rays (default: all of them).  The oracle works through the rays in chunks of `chunk` (memory),
+    each chunk diffed against its slice of the one GPU result; its time is reported: it is two oracle walks per ray."""
     from bvh_amd import RayBatch
     last = env["last"]
     tree = last["tree"]
     n = min(n_check, wl.R)
     a = wl.aabbs_np.astype(wl.np_dtype)
-    rays_o = wl.oracle_rays(orc, wl.first, n)
     ot = orc.build(a, threads=min(16, orc.max_threads()))
     oflat = orc.flatten(ot.nodes)
-    t0 = time.perf_counter()
-    ooff, oidx, _, ost = orc.traverse_flat(oflat, a, rays_o, threads=orc.max_threads())
-    t_or = time.perf_counter() - t0
+    try:
+        last["oracle_levels"] = float(orc.tree_stats(ot.nodes, a)["mean_leaf_depth"])   # = sum over the levels of live shapes / N
+    except Exception:
+        pass
     sub = RayBatch(n, wl.np_dtype, host=None, device=wl.rays_buf, device_ptr=wl.rays_buf.data_ptr())
     off, idx, _, _ = tree.traverse_batch(sub, coherent=wl.coherent)
     st = tree.traverse_batch(sub, stats=True, fetch=False, coherent=wl.coherent)[3]
-    csr_equal = bool(np.array_equal(off, ooff) and np.array_equal(idx, oidx))
-    cnt_equal = bool(st["visited"] == ost["visited"] and st["leaf_visits"] == ost["leaf_visits"] and st["hits"] == ost["hits"])
+    csr_equal, V, VL, H, t_or, n_chunks = True, 0, 0, 0, 0.0, 0
+    for c0 in range(0, n, chunk):
+        m = min(chunk, n - c0)
+        rays_o = wl.oracle_rays(orc, wl.first + c0, m)
+        t0 = time.perf_counter()
+        ooff, oidx, _, ost = orc.traverse_flat(oflat, a, rays_o, threads=orc.max_threads())
+        t_or += time.perf_counter() - t0
+        base = int(off[c0])
+        csr_equal = csr_equal and bool(np.array_equal(off[c0:c0 + m + 1] - np.uint32(base), ooff)
+                                       and np.array_equal(idx[base:int(off[c0 + m])], oidx))
+        V += ost["visited"]; VL += ost["leaf_visits"]; H += ost["hits"]; n_chunks += 1
+    cnt_equal = bool(st["visited"] == V and st["leaf_visits"] == VL and st["hits"] == H and len(idx) == H)
     nodes_equal = None
     if last["builder"] and last["bvh"] is not None:
         nodes_equal = bool(last["bvh"].nodes.tobytes() == ot.nodes.tobytes())
-    return {"checked_rays": int(n), "equal": bool(csr_equal and cnt_equal and nodes_equal is not False),
+    return {"checked_rays": int(n), "rays_this_rank": int(wl.R), "equal": bool(csr_equal and cnt_equal and nodes_equal is not False),
             "csr_offsets_and_indices_equal": csr_equal, "visit_counters_equal": cnt_equal, "bvh_nodes_equal": nodes_equal,
-            "hits": int(ost["hits"]), "against": "oracle (C restatement of bvh_node.rs / flat_bvh.rs, see oracle/bvh_oracle.h)",
-            "oracle_traverse_s": round(t_or, 4)}
+            "hits": int(H), "against": "oracle (C restatement of bvh_node.rs / flat_bvh.rs, see oracle/bvh_oracle.h)",
+            "oracle_chunks": n_chunks, "oracle_traverse_s": round(t_or, 4)}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -424,6 +483,7 @@ def main():
         "metric": "Mrays/s (build+traverse)", "value": res["value"], "unit": "Mrays/s", "n_gpus": n_gpus,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "workload_name": wl.name,
         "config": {
             "workload": wl.describe(), "triangles": wl.n_tri, "rays_per_gpu": wl.R, "rays_total": wl.total_rays,
             "scene_dist": res["scene_dist"],
@@ -443,8 +503,10 @@ def main():
     parity_run = None
     if not args.no_parity and rank == 0:
         from oracle import orc
-        parity_run = check_parity(wl, env, orc, wl.R if wl.R <= 2_000_000 else 1_000_000)
+        parity_run = check_parity(wl, env, orc, min(wl.R, args.parity_max_rays))
         out["parity"] = parity_run
+        if out.get("roofline_build") and env["last"].get("oracle_levels"):
+            out["roofline_build"] = build_roofline(wl, main_env["phases"], env["last"]["oracle_levels"])
 
     # ---- supplementary: independent steps kept in flight on several HIP streams by ONE host thread (N = 1) ----
     # `value` above is the time of K steps issued one after the other, each waited for.  Steps are independent (each rebuilds the
@@ -493,22 +555,25 @@ def main():
     if not args.no_extra and args.workload == "cubes120k" and args.dtype == "f32":
         extras = []
         if n_gpus == 1:
-            plan = [("standin-primary", "f32", None, None), ("standin-incoherent", "f32", "weak", 12_500_000), ("cubes120k", "f64", None, None)]
+            plan = [("standin-primary", "f32", None, None), ("standin-incoherent", "f32", "weak", 12_500_000), ("cubes120k", "f64", None, None),
+                    ("standin-incoherent", "f32", "strong", 100_000_000)]   # configs[3] whole on ONE GPU: the N = 1 point of the strong curve
         else:
             plan = [("standin-incoherent", "f32", "strong", 100_000_000)]
         for name, dt, scaling, nrays in plan:
             try:
                 w2 = Workload(name, args, dt, rank, n_gpus, dev, ctx, scaling=scaling, rays=nrays)
-                if name == "standin-incoherent" and n_gpus == 1:   # the shard rank 5 of 8 owns (tests/test_gpu_scene.py checks the same one)
+                if name == "standin-incoherent" and n_gpus == 1 and scaling == "weak":   # the shard rank 5 of 8 owns (tests/test_gpu_scene.py checks the same one)
                     from bvh_amd import RayBatch
                     w2.first = 62_500_000
                     w2.rays = RayBatch.generate(w2.first, w2.R, w2.bounds, w2.rays_buf, w2.np_dtype, ctx)
                 r2 = run_workload(w2, args, env, args.extra_steps, 3, detailed=False)
                 if name == "standin-incoherent" and n_gpus == 1:
-                    r2["note"] = "one GPU's share of configs[3]: rays [62.5 M, 75 M) of the 100 M-ray stream (rank 5 of 8)"
+                    r2["note"] = ("one GPU's share of configs[3]: rays [62.5 M, 75 M) of the 100 M-ray stream (rank 5 of 8)" if scaling == "weak" else
+                                  "configs[3] whole: all 100 M rays of the stream on one GPU in one batch — the N = 1 point of the strong-scaling "
+                                  "curve whose N > 1 points the same entry carries when bench.py runs with --gpus N")
                 if rank == 0 and not args.no_parity:
                     from oracle import orc
-                    r2["parity"] = check_parity(w2, env, orc, 200_000)
+                    r2["parity"] = check_parity(w2, env, orc, min(w2.R, args.parity_max_rays))
                 extras.append(r2)
                 del w2
                 torch.cuda.empty_cache()
@@ -524,7 +589,7 @@ def main():
         ns = min(args.cpu_sample_rays, wl.R)
         rr = wl.oracle_rays(orc, wl.first, ns)
         n1 = max(ns // 16, 1000)
-        tb_par, par_threads, tb_ser, tf, tt_all, trav_threads, tt_1 = 1e9, 0, 1e9, 1e9, 1e9, cores, 1e9
+        tb_par, par_threads, tb_ser, tf, tt_all, trav_threads, tt_1, tt_csr = 1e9, 0, 1e9, 1e9, 1e9, cores, 1e9, 1e9
         builds_timed = []
         # the portable -O2 build that travelled with the repository, then the -O3 -march=native build made on THIS box
         # (SURVEY §8d); every phase keeps its best time over the two (neither flag set wins everywhere)
@@ -543,12 +608,15 @@ def main():
             for th in sorted({8, 16, 32, 64, 128, cores} & set(range(1, cores + 1))):   # the box may grant fewer CPUs than it shows
                 for _ in range(2):
                     t0 = time.perf_counter()
-                    orc.traverse_flat(of, a, rr, threads=th)        # count pass + fill pass: offsets AND indices, like Vec<&Shape> per ray
+                    orc.traverse_flat_once(of, a, rr, threads=th)   # the harness loop (testbase.rs:826-836): ONE walk per ray, hits pushed into a per-ray Vec
                     dt = time.perf_counter() - t0
                     if dt < tt_all:
                         tt_all, trav_threads = dt, th
             t0 = time.perf_counter()
-            orc.traverse_flat(of, a, rr[:n1], threads=1)
+            orc.traverse_flat(of, a, rr, threads=trav_threads)      # the CSR form the parity leg uses: count pass + fill pass (two walks per ray)
+            tt_csr = min(tt_csr, time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            orc.traverse_flat_once(of, a, rr[:n1], threads=1)
             tt_1 = min(tt_1, time.perf_counter() - t0)
         native = "O3-native" in builds_timed
         tbuild = min(tb_par, tb_ser)
@@ -559,11 +627,12 @@ def main():
             "sample": f"oracle = C restatement of the reference, NOT the Rust crate (no cargo here); gcc -ffp-contract=off + OpenMP, best per phase of "
                       f"{' and '.join(builds_timed)}{'' if native else ' (the native rebuild failed)'}; full {wl.n_tri}-triangle build "
                       f"(best of task-parallel {tb_par * 1e3:.1f} ms on {par_threads} threads with rayon_executor's cut-off bvh_impl.rs:534 / serial "
-                      f"{tb_ser * 1e3:.1f} ms) + serial flatten {tf * 1e3:.1f} ms + traversal of {ns} of the {wl.R} rays, count AND fill pass, "
-                      f"rays-parallel on {trav_threads} threads (best team size: {tt_all * 1e3:.1f} ms), scaled to {wl.R} rays; single-thread "
+                      f"{tb_ser * 1e3:.1f} ms) + serial flatten {tf * 1e3:.1f} ms + traversal of {ns} of the {wl.R} rays as the reference's harness does it "
+                      f"(testbase.rs:826-836: one walk per ray, hits pushed into a per-ray growable list), rays-parallel on {trav_threads} threads (best team size: "
+                      f"{tt_all * 1e3:.1f} ms; the two-walk CSR form of the parity leg: {tt_csr * 1e3:.1f} ms), scaled to {wl.R} rays; single-thread "
                       f"traversal {tt_1 / n1 * 1e9:.0f} ns/ray (README.md:175 quotes 866 ns/ray for the Rust crate on a Ryzen 9 3900X)",
             "build_ms": round(tbuild * 1e3, 2), "flatten_ms": round(tf * 1e3, 2),
-            "traverse_ms_all_cores": round(tt_all * (wl.R / ns) * 1e3, 2),
+            "traverse_ms_all_cores": round(tt_all * (wl.R / ns) * 1e3, 2), "traverse_csr_two_pass_ms": round(tt_csr * (wl.R / ns) * 1e3, 2),
             "traverse_ns_per_ray_1thread": round(tt_1 / n1 * 1e9, 1), "native_build": bool(native),
         }
         out["speedup_vs_cpu_baseline"] = round(out["value"] / out["cpu_baseline"]["value"], 2)

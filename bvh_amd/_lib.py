@@ -71,6 +71,9 @@ SYMBOLS = [
     ("bvhgpu_last_error", C.c_char_p, [_vp]),
     ("bvhgpu_synchronize", _i, [_vp]),
     ("bvhgpu_stream", _vp, [_vp]),
+    ("bvhgpu_device_alloc", _i, [_vp, _sz, _pp]),
+    ("bvhgpu_device_free", _i, [_vp, _vp]),
+    ("bvhgpu_device_copy", _i, [_vp, _vp, _i, _vp, _i, _sz]),
     ("bvhgpu_build_f32", _i, [_vp, _vp, _sz, _i, _pp]),
     ("bvhgpu_build_f64", _i, [_vp, _vp, _sz, _i, _pp]),
     ("bvhgpu_rebuild_f32", _i, [_vp, _vp, _sz, _i]),

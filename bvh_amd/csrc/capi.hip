@@ -503,6 +503,30 @@ int bvhgpu_synchronize(bvhgpu_ctx* ctx) {
 
 void* bvhgpu_stream(bvhgpu_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+int bvhgpu_device_alloc(bvhgpu_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return fail(ctx, BVHGPU_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    return guarded(ctx, [&] { use_device(ctx); BVH_HIP(hipMalloc(out, bytes ? bytes : 1)); return (int)BVHGPU_OK; });
+}
+int bvhgpu_device_free(bvhgpu_ctx* ctx, void* p) {
+    if (!ctx) return BVHGPU_INVALID_ARG;
+    if (!p) return BVHGPU_OK;
+    return guarded(ctx, [&] { use_device(ctx); BVH_HIP(hipStreamSynchronize(ctx->stream)); BVH_HIP(hipFree(p)); return (int)BVHGPU_OK; });
+}
+int bvhgpu_device_copy(bvhgpu_ctx* ctx, void* dst, int dst_mem, const void* src, int src_mem, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !src))) return fail(ctx, BVHGPU_INVALID_ARG, "NULL argument");
+    if ((dst_mem != BVHGPU_HOST && dst_mem != BVHGPU_DEVICE) || (src_mem != BVHGPU_HOST && src_mem != BVHGPU_DEVICE))
+        return fail(ctx, BVHGPU_INVALID_ARG, "bad mem kind");
+    return guarded(ctx, [&] {
+        use_device(ctx);
+        if (bytes) {
+            BVH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, ctx->stream));   // (ordered behind the ctx's earlier work)
+            BVH_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        return (int)BVHGPU_OK;
+    });
+}
+
 int bvhgpu_build_f32(bvhgpu_ctx* ctx, const float* aabbs, size_t n, int mem, bvhgpu_tree** out) {
     return new_build<float>(ctx, aabbs, n, mem, out);
 }

@@ -125,6 +125,13 @@ const char *bvhgpu_last_error(const bvhgpu_ctx *ctx);
 int bvhgpu_synchronize(bvhgpu_ctx *ctx);
 void *bvhgpu_stream(bvhgpu_ctx *ctx); /* the hipStream_t work is enqueued on */
 
+/* ---- device memory for hosts without HIP bindings (a Rust or C caller that keeps rays / AABBs resident in HBM, the
+ * BVHGPU_DEVICE form of every `mem` argument): hipMalloc / hipFree / a synchronous hipMemcpy on the ctx's device.
+ * Memory from any other allocator of the same device (hipMalloc, a torch tensor) is just as good. ---- */
+int bvhgpu_device_alloc(bvhgpu_ctx *ctx, size_t bytes, void **out);
+int bvhgpu_device_free(bvhgpu_ctx *ctx, void *ptr);
+int bvhgpu_device_copy(bvhgpu_ctx *ctx, void *dst, int dst_mem, const void *src, int src_mem, size_t bytes);
+
 /* ---- build: replaces Bvh::build / Bvh::build_par / build_with_executor (bvh_impl.rs:40-96,
  * bounding_hierarchy.rs:158-177) once the caller has gathered shape.aabb() for every shape
  * (aabb_impl.rs:28-56) into `aabbs` = n x [min xyz, max xyz].  n == 0 → valid empty tree

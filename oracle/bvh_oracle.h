@@ -132,6 +132,9 @@ void orc_aligned_boxes(float *aabbs /* 21*6 */);
                                    const RAY *rays, size_t n_rays, uint32_t *offsets,            \
                                    uint32_t *indices, uint64_t cap, T *tslice,                   \
                                    orc_trav_stats *stats, int threads);                          \
+    /* the harness loop of testbase.rs:826-836: one walk per ray into a growable per-ray Vec (cpu_baseline only). */ \
+    uint64_t orc_traverse_flat_once_##S(const FLAT *flat, size_t n_flat, const T *shape_aabbs,   \
+                                        const RAY *rays, size_t n_rays, int threads, uint64_t *checksum); \
     /* Bvh::traverse (bvh_impl.rs:104-119; bvh_node.rs:288-319). */                              \
     uint64_t orc_traverse_tree_##S(const NODE *nodes, size_t n_nodes, const T *shape_aabbs,      \
                                    const RAY *rays, size_t n_rays, uint32_t *offsets,            \

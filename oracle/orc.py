@@ -62,6 +62,7 @@ def _load(path):
         getattr(l, f"orc_flatten_{s}").restype = C.c_size_t
         getattr(l, f"orc_traverse_flat_{s}").restype = C.c_uint64
         getattr(l, f"orc_traverse_tree_{s}").restype = C.c_uint64
+        getattr(l, f"orc_traverse_flat_once_{s}").restype = C.c_uint64
     return l
 
 
@@ -263,6 +264,19 @@ def traverse_flat(flat, shape_aabbs, rays, want_t: bool = False, threads: int = 
        C.c_uint64(total), _p(ts), C.byref(st), C.c_int(threads))
     stats = dict(visited=st.visited, leaf_visits=st.leaf_visits, hits=st.hits, max_visited=st.max_visited)
     return offsets, indices, ts, stats
+
+
+def traverse_flat_once(flat, shape_aabbs, rays, threads: int = 1):
+    """the reference harness' loop (testbase.rs:826-836): ONE walk per ray into a growable per-ray list, lists dropped; returns
+    (total hits, checksum of the shape indices).  bench.py's cpu_baseline times this; the CSR form above walks twice."""
+    s = "f32" if flat.dtype == FLAT_F32 else "f64"
+    ft = _types(s)[0]
+    sa = np.ascontiguousarray(shape_aabbs, dtype=ft).reshape(-1, 6)
+    rays = np.ascontiguousarray(rays)
+    ck = C.c_uint64(0)
+    total = getattr(lib(), f"orc_traverse_flat_once_{s}")(_p(flat), C.c_size_t(len(flat)), _p(sa), _p(rays), C.c_size_t(len(rays)),
+                                                          C.c_int(threads), C.byref(ck))
+    return int(total), int(ck.value)
 
 
 def traverse_tree(nodes, shape_aabbs, rays):

@@ -79,6 +79,9 @@ extern "C" {
     pub fn bvhgpu_last_error(ctx: *const bvhgpu_ctx) -> *const c_char;
     pub fn bvhgpu_synchronize(ctx: *mut bvhgpu_ctx) -> c_int;
     pub fn bvhgpu_stream(ctx: *mut bvhgpu_ctx) -> *mut c_void;
+    pub fn bvhgpu_device_alloc(ctx: *mut bvhgpu_ctx, bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn bvhgpu_device_free(ctx: *mut bvhgpu_ctx, ptr: *mut c_void) -> c_int;
+    pub fn bvhgpu_device_copy(ctx: *mut bvhgpu_ctx, dst: *mut c_void, dst_mem: c_int, src: *const c_void, src_mem: c_int, bytes: usize) -> c_int;
     // build: Bvh::build / build_par / build_with_executor (bvh_impl.rs:40-96)
     pub fn bvhgpu_build_f32(ctx: *mut bvhgpu_ctx, aabbs: *const f32, n: usize, mem: c_int, out: *mut *mut bvhgpu_tree) -> c_int;
     pub fn bvhgpu_build_f64(ctx: *mut bvhgpu_ctx, aabbs: *const f64, n: usize, mem: c_int, out: *mut *mut bvhgpu_tree) -> c_int;

@@ -1,6 +1,7 @@
 /* Plain C consumer of include/bvh_mi355x.h: build → flatten → traverse → fetch, printing everything a test needs
  * to compare with the CPU checker.  Proves the drop-in boundary is a C ABI (no Python, no C++ types).
- * usage: abi_roundtrip <n_cubes_per_axis>   — boxes of the reference's generate_aligned_boxes pattern, extended to 3-D */
+ * usage: abi_roundtrip <n_cubes_per_axis> [ranks]   — boxes of the reference's generate_aligned_boxes pattern, extended to 3-D;
+ * ranks: ctxs of the multi-GPU part (default: one per device) */
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -51,25 +52,75 @@ int main(int argc, char** argv) {
     uint32_t ns_; float nd_;
     CHECK(bvhgpu_nearest_f32(tree, q, 1, BVHGPU_HOST, 0, &ns_, &nd_));
     printf("nearest %u %.6f\n", ns_, nd_);
-    /* the multi-GPU exchange step with the one device this box has: a one-rank RCCL communicator (ncclCommInitAll),
-     * the broadcast of the flattened tree (in place on the root), both forms; then the same two rays on the result */
+    /* the multi-GPU exchange step: ONE process, one ctx per device (ncclCommInitAll) — every device this box has, i.e. one
+     * here and eight on a node; `abi_roundtrip <m> <K>` makes K ctxs (ctx i on device i % ndev: more ctxs than devices needs the
+     * tests' stand-in library, BVHGPU_RCCL_LIB + BVHGPU_RCCL_SHARED_DEVICE).  Rank 0 holds the tree; both forms of the
+     * broadcast; then the asynchronous step of a frame loop: rebuild_flat_async on the root, bcast_known on every rank, every
+     * rank walks its shard of ONE ray stream (rays [r T / K, (r + 1) T / K), generated in place) and is waited for once.
+     * The per-rank hit counts and a checksum over the concatenated CSR are printed for the checker. */
+    int K = argc > 2 ? atoi(argv[2]) : ndev;
+    if (K < 1 || K > 64) { fprintf(stderr, "bad rank count\n"); return 3; }
+    bvhgpu_ctx* ctxs[64];
+    ctxs[0] = ctx;
+    for (int i = 1; i < K; i++) CHECK(bvhgpu_create(i % ndev, NULL, &ctxs[i]));
     bvhgpu_comm* comm = NULL;
-    bvhgpu_ctx* ctxs[1] = {ctx};
-    CHECK(bvhgpu_comm_init_all(ctxs, 1, &comm));
+    CHECK(bvhgpu_comm_init_all(ctxs, K, &comm));
     int nranks = -1, first = -1, nlocal = -1;
     CHECK(bvhgpu_comm_info(comm, &nranks, &first, &nlocal));
-    bvhgpu_tree* trees[1] = {tree};
+    bvhgpu_tree* trees[64];
+    for (int i = 0; i < K; i++) trees[i] = i == 0 ? tree : NULL;
     CHECK(bvhgpu_bcast(comm, trees, 0));
     CHECK(bvhgpu_bcast_known(comm, trees, 0, BVHGPU_F32, n, 0u));
     CHECK(bvhgpu_traverse_f32(trees[0], rays, 2, BVHGPU_HOST, 0u, &hits));
     uint64_t total2;
     CHECK(bvhgpu_hits_info(hits, &nr, &total2, NULL));
     printf("comm ranks %d first %d local %d; after bcast total %llu\n", nranks, first, nlocal, (unsigned long long)total2);
+    {
+        const size_t T = 60000;
+        const float bounds[6] = {-3.f, -3.f, -3.f, 2.f * (float)m + 1.f, 2.f * (float)m + 1.f, 2.f * (float)m + 1.f};
+        bvhgpu_hits* hs[64];
+        unsigned long long sum = 0, count = 0, per_rank[64];
+        void* ray_dev[64];   /* HBM through the ABI: this file has no HIP headers */
+        for (int i = 0; i < K; i++) {
+            size_t lo = (size_t)i * T / (size_t)K, hi = (size_t)(i + 1) * T / (size_t)K, cnt = hi - lo;
+            CHECK(bvhgpu_device_alloc(ctxs[i], (cnt ? cnt : 1) * sizeof(bvhgpu_ray_f32), &ray_dev[i]));
+            CHECK(bvhgpu_gen_rays_f32(ctxs[i], (uint64_t)lo, cnt, bounds, (bvhgpu_ray_f32*)ray_dev[i]));
+            hs[i] = NULL;
+        }
+        for (int step = 0; step < 2; step++) {
+            CHECK(bvhgpu_rebuild_flat_async_f32(trees[0], aabbs, n, BVHGPU_HOST));
+            CHECK(bvhgpu_bcast_known(comm, trees, 0, BVHGPU_F32, n, 0u));
+            for (int i = 0; i < K; i++) {
+                size_t lo = (size_t)i * T / (size_t)K, hi = (size_t)(i + 1) * T / (size_t)K;
+                CHECK(bvhgpu_traverse_async_f32(trees[i], (const bvhgpu_ray_f32*)ray_dev[i], hi - lo, BVHGPU_DEVICE, 0u, &hs[i]));
+            }
+            for (int i = 0; i < K; i++) CHECK(bvhgpu_hits_wait(hs[i]));
+        }
+        for (int i = 0; i < K; i++) {
+            size_t lo = (size_t)i * T / (size_t)K, hi = (size_t)(i + 1) * T / (size_t)K, cnt = hi - lo;
+            uint64_t tot; size_t nr2;
+            CHECK(bvhgpu_hits_info(hs[i], &nr2, &tot, NULL));
+            uint32_t* o2 = (uint32_t*)malloc((cnt + 1) * 4);
+            uint32_t* i2 = (uint32_t*)malloc((tot ? tot : 1) * 4);
+            CHECK(bvhgpu_hits_fetch(hs[i], o2, i2, NULL, BVHGPU_HOST));
+            per_rank[i] = tot;
+            for (size_t r = 0; r < cnt; r++)
+                for (uint32_t j = o2[r]; j < o2[r + 1]; j++) { sum = sum * 1000003ull + (unsigned long long)(lo + r) * 31ull + i2[j]; count++; }
+            free(o2); free(i2);
+        }
+        printf("shards %d rays %zu hits %llu checksum %llu per-rank", K, T, count, sum);
+        for (int i = 0; i < K; i++) printf(" %llu", per_rank[i]);
+        printf("\n");
+        for (int i = 0; i < K; i++) { bvhgpu_hits_destroy(hs[i]); CHECK(bvhgpu_device_free(ctxs[i], ray_dev[i])); }
+    }
+    for (int i = 1; i < K; i++) bvhgpu_tree_destroy(trees[i]);
     bvhgpu_comm_destroy(comm);
+    for (int i = 1; i < K; i++) bvhgpu_destroy(ctxs[i]);
     /* the process-per-GPU form with one rank */
     unsigned char id[BVHGPU_COMM_ID_BYTES];
     CHECK(bvhgpu_comm_unique_id(id));
     CHECK(bvhgpu_comm_init_rank(ctx, 1, 0, id, &comm));
+    trees[0] = tree;
     CHECK(bvhgpu_bcast(comm, trees, 0));
     bvhgpu_comm_destroy(comm);
     bvhgpu_hits_destroy(hits);

@@ -950,8 +950,8 @@ def test_c_abi_from_plain_c(eng, orc, tmp_path):
     # the engine must bind to the same HIP runtime the wheel ships (see bvh_amd/_lib.py); for a C program that is
     # whatever libamdhip64.so.7 the loader finds first: point it at torch's copy, like the Python path does
     env["LD_LIBRARY_PATH"] = os.path.join(os.path.dirname(torch.__file__), "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
-    out = [ln for ln in subprocess.check_output([exe, "5"], env=env, text=True).strip().splitlines()
-           if not ln.startswith(("RCCL version", "HIP version", "ROCm version", "Hostname", "Librccl path"))]
+    banner = ("RCCL version", "HIP version", "ROCm version", "Hostname", "Librccl path")
+    out = [ln for ln in subprocess.check_output([exe, "5"], env=env, text=True).strip().splitlines() if not ln.startswith(banner)]
     m = 5
     g = np.stack(np.meshgrid(np.arange(m), np.arange(m), np.arange(m), indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float32) * 2
     aabbs = np.concatenate([g + np.float32(-0.5), g + np.float32(0.5)], axis=1)
@@ -968,7 +968,37 @@ def test_c_abi_from_plain_c(eng, orc, tmp_path):
     assert out[4] == f"nearest {int(s[0])} {d[0]:.6f}"
     # the RCCL exchange step through the C ABI (one-rank communicator on this one-GPU box): the tree survives a broadcast
     comm_line = [ln for ln in out if ln.startswith("comm ranks")]   # (RCCL prints its own version banner to stdout)
-    assert comm_line == [f"comm ranks 1 first 0 local 1; after bcast total {len(oidx)}"]
+    ndev = eng.device_count()
+    assert comm_line == [f"comm ranks {ndev} first 0 local {ndev}; after bcast total {len(oidx)}"]
+
+    # the sharded step (one ctx per device over real RCCL; then K = 4 ranks sharing device 0 over the tests' stand-in library):
+    # rebuild_flat_async on the root, bcast_known, every rank walks its slice of ONE ray stream — concatenation == oracle
+    def shard_line(lines):
+        return [ln for ln in lines if ln.startswith("shards ")][0].split()
+
+    T = 60000
+    bounds = np.array([-3, -3, -3, 2 * m + 1, 2 * m + 1, 2 * m + 1], np.float32)
+    soff, sidx, _, _ = orc.traverse_flat(oflat, aabbs, orc.create_rays(0, T, bounds), threads=orc.max_threads())
+    csum = 0
+    for r in range(T):
+        for j in range(int(soff[r]), int(soff[r + 1])):
+            csum = (csum * 1000003 + r * 31 + int(sidx[j])) % (1 << 64)
+
+    def check_shards(lines, K):
+        f = shard_line(lines)
+        assert f[1] == str(K) and f[3] == str(T) and f[5] == str(len(sidx)) and f[7] == str(csum), f
+        per = [int(x) for x in f[9:]]
+        cuts = [int(soff[(i * T) // K]) for i in range(K + 1)]
+        assert per == [cuts[i + 1] - cuts[i] for i in range(K)]
+
+    check_shards(out, ndev)
+    fake = os.path.join(root, "tests", "c_abi", "libfakerccl.so")
+    src = os.path.join(root, "tests", "c_abi", "fake_rccl.cpp")
+    if not os.path.exists(fake) or os.path.getmtime(fake) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O1", "-o", fake, src])
+    env4 = dict(env, BVHGPU_RCCL_LIB=fake, BVHGPU_RCCL_SHARED_DEVICE="1")
+    out4 = subprocess.check_output([exe, "5", "4"], env=env4, text=True).strip().splitlines()
+    check_shards(out4, 4)
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("BVH_FUZZ_SEEDS", "12"))))   # BVH_FUZZ_SEEDS=400 for a long soak

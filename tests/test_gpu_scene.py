@@ -151,3 +151,64 @@ def test_config3_incoherent_rays_shard(eng, orc, atrium):
     peer = eng.FlatBvh.scene_import(blob, blob.numel(), ctx)
     cl3, prim3, _ = peer.closest_hits(tb_)
     assert cl3.tobytes() == cl2.tobytes() and np.array_equal(prim3, prim2)
+
+
+# ---- round 3: EVERY ray of configs[2] / [3] diffed against the oracle, at the bench's scene size ----------
+def _full_csr_diff(eng, orc, flat, aabbs, rb, oracle_rays, n, chunk=1_000_000):
+    """ONE GPU traversal of the whole batch (the walk the bench times: the wide walk with whole rays above ~2 M rays), CSR fetched
+    once; the oracle goes through the rays in 1 M-ray chunks and each chunk is compared with its slice — offsets, indices (i.e.
+    the per-ray ORDER of flat_bvh.rs:396-431) — and the reference-equivalent visit counters with a STATS pass."""
+    import hashlib
+    off, idx, _, _ = flat.traverse_batch(rb)
+    st = flat.traverse_batch(rb, stats=True, fetch=False)[3]
+    oflat = orc.flatten(orc.build(aabbs).nodes)
+    V = VL = H = 0
+    hg, ho = hashlib.sha256(), hashlib.sha256()
+    for c0 in range(0, n, chunk):
+        m = min(chunk, n - c0)
+        ooff, oidx, _, ost = orc.traverse_flat(oflat, aabbs, oracle_rays(c0, m), threads=orc.max_threads())
+        base = int(off[c0])
+        goff, gidx = off[c0:c0 + m + 1] - np.uint32(base), idx[base:int(off[c0 + m])]
+        assert np.array_equal(goff, ooff), f"offsets differ in rays [{c0}, {c0 + m})"
+        assert np.array_equal(gidx, oidx), f"indices differ in rays [{c0}, {c0 + m})"
+        hg.update(goff.tobytes()); hg.update(gidx.tobytes()); ho.update(ooff.tobytes()); ho.update(oidx.tobytes())
+        V += ost["visited"]; VL += ost["leaf_visits"]; H += ost["hits"]
+    assert hg.hexdigest() == ho.hexdigest()
+    assert len(idx) == H and (st["visited"], st["leaf_visits"], st["hits"]) == (V, VL, H)
+    return H
+
+
+@pytest.fixture(scope="module")
+def atrium16(eng):
+    from bvh_amd import scene
+    return scene.parse_obj(scene.make_atrium_obj(16))      # the scene bench.py's configs[2] / [3] run on (165 k triangles)
+
+
+def test_config2_all_10m_primary_rays_against_oracle(eng, orc, atrium16):
+    import torch
+    from bvh_amd import Context
+    from bvh_amd._lib import RAY_F32
+    tris, aabbs, bounds = atrium16
+    cam = _camera(bounds)
+    W, H = 4000, 2500
+    ctx = Context(0)
+    flat = eng.Bvh.from_aabbs(aabbs, ctx).flatten()
+    buf = torch.empty(W * H * RAY_F32.itemsize, dtype=torch.uint8, device="cuda")
+    rb = eng.RayBatch.primary(cam, W, H, 0, W * H, buf, np.float32, ctx)
+    hits = _full_csr_diff(eng, orc, flat, aabbs, rb, lambda c0, m: orc.primary_rays(cam, W, H, c0, m), W * H)
+    assert hits > 3 * W * H
+
+
+def test_config3_all_12_5m_shard_rays_against_oracle(eng, orc, atrium16):
+    import torch
+    from bvh_amd import Context
+    from bvh_amd._lib import RAY_F32
+    tris, aabbs, bounds = atrium16
+    ctx = Context(0)
+    flat = eng.Bvh.from_aabbs(aabbs, ctx).flatten()
+    R = 100_000_000 // 8
+    first = 5 * R                                           # the shard rank 5 of 8 owns
+    buf = torch.empty(R * RAY_F32.itemsize, dtype=torch.uint8, device="cuda")
+    rb = eng.RayBatch.generate(first, R, bounds, buf, np.float32, ctx)
+    hits = _full_csr_diff(eng, orc, flat, aabbs, rb, lambda c0, m: orc.create_rays(first + c0, m, bounds), R)
+    assert hits > R

@@ -76,7 +76,13 @@ for k in kernels:
                 e["bound"] = max(fr, key=fr.get)
     rows.append(e)
 rows.sort(key=lambda e: -(e.get("total_us") or 0))
-json.dump({"note": __doc__.split("usage:")[0].strip(), "kernels": rows}, open(os.path.join(out, "bound.json"), "w"), indent=1)
+tag = {"workload": "cubes120k", "dtype": "f32", "rays_per_launch": 1_000_000}   # what the profiled bench command ran (bench.py matches on it)
+try:
+    bj = json.loads(open(os.path.join(out, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+    tag = {"workload": bj.get("workload_name", "cubes120k"), "dtype": bj.get("dtype", "f32"), "rays_per_launch": bj["config"]["rays_per_gpu"]}
+except Exception:
+    pass
+json.dump(dict(tag, note=__doc__.split("usage:")[0].strip(), kernels=rows), open(os.path.join(out, "bound.json"), "w"), indent=1)
 print("\n## resource fractions (counters per launch / average duration of the kernel-trace pass)\n")
 print("| kernel | avg µs | hbm | valu | lds | wait | bound |")
 print("|---|---:|---:|---:|---:|---:|---|")
