@@ -184,7 +184,7 @@ def run_workload(wl, args, env, steps, warmup, detailed):
     import torch
     import torch.distributed as dist
     from bvh_amd import Bvh, FlatBvh, dist as bdist
-    from bvh_amd._lib import REBROADCAST, TRAVERSE_COHERENT, BvhGpuError
+    from bvh_amd._lib import REBROADCAST, TRAVERSE_COHERENT, TRAVERSE_RAYS_READY, BvhGpuError
     rank, n_gpus, dev, ctx, comm = env["rank"], env["n_gpus"], env["dev"], env["ctx"], env["comm"]
     R, aabbs, rays = wl.R, wl.aabbs, wl.rays
 
@@ -206,7 +206,8 @@ def run_workload(wl, args, env, steps, warmup, detailed):
 
     def step():
         plan = state["plan"]
-        flags = TRAVERSE_COHERENT if wl.coherent else 0
+        # (the ray batch is resident in HBM since before the timed region: it does not depend on the rebuild enqueued in this step)
+        flags = (TRAVERSE_COHERENT if wl.coherent else 0) | TRAVERSE_RAYS_READY
         if plan == "bcast":
             # the same asynchronous triple as on one GPU, with the exchange step in the middle and NO host synchronisation before the
             # final wait on any rank: rank 0 enqueues Bvh::build_par + flatten, the broadcast out of the tree's own buffers
@@ -457,11 +458,15 @@ def main():
             dist.init_process_group(backend="gloo")
 
     from bvh_amd import Bvh, Context, dist as bdist
+    from bvh_amd._lib import TRAVERSE_RAYS_READY as RAYS_READY
     from bvh_amd.api import _Hits
 
     # the engine enqueues on torch's current stream: torch events / synchronize see all of it
     stream = torch.cuda.current_stream(dev)
     ctx = Context(local_rank, stream=stream.cuda_stream)
+    for k, v in os.environ.items():   # developer A/B runs: BVH_TUNE_<knob number>=<value> (tools/ab_tune.sh); results never depend on a knob
+        if k.startswith("BVH_TUNE_"):
+            ctx.set_tuning(int(k[9:]), int(v))
     comm, comm_err = None, None
     if n_gpus > 1 and args.backend == "nccl" and args.scene_dist in ("auto", "bcast"):
         try:   # the RCCL communicator of the C ABI; torch.distributed only carries the 128-byte id
@@ -523,7 +528,7 @@ def main():
             lanes.append([c, tr, _Hits(c), False])
         for k in range(3 * S):
             ln = lanes[k % S]
-            ln[1].rebuild_async(wl.aabbs); ln[1].traverse_async(wl.rays, ln[2]); ln[2].wait()
+            ln[1].rebuild_async(wl.aabbs); ln[1].traverse_async(wl.rays, ln[2], flags=RAYS_READY); ln[2].wait()
         torch.cuda.synchronize(dev)
         K = args.steps
         hits_p = []
@@ -533,7 +538,7 @@ def main():
             if ln[3]:
                 hits_p.append(ln[2].wait()["hits"])
             ln[1].rebuild_async(wl.aabbs)
-            ln[1].traverse_async(wl.rays, ln[2])
+            ln[1].traverse_async(wl.rays, ln[2], flags=RAYS_READY)
             ln[3] = True
         for ln in lanes:
             if ln[3]:

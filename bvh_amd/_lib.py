@@ -27,6 +27,7 @@ TRAVERSE_COHERENT = 16
 TRAVERSE_NEAREST_FIRST = 32
 TRAVERSE_FARTHEST_FIRST = 64
 TRAVERSE_BEST_FIRST = 128
+TRAVERSE_RAYS_READY = 256
 # `order=` of the batch calls → flags: the child-ordered depth-first iterators and the heap-driven best-first ones
 ORDER_FLAGS = {None: 0, "nearest": TRAVERSE_NEAREST_FIRST, "farthest": TRAVERSE_FARTHEST_FIRST,
                "nearest_heap": TRAVERSE_NEAREST_FIRST | TRAVERSE_BEST_FIRST,
@@ -141,6 +142,8 @@ SYMBOLS = [
 TUNE_TRAVERSE_VARIANT = 0
 TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_TRAVERSE_LDS_SLOTS, TUNE_TRAVERSE_LDS_THREADS, TUNE_TRAVERSE_SPLIT = 3, 4, 5, 6
 TUNE_WIDE_ITEMS_LOG4, TUNE_WIDE_STACK_LDS, TUNE_WIDE_WG_PER_CU, TUNE_WIDE_THREADS, TUNE_WIDE_SLOTS = 1, 2, 7, 8, 9
+TUNE_WIDE_EARLY_ITEMS = 11       # wide walk on a tree being rebuilt, RAYS_READY batches: item filter beside the build (1) or in the walk's prologue (0, default)
+TUNE_WIDE_STAGE_SHIFT = 12       # wide walk, whole rays, indices only: 2^v shapes per ray staged without pool records (-1 default = 3, 0 off)
 TUNE_BUILD_LEVEL_LAUNCHES = 10   # builder, level tier: 1 one launch per level, 2 k_bin + k_split per level, 0 (default) by scene size
 ABI_VERSION = 3
 

@@ -33,6 +33,8 @@ constexpr int CTR_SMALL = 0;     // u32: number of small items (<= 64 shapes, wa
 // (u32 slot 3 is unused: it was the arrival ticket of a k_prep that created the root item itself)
 constexpr int CTR_MID2 = 2;      // u32: number of workgroup-tier items (65 .. BuildArgs::mid_max shapes)
 constexpr int CTR_FLAGS = 4;     // u32: BUILD_FLAG_* bits raised by the kernels, read back by the host with the counters
+constexpr int CTR_TOPMASK = BUILD_CTR_TOPMASK;   // u32: bit h set when the level tier has written the BvhNode of heap number h < 16 (levels 0..3):
+                                 // once bits 1..15 are there, the walk's item filter can run beside the rest of the build (traverse.hip k_wide_items)
 constexpr uint32_t BUILD_FLAG_NONFINITE = 1u;    // a shape AABB holds NaN / ±inf, or the root centroid extent overflows: the
                                                  // reference panics there (bvh_node.rs:214-217, `to_usize().unwrap()`); nothing is built
 constexpr uint32_t BUILD_FLAG_EMPTY_SPLIT = 2u;  // some node had no winning SAH candidate (NaN / inf costs): its children carry
@@ -591,6 +593,7 @@ template <typename T> __device__ void select_role(const BuildArgs<T>& a, int lev
             a.node_start[ni] = start;
             a.node_count[ni] = count;
             a.node_slot[ni] = (uint16_t)it->heap;
+            if (it->heap < 16u) atomicOr(&a.ctr[CTR_TOPMASK], 1u << it->heap);
         }
         push_pair<T>(a, level + 1, ni, li, start, nl, AL, CL, heap_child(it->heap, 0u), ri, start + nl, count - nl, AR, CR,
                      heap_child(it->heap, 1u), lane);
@@ -1204,6 +1207,7 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
                 a.node_start[ni] = start;
                 a.node_count[ni] = count;
                 a.node_slot[ni] = (uint16_t)heap;
+                if (heap < 16u) atomicOr(&a.ctr[CTR_TOPMASK], 1u << heap);
             }
             // queue slots of the children that leave this tier: lanes 0 / 1 reserve them at the same time
             const uint32_t mykind = ch[lane & 1].kind;
@@ -2057,7 +2061,15 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
         for (size_t m = n; m > (size_t)MID_MAX; m = (m + 1) / 2) fixed++;
         if (t->hint_levels > 0 && t->hint_n == n) fixed = t->hint_levels;
         if (fixed > MAXLV - 4) fixed = MAXLV - 4;
-        for (; level < fixed; level++) run_level<T>(t, a, g, level);
+        for (; level < fixed; level++) {
+            run_level<T>(t, a, g, level);
+            if (level == 3) {   // tree levels 0..3 are split: their BvhNode records (and with them the boxes of the 16 subtrees the wide
+                                // walk cuts its rays into) are final — a batch enqueued behind this build may filter its rays from here on
+                if (!t->ev_top) BVH_HIP(hipEventCreateWithFlags(&t->ev_top, hipEventDisableTiming));
+                BVH_HIP(hipEventRecord(t->ev_top, st));
+                t->ev_top_gen = t->gen;
+            }
+        }
     }
     run_lower_tiers<T>(t, a, g, 0u, 0u);
     // counters: readback through the pinned page + reset for the next build, by the flatten kernel when there is one

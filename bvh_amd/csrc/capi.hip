@@ -76,6 +76,7 @@ void free_tree_buffers(bvhgpu_tree* t) {
     t->tile_item[0].release(); t->tile_item[1].release(); t->tile_cnt.release(); t->ctr.release(); t->refit_seg.release();
     t->wide.release(); t->wslot_node.release();
     t->bstat.release();
+    if (t->ev_top) { (void)hipEventDestroy(t->ev_top); t->ev_top = nullptr; }
     if (t->pin) { (void)hipHostFree(t->pin); t->pin = nullptr; }
     if (t->pin_recv) { (void)hipHostFree(t->pin_recv); t->pin_recv = nullptr; }
 }
@@ -490,6 +491,7 @@ void bvhgpu_destroy(bvhgpu_ctx* ctx) {
     ctx->counters.release();
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -939,6 +941,8 @@ void bvhgpu_hits_destroy(bvhgpu_hits* h) {
     h->indices.release(); h->tslice.release(); h->blocksums.release(); h->scan_sums.release(); h->ctr.release();
     h->isect.release(); h->closest.release(); h->closest_prim.release();
     h->heap_dist.release(); h->heap_node.release();
+    h->wg_items.release(); h->raybuf.release();
+    if (h->ev_items) (void)hipEventDestroy(h->ev_items);
     h->wcounts.release(); h->ray_mask.release(); h->item_cnt.release(); h->wstack.release(); h->ray_items.release(); h->witems.release();
     if (h->pin) (void)hipHostFree(h->pin);
     delete h;

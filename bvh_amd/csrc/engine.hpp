@@ -46,7 +46,7 @@ struct bvhgpu_ctx {
     bool own_stream = false;
     std::string err;
     int n_cu = 256;
-    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0};  // bvhgpu_set_tuning defaults
+    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0, 0, -1};  // bvhgpu_set_tuning defaults
     // timing
     bool timing = false;
     hipEvent_t ev[8] = {};
@@ -56,6 +56,8 @@ struct bvhgpu_ctx {
     bvhgpu::DevBuf upload;    // staging for host→device inputs (aabbs / rays)
     bvhgpu::DevBuf counters;  // small device counters
     void* pinned = nullptr;   // 4 KiB pinned host page for tiny D2H reads
+    hipStream_t side = nullptr;   // second stream of the ctx (created on first use): work that may run BESIDE the main chain — the
+                                  // item filter of a batch whose tree is still building (traverse.hip k_wide_items)
 };
 
 struct bvhgpu_tree {
@@ -81,6 +83,9 @@ struct bvhgpu_tree {
     bvhgpu_comm* recv_comm = nullptr;
     bvhgpu::DevBuf bstat;        // 64 B: build status word for the device-side broadcast header (written by k_flatten's publishing block)
     std::vector<bvhgpu_hits*> waiters;   // asynchronous batches enqueued on this tree that bvhgpu_hits_wait has not completed yet
+    hipEvent_t ev_top = nullptr;         // recorded by build_enqueue behind the level pass that splits tree level 3: from then on the
+    uint64_t ev_top_gen = 0;             // BvhNode records of tree levels 0..3 of generation ev_top_gen are final (if the level tier wrote
+                                         // them: counter CTR_TOPMASK) — what the walk's item filter needs, 100+ µs before the tree is complete
     bool exact_only = false;     // some split had no SAH winner (empty child bounds): a child box is not the join of its
                                  // grandchildren, so traversal must test every ancestor (binary walk only)
     int pend_level = 0;
@@ -139,6 +144,9 @@ struct bvhgpu_hits {
     bvhgpu::DevBuf heap_dist, heap_node;  // best-first traversal: the part of the lanes' heaps that does not fit in LDS
     uint32_t heap_cap = 48;  // ... entries per lane (doubles when a batch overflows it)
     size_t pool_cap = 0;
+    size_t idx_cap = 0;      // capacity of indices[] in entries (>= pool_cap; staged output sizes it by the hit total)
+    bvhgpu::DevBuf raybuf;   // staged output of the wide walk: 2^shift shape indices per ray (traverse.hip WalkOut::raybuf)
+    bool pend_staged = false;
     bool ctr_clean = false;  // the counters were zeroed behind the previous call's readback
     int ctr_set = 0;         // which of the two counter sets the next batch uses
     int bsum_set = 0;        // likewise for the wide walk's scan-block sums
@@ -162,6 +170,9 @@ struct bvhgpu_hits {
     bvhgpu_tree* wait_tree = nullptr;   // the tree whose `waiters` list holds this object (NULL: none)
     uint64_t pend_gen = 0;              // generation of the tree the batch was enqueued on
     bool pend_on_pending = false;       // ... and that generation was not finalized yet at that moment
+    hipEvent_t ev_items = nullptr;      // the early item filter of this batch has finished (side stream → main stream)
+    bvhgpu::DevBuf wg_items;            // per workgroup of the wide walk: {items at the front, items at the back} of its list region, written by
+                                        // the early filter (front == NONE: the workgroup filters its rays itself)
     int deferred_rc = 0;                // status of a completion that ran on behalf of another call (rebuild / destroy of the tree)
     std::string deferred_err;
 };
@@ -178,7 +189,8 @@ template <typename T> void build_finalize(bvhgpu_tree* t);
 template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr = nullptr, uint32_t* pub_host = nullptr, uint32_t pub_words = 0,
                                         uint32_t* bstat = nullptr, uint32_t flags_idx = 0, uint32_t level_idx = 0);
 constexpr uint32_t BSTAT_NONFINITE = 1u, BSTAT_EMPTY_SPLIT = 2u;   // = build.hip BUILD_FLAG_*
-constexpr uint32_t BSTAT_UNFINISHED = 0x100u;                      // the optimistic schedule left nodes in the level queue
+constexpr uint32_t BSTAT_UNFINISHED = 0x100u;
+constexpr int BUILD_CTR_TOPMASK = 5;   // u32 slot of the build counters: bit h = the level tier wrote the BvhNode of heap number h (h < 16)                      // the optimistic schedule left nodes in the level queue
 template <typename T> void wide_from_trav(bvhgpu_tree* t);   // wide nodes + their LDS slot table from trav + slot_entry
 // comm.hip: completes a broadcast that was received on the stream (reads the status header; throws RECV_* on a bad one)
 void recv_finalize(bvhgpu_tree* t);

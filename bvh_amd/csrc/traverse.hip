@@ -73,6 +73,8 @@ template <typename T> struct WalkOut {
     uint32_t* item_cnt;          // wide walk with several items per ray: hits of item (ray, j), written only when non-zero
     uint32_t* ray_items;         // ... and per ray the set of j that wrote one (kept all-zero between batches like counts)
     uint32_t* scan_sums;         // wide walk: hits per SCAN_BLOCK rays, added up by the workgroups as they finish (a zeroed set; NULL: k_scan_reduce does the sums)
+    uint32_t* raybuf;            // wide walk, whole rays, indices only: the first 2^stage_shift shapes of ray r go straight to raybuf[r << stage_shift | k]
+    uint32_t stage_shift;        // (4 bytes per hit, no record, no atomic); only later hits of a ray become pool records.  NULL: everything through the pool
 };
 
 // ---- Ray::intersects_triangle (ray_impl.rs:154-213), Möller–Trumbore with back-face culling.  Same
@@ -817,6 +819,118 @@ template <int ITEMS_LOG4> __device__ __forceinline__ uint32_t item_slot(uint32_t
     return ITEMS_LOG4 == 2 ? 5u + j : 1u + j;   // level 1: 1 + c; level 2: 4 * (1 + c) + 1 + k = 5 + 4c + k
 }
 
+// The rays of one workgroup of the wide walk (64-ray blocks b, b + G, b + 2G, ... of the batch) → its live items, written
+// into its own region of the list: the 4^L subtree boxes are tested, the survivors compacted per wave (one LDS atomic per
+// wave and list end).  Items whose ray stays long inside their subtree's box (long walks expected) fill the list from the
+// front, the others from the back — the walk draws from the front, so that the longest chains start first instead of setting
+// the end of the launch.  Called by the walk's prologue or, earlier and beside the build, by k_wide_items.
+template <typename T, int L4>
+__device__ __forceinline__ void filter_rays_into_list(const ItemTable<T>* tb, const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_rays,
+                                                      uint32_t* __restrict__ list, uint32_t per_wg, uint32_t my_rays, uint32_t G, uint32_t b,
+                                                      uint32_t tid, uint32_t bd, int lane, uint32_t* s_nlist, uint32_t* s_nback) {
+    constexpr uint32_t ITEMS = 1u << (2 * L4);
+    for (uint32_t l0 = 0; l0 < my_rays; l0 += bd) {   // workgroup-uniform
+        const uint32_t local = l0 + tid;
+        const uint32_t r = local < my_rays ? ((((local >> 6) * G + b) << 6) | (local & 63u)) : n_rays;
+        uint32_t mask = 0, longm = 0;
+        if (r < n_rays) {
+            const typename Traits<T>::Ray* rp = rays + r;
+            const T o[3] = {rp->o[0], rp->o[1], rp->o[2]}, inv[3] = {rp->inv[0], rp->inv[1], rp->inv[2]};
+            if (!ray_is_finite<T>(o, inv)) {
+                mask = 1u << WIDE_ITEM_WHOLE; longm = mask;
+            } else {
+#pragma unroll 4
+                for (uint32_t j = 0; j < ITEMS; j++) {   // the boxes are workgroup-uniform: LDS broadcast reads
+                    const T mn[3] = {tb->box[j][0], tb->box[j][1], tb->box[j][2]}, mx[3] = {tb->box[j][3], tb->box[j][4], tb->box[j][5]};
+                    T len;
+                    const bool hit = slab_hit_finite_len<T>(o, inv, mn, mx, len);
+                    mask |= hit ? (1u << j) : 0u;
+                    longm |= (hit && len > tb->half_diag[j]) ? (1u << j) : 0u;
+                }
+            }
+        }
+        const uint32_t cap = per_wg * ITEMS;
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            const uint32_t mm0 = side ? (mask & ~longm) : (mask & longm);
+            const uint32_t mine = (uint32_t)__popc(mm0);
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < WAVE; d <<= 1) {
+                const uint32_t u = __shfl_up(incl, d);
+                if (lane >= d) incl += u;
+            }
+            const uint32_t total = __shfl(incl, WAVE - 1);
+            uint32_t base = 0;
+            if (lane == 0 && total) base = atomicAdd(side ? s_nback : s_nlist, total);
+            base = __shfl(base, 0) + incl - mine;
+            uint32_t mm = mm0;
+            while (mm) {
+                const uint32_t bit = (uint32_t)__ffs(mm) - 1u;
+                mm &= mm - 1u;
+                list[side ? cap - 1u - base : base] = (r << WIDE_ITEM_BITS) | bit;
+                base++;
+            }
+        }
+    }
+}
+
+// The item filter of a batch, EARLY: launched on the ctx's side stream behind the level pass that splits tree level 3, it
+// runs beside the rest of the build (nine tenths of which leave the chip idle) instead of in front of the walk — the walk's
+// prologue shrinks from 17-28 µs to the LDS image load.  The 16 item boxes are those of tree level 4 (heap numbers 16..31),
+// read out of the BvhNode records of levels 0..3, which are final by then IF the level tier wrote them all (counter
+// CTR_TOPMASK) and every level-4 node is an inner node; otherwise the kernel says so (front = NONE) and every workgroup of the
+// walk filters its rays itself, as it does for a tree that is not being rebuilt.  Same grid as the walk (workgroup b owns the
+// same 64-ray blocks and the same list region), a quarter of its threads: it is a guest on the chip.
+template <typename T>
+__global__ __launch_bounds__(256) void k_wide_items(const typename Traits<T>::Node* __restrict__ nodes, uint32_t n_nodes,
+                                                    const uint32_t* __restrict__ node_count, const uint32_t* __restrict__ build_ctr,
+                                                    const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_rays,
+                                                    uint32_t* __restrict__ list_all, uint32_t* __restrict__ wg_items) {
+    constexpr int L4 = 2;
+    constexpr uint32_t ITEMS = 16;
+    __shared__ ItemTable<T> tb;
+    __shared__ uint32_t s_nlist, s_nback, s_bad;
+    const uint32_t tid = threadIdx.x, bd = blockDim.x;
+    const int lane = lane_id();
+    if (tid == 0) { s_nlist = 0u; s_nback = 0u; s_bad = (build_ctr[BUILD_CTR_TOPMASK] & 0xFFFEu) == 0xFFFEu ? 0u : 1u; }
+    __syncthreads();
+    if (s_bad) { if (tid == 0) wg_items[2u * blockIdx.x] = NONE; return; }
+    if (tid < ITEMS) {   // item j = subtree of heap number 16 + j: four steps down from the root, its box is in its parent's record
+        uint32_t node = 0;
+        T bx[6];
+        bool ok = n_nodes > 1u;
+        uint32_t cnt = ok ? node_count[0] : 0u;
+#pragma unroll
+        for (int lv = 3; lv >= 0 && ok; lv--) {
+            const typename Traits<T>::Node nd = nodes[node];
+            const uint32_t right = ((16u + tid) >> lv) & 1u;
+            ok = nd.shape == NONE && nd.l < n_nodes && nd.r < n_nodes && nd.r > nd.l;
+            if (!ok) break;
+            const uint32_t nl = (nd.r - nd.l + 1u) >> 1;   // the left subtree holds 2 nl - 1 nodes (bvh_node.rs:138-142)
+            cnt = right ? cnt - nl : nl;
+            node = right ? nd.r : nd.l;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { bx[k] = right ? nd.r_min[k] : nd.l_min[k]; bx[3 + k] = right ? nd.r_max[k] : nd.l_max[k]; }
+        }
+        ok = ok && cnt > 1u;   // the item's root must be an inner node (the walk names it by its wide node)
+        if (!ok) atomicOr(&s_bad, 1u);
+#pragma unroll
+        for (int k = 0; k < 6; k++) tb.box[tid][k] = bx[k];
+        const T dx = bx[3] - bx[0], dy = bx[4] - bx[1], dz = bx[5] - bx[2];
+        tb.half_diag[tid] = (T)BVH_WIDE_LONG_FRAC * sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    __syncthreads();
+    if (s_bad) { if (tid == 0) wg_items[2u * blockIdx.x] = NONE; return; }
+    const uint32_t n_blocks = (n_rays + 63u) >> 6;
+    const uint32_t my_blocks = n_blocks > blockIdx.x ? (n_blocks - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
+    const uint32_t per_wg = ((n_blocks + gridDim.x - 1u) / gridDim.x) << 6;
+    uint32_t* list = list_all + (size_t)blockIdx.x * per_wg * ITEMS;
+    filter_rays_into_list<T, L4>(&tb, rays, n_rays, list, per_wg, my_blocks << 6, gridDim.x, blockIdx.x, tid, bd, lane, &s_nlist, &s_nback);
+    __syncthreads();
+    if (tid == 0) { wg_items[2u * blockIdx.x] = s_nlist; wg_items[2u * blockIdx.x + 1u] = s_nback; }
+}
+
 #ifdef BVH_WIDE_PROFILE   // developer build: per-wave timestamps (100 MHz wall clock) of the wide walk's phases
 __device__ unsigned long long g_wide_prof[4 * 16384];
 #endif
@@ -826,8 +940,8 @@ __device__ unsigned long long g_wide_prof[4 * 16384];
 template <typename T, int MODE, int ITEMS_LOG4, int MAX_THREADS, int MIN_WAVES>
 __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     const WideNode<T>* __restrict__ wide, const uint32_t* __restrict__ wslot_node, uint32_t K, uint32_t stack_lds,
-    const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_rays, uint32_t* __restrict__ list_all, WalkOut<T> w,
-    uint32_t* __restrict__ gstack, uint32_t gstack_cap, uint32_t* __restrict__ overflow) {
+    const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_rays, uint32_t* __restrict__ list_all, const uint32_t* __restrict__ wg_items,
+    WalkOut<T> w, uint32_t* __restrict__ gstack, uint32_t gstack_cap, uint32_t* __restrict__ overflow) {
     static_assert(ITEMS_LOG4 >= 0 && ITEMS_LOG4 <= 2, "1, 4 or 16 items per ray");
     static_assert(MODE != MODE_T_SLICE, "the t-slice output walks the binary array");
     static_assert(MODE != MODE_CLOSEST || ITEMS_LOG4 == 0, "closest hit: one lane owns the ray");
@@ -885,53 +999,14 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
             const uint32_t ref = tb.ref[tid], slot = item_slot<L4>(tid);
             s_item_ref[tid] = (ref != NONE && (ref & WIDE_INNER) && slot < K) ? (WIDE_INNER | WIDE_RESIDENT | slot) : ref;
         }
-        // rays → live items, into this workgroup's region of the list (at most ITEMS per ray)
+        // rays → live items, into this workgroup's region of the list (at most ITEMS per ray) — unless the batch's early filter
+        // (k_wide_items, enqueued beside the build of the tree) has done it already
         list = list_all + (size_t)blockIdx.x * per_wg * ITEMS;
-        for (uint32_t l0 = 0; l0 < my_rays; l0 += bd) {   // workgroup-uniform
-            const uint32_t r = l0 + tid < my_rays ? ray_of(l0 + tid) : n_rays;
-            uint32_t mask = 0, longm = 0;
-            if (r < n_rays) {
-                const typename Traits<T>::Ray* rp = rays + r;
-                const T o[3] = {rp->o[0], rp->o[1], rp->o[2]}, inv[3] = {rp->inv[0], rp->inv[1], rp->inv[2]};
-                if (!ray_is_finite<T>(o, inv)) {
-                    mask = 1u << WIDE_ITEM_WHOLE; longm = mask;
-                } else {
-#pragma unroll 4
-                    for (uint32_t j = 0; j < ITEMS; j++) {   // the boxes are workgroup-uniform: LDS broadcast reads
-                        const T mn[3] = {tb.box[j][0], tb.box[j][1], tb.box[j][2]}, mx[3] = {tb.box[j][3], tb.box[j][4], tb.box[j][5]};
-                        T len;
-                        const bool hit = slab_hit_finite_len<T>(o, inv, mn, mx, len);
-                        mask |= hit ? (1u << j) : 0u;
-                        longm |= (hit && len > tb.half_diag[j]) ? (1u << j) : 0u;
-                    }
-                }
-            }
-            // wave-level compaction, one LDS atomic per wave and end of the list: items whose ray stays long inside their
-            // subtree's box (long walks expected) fill the list from the front, the others from the back — the walk draws from
-            // the front, so that the longest chains start first instead of setting the end of the launch
-            const uint32_t cap = per_wg * ITEMS;
-#pragma unroll
-            for (int side = 0; side < 2; side++) {
-                const uint32_t mm0 = side ? (mask & ~longm) : (mask & longm);
-                const uint32_t mine = (uint32_t)__popc(mm0);
-                uint32_t incl = mine;
-#pragma unroll
-                for (int d = 1; d < WAVE; d <<= 1) {
-                    const uint32_t u = __shfl_up(incl, d);
-                    if (lane >= d) incl += u;
-                }
-                const uint32_t total = __shfl(incl, WAVE - 1);
-                uint32_t base = 0;
-                if (lane == 0 && total) base = atomicAdd(side ? &s_nback : &s_nlist, total);
-                base = __shfl(base, 0) + incl - mine;
-                uint32_t mm = mm0;
-                while (mm) {
-                    const uint32_t bit = (uint32_t)__ffs(mm) - 1u;
-                    mm &= mm - 1u;
-                    list[side ? cap - 1u - base : base] = (r << WIDE_ITEM_BITS) | bit;
-                    base++;
-                }
-            }
+        const uint32_t pre_front = wg_items ? wg_items[2u * blockIdx.x] : NONE;   // workgroup-uniform
+        if (pre_front != NONE) {
+            if (tid == 0) { s_nlist = pre_front; s_nback = wg_items[2u * blockIdx.x + 1u]; }
+        } else {
+            filter_rays_into_list<T, L4>(&tb, rays, n_rays, list, per_wg, my_rays, gridDim.x, blockIdx.x, tid, bd, lane, &s_nlist, &s_nback);
         }
         __threadfence_block();
     }
@@ -1044,9 +1119,16 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                 }
                 cur = first == 0u ? pop_or_none() : (first == 1u ? nd.ref[0] : (first == 2u ? nd.ref[1] : (first == 4u ? nd.ref[2] : nd.ref[3])));
             }
-            const bool rec = cur < CUR_NONE;   // a leaf: report it, take the next pending grandchild
+            bool rec = cur < CUR_NONE;   // a leaf: report it, take the next pending grandchild
             const uint32_t shape = cur;
             if (rec) cur = pop_or_none();
+            if (MODE == MODE_INDICES && ITEMS_LOG4 == 0 && w.raybuf) {   // (wave-uniform) the ray's first hits need no record: see WalkOut::raybuf
+                if (rec && (ray.cnt >> w.stage_shift) == 0u) {
+                    w.raybuf[((size_t)ray.r << w.stage_shift) | ray.cnt] = shape;
+                    ray.cnt++;
+                    rec = false;
+                }
+            }
             report<T, MODE>(rec, shape, (T)0, (T)0, ray, w, pc, lane, lt);
         }
         if (ovf) { cur = CUR_NONE; sp = 0; }
@@ -1097,26 +1179,29 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint32_t* __restrict_
     if (threadIdx.x == 0) blocksums[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-__global__ __launch_bounds__(256) void k_scan_sums(unsigned long long* __restrict__ blocksums, uint32_t nb,
-                                                   unsigned long long* __restrict__ total_out) {
-    __shared__ unsigned long long sh[256];
-    unsigned long long carry = 0;
-    for (uint32_t c0 = 0; c0 < nb; c0 += 256) {
-        const uint32_t j = c0 + threadIdx.x;
-        const unsigned long long v = j < nb ? blocksums[j] : 0ull;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (int d = 1; d < 256; d <<= 1) {
-            unsigned long long u = threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0ull;
-            __syncthreads();
-            sh[threadIdx.x] += u;
-            __syncthreads();
-        }
-        if (j < nb) blocksums[j] = carry + sh[threadIdx.x] - v;
-        carry += sh[255];
-        __syncthreads();
+__global__ __launch_bounds__(1024) void k_scan_sums(unsigned long long* __restrict__ blocksums, uint32_t nb,
+                                                    unsigned long long* __restrict__ total_out) {
+    // exclusive scan of the block sums by ONE workgroup: every thread adds up a contiguous share serially, one 1024-wide scan over
+    // the shares, every thread writes its share's prefixes.  (Round 2 looped a 256-wide Hillis-Steele scan with 16 barriers per 256
+    // sums: 44 µs for the 2 442 sums of a 10 M-ray batch, 54 µs at 12.5 M — a tenth of the CSR assembly; this form takes ~5 µs.)
+    __shared__ unsigned long long ws[16];
+    const uint32_t per = (nb + 1023u) / 1024u;
+    const uint32_t lo = min(nb, threadIdx.x * per), hi = min(nb, lo + per);
+    unsigned long long s = 0;
+    for (uint32_t j = lo; j < hi; j++) s += blocksums[j];
+    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+    unsigned long long inc = s;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const unsigned long long u = __shfl_up(inc, d);
+        if (lane >= d) inc += u;
     }
-    if (threadIdx.x == 0) *total_out = carry;
+    if (lane == WAVE - 1) ws[wv] = inc;
+    __syncthreads();
+    unsigned long long run = inc - s;
+    for (int w2 = 0; w2 < wv; w2++) run += ws[w2];
+    for (uint32_t j = lo; j < hi; j++) { const unsigned long long v = blocksums[j]; blocksums[j] = run; run += v; }
+    if (threadIdx.x == 1023u) *total_out = run;   // (the last thread's running sum ends at the total, whether it owns sums or not)
 }
 
 constexpr uint32_t SCAN_FUSED_MAX_BLOCKS = 2048;   // up to this many blocks every block sums its predecessors itself
@@ -1226,11 +1311,11 @@ __global__ __launch_bounds__(256) void k_hits_scatter(const HitRec* __restrict__
 template <typename T, int NV, int ITEMS_LOG4>
 __global__ __launch_bounds__(256) void k_hits_scatter_wide(const HitRec* __restrict__ pool, const T* __restrict__ pool_v,
                                                            const unsigned long long* __restrict__ ctr,
-                                                           unsigned long long pool_cap, const uint32_t* __restrict__ offsets,
+                                                           unsigned long long pool_cap, unsigned long long idx_cap, const uint32_t* __restrict__ offsets,
                                                            const uint32_t* __restrict__ item_cnt, const uint16_t* __restrict__ ray_mask,
                                                            uint32_t* __restrict__ indices, T* __restrict__ vals) {
     const unsigned long long n = ctr[0];
-    if (n > pool_cap) return;  // pool overflowed: the host grows it and replays
+    if (n > pool_cap || ctr[3] > idx_cap) return;  // pool overflowed / more hits than indices[] holds: the host grows it and replays
     for (unsigned long long j = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; j < n;
          j += (unsigned long long)gridDim.x * blockDim.x) {
         const HitRec h = pool[j];
@@ -1251,6 +1336,33 @@ __global__ __launch_bounds__(256) void k_hits_scatter_wide(const HitRec* __restr
 #pragma unroll
         for (int k = 0; k < NV; k++) vals[NV * (size_t)d + k] = pool_v[NV * j + k];
     }
+}
+
+// Staged hits (WalkOut::raybuf) → CSR: one thread per ray copies the ray's first min(count, 2^shift) shapes from its own 2^shift-word
+// slot to indices[offsets[ray] ..]: reads of whole 16-byte quads of the slot, writes that neighbouring threads make contiguous.  The later
+// hits of a ray (k >= 2^shift) are pool records and go through k_hits_scatter_wide as before.  Together they replace the
+// 12-byte-record round trip (write, read, scatter) that cost configs[2] 0.42 ms for 58.8 M hits.  (Fusing this copy into
+// k_scan_final — the thread that computes a ray's offset copies its shapes — was measured and dropped: four rays per thread
+// break the contiguity of the writes, 0.31 ms against 0.13 + 0.03.)
+template <int SHIFT>
+__global__ __launch_bounds__(256) void k_hits_gather_staged(const uint32_t* __restrict__ raybuf, const uint32_t* __restrict__ offsets, uint32_t n_rays,
+                                                            const unsigned long long* __restrict__ ctr, unsigned long long idx_cap,
+                                                            uint32_t* __restrict__ indices) {
+    constexpr uint32_t CAP = 1u << SHIFT;
+    if (ctr[3] > idx_cap) return;   // more hits than indices[] holds: the host grows it and replays
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const uint32_t o0 = offsets[r], cnt = offsets[r + 1] - o0;
+    if (!cnt) return;
+    const uint4* src = reinterpret_cast<const uint4*>(raybuf + ((size_t)r << SHIFT));
+    uint32_t v[CAP];
+#pragma unroll
+    for (uint32_t q = 0; q < CAP / 4; q++) {
+        if (4u * q < cnt) { const uint4 x = src[q]; v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w; }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < CAP; k++)
+        if (k < cnt) indices[o0 + k] = v[k];
 }
 
 // The 8 walk / scan counters go to the context's pinned host page and are zeroed for the next call: one 64-thread
@@ -1332,7 +1444,7 @@ constexpr uint32_t WIDE_GSTACK = 24;   // stack entries per lane beyond the LDS 
 
 template <typename T, int MODE, int ITEMS_LOG4>
 static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, const WalkOut<T>& w, bvhgpu_hits* h,
-                        uint32_t* ovf_flag) {
+                        uint32_t* ovf_flag, bool early_items) {
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
     const WideGeom<T> g(ctx);
@@ -1344,6 +1456,22 @@ static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
         const size_t per_wg = ((n_blocks + grid.x - 1) / grid.x) * 64;   // k_traverse_wide: capacity of a workgroup's share
         h->witems.reserve(((size_t)grid.x * per_wg << (2 * ITEMS_LOG4)) * 4 + 16);
         list = h->witems.as<uint32_t>();
+    }
+    const uint32_t* wg_items = nullptr;
+    if (ITEMS_LOG4 == 2 && early_items) {
+        // The item filter runs on the ctx's side stream as soon as the build on the main stream has split tree level 3 (t->ev_top) —
+        // beside the remaining level passes and the workgroup / wave tiers, which leave most of the chip idle — and the walk waits
+        // for it (h->ev_items) instead of filtering in its own prologue.  k_wide_items checks on the device that the top of the tree
+        // is what this needs; if not, every workgroup of the walk filters its rays itself.
+        if (!ctx->side) BVH_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+        if (!h->ev_items) BVH_HIP(hipEventCreateWithFlags(&h->ev_items, hipEventDisableTiming));
+        h->wg_items.reserve((size_t)grid.x * 2 * 4 + 16);
+        BVH_HIP(hipStreamWaitEvent(ctx->side, t->ev_top, 0));
+        hipLaunchKernelGGL(k_wide_items<T>, grid, dim3(256), 0, ctx->side, t->nodes.as<typename Traits<T>::Node>(), (uint32_t)t->n_nodes,
+                           t->node_count.as<uint32_t>(), t->ctr.as<uint32_t>(), rays_dev, (uint32_t)n_rays, list, h->wg_items.as<uint32_t>());
+        BVH_HIP(hipEventRecord(h->ev_items, ctx->side));
+        BVH_HIP(hipStreamWaitEvent(st, h->ev_items, 0));
+        wg_items = h->wg_items.as<uint32_t>();
     }
     const size_t lanes = (size_t)grid.x * g.threads;
     h->wstack.reserve(lanes * WIDE_GSTACK * 4);
@@ -1357,7 +1485,7 @@ static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
         have = g.lds_bytes;
     }
     hipLaunchKernelGGL(kern, grid, dim3(g.threads), g.lds_bytes, st, t->wide.as<WideNode<T>>(), t->wslot_node.as<uint32_t>(),
-                       g.K, g.stack_lds, rays_dev, (uint32_t)n_rays, list, w, h->wstack.as<uint32_t>(), WIDE_GSTACK, ovf_flag);
+                       g.K, g.stack_lds, rays_dev, (uint32_t)n_rays, list, wg_items, w, h->wstack.as<uint32_t>(), WIDE_GSTACK, ovf_flag);
 }
 
 // ---- one batch = enqueue (no host round trip) + check (after the stream has been synchronised) --------------------
@@ -1394,6 +1522,10 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         const int want = ctx->tune[BVHGPU_TUNE_WIDE_ITEMS_LOG4];
         items_log4 = want >= 0 ? std::min(want, 2) : (few_rays ? 2 : 0);
     }
+    // the item filter beside the build (launch_wide): the tree is being rebuilt on this stream, the build has recorded the event behind
+    // the pass that splits level 3, and the caller says that the rays do not depend on anything enqueued since
+    const bool early_items = use_wide && items_log4 == 2 && (flags & BVHGPU_TRAVERSE_RAYS_READY) != 0 && t->pending_build && t->ev_top != nullptr &&
+                             t->ev_top_gen == t->gen && ctx->tune[BVHGPU_TUNE_WIDE_EARLY_ITEMS] != 0;
     const size_t n_items = split_at ? 2 * n_rays : n_rays;
     h->ctx = ctx; h->dtype = Traits<T>::dtype; h->n_rays = n_rays; h->flags = flags; h->total = 0;
     h->stats = bvhgpu_traverse_stats{0, 0, 0, 0, 0};
@@ -1408,6 +1540,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     WalkOut<T> w;
     w.counts = nullptr; w.pool = nullptr; w.pool_v = nullptr; w.pool_cap = 0; w.ctr = ctr;
     w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr; w.item_cnt = nullptr; w.ray_items = nullptr; w.scan_sums = nullptr;
+    w.raybuf = nullptr; w.stage_shift = 0;
 
     uint32_t* ovf_flag = reinterpret_cast<uint32_t*>(ctr + 7);   // bit 0 ordered-iterator stack, bit 1 heap workspace, bit 2 wide-walk stack
     const bool best_first = ordered && (flags & BVHGPU_TRAVERSE_BEST_FIRST) != 0;
@@ -1435,9 +1568,9 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     };
     auto dispatch_wide = [&](auto mode_tag) {
         constexpr int M = decltype(mode_tag)::value;
-        if (M != MODE_CLOSEST && items_log4 == 2) launch_wide<T, M, (M == MODE_CLOSEST ? 0 : 2)>(t, rays_dev, n_rays, w, h, ovf_flag);
-        else if (M != MODE_CLOSEST && items_log4 == 1) launch_wide<T, M, (M == MODE_CLOSEST ? 0 : 1)>(t, rays_dev, n_rays, w, h, ovf_flag);
-        else launch_wide<T, M, 0>(t, rays_dev, n_rays, w, h, ovf_flag);
+        if (M != MODE_CLOSEST && items_log4 == 2) launch_wide<T, M, (M == MODE_CLOSEST ? 0 : 2)>(t, rays_dev, n_rays, w, h, ovf_flag, early_items);
+        else if (M != MODE_CLOSEST && items_log4 == 1) launch_wide<T, M, (M == MODE_CLOSEST ? 0 : 1)>(t, rays_dev, n_rays, w, h, ovf_flag, false);
+        else launch_wide<T, M, 0>(t, rays_dev, n_rays, w, h, ovf_flag, false);
     };
 #define DISPATCH_WALK()                                                                              \
     do {                                                                                             \
@@ -1493,8 +1626,14 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         h->pend_tree = nullptr;
         return;
     }
+    // staged output (WalkOut::raybuf): whole rays, indices only — the hit-heavy large batches; stage_shift 3 = eight shapes per ray
+    const int stage_shift = ctx->tune[BVHGPU_TUNE_WIDE_STAGE_SHIFT] < 0 ? 3 : std::min(ctx->tune[BVHGPU_TUNE_WIDE_STAGE_SHIFT], 5);
+    const bool staged = use_wide && items_log4 == 0 && mode == MODE_INDICES && stage_shift >= 2;
+    h->pend_staged = staged;
+    if (h->idx_cap < h->pool_cap) h->idx_cap = h->pool_cap;
     h->pool.reserve(h->pool_cap * sizeof(HitRec));
-    h->indices.reserve(h->pool_cap * 4);
+    h->indices.reserve(h->idx_cap * 4);
+    if (staged) { h->raybuf.reserve(((size_t)n_rays << stage_shift) * 4 + 64); w.raybuf = h->raybuf.as<uint32_t>(); w.stage_shift = (uint32_t)stage_shift; }
     if (nv) {
         h->pool_t.reserve(h->pool_cap * nv * sizeof(T));
         (mode == MODE_T_SLICE ? h->tslice : h->isect).reserve(h->pool_cap * nv * sizeof(T));
@@ -1546,7 +1685,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         constexpr int KD = decltype(kind_tag)::value;
         if (!w.scan_sums) hipLaunchKernelGGL(k_scan_reduce<KD>, dim3(nb), dim3(256), 0, st, counts, nr, bs);
         if (nb > SCAN_FUSED_MAX_BLOCKS) {
-            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, st, bs, nb, ctr + 3);
+            hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, bs, nb, ctr + 3);
             hipLaunchKernelGGL((k_scan_final<KD, true>), dim3(nb), dim3(256), 0, st, counts, nr, bs, ctr + 3, offs, ritems, rmask,
                                (unsigned long long*)nullptr, (unsigned long long*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0u);
         } else {
@@ -1562,9 +1701,19 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     const int sgrid = (int)std::min<size_t>((cap + 255) / 256, (size_t)ctx->n_cu * 8);
     T* vals = mode == MODE_T_SLICE ? h->tslice.as<T>() : h->isect.as<T>();
     uint32_t* indices = h->indices.as<uint32_t>();
+    if (staged) {   // the rays' first 2^shift shapes, straight from their slots; the pool records (later hits) follow below
+        const unsigned ggrid = (unsigned)((n_rays + 255) / 256);
+        const unsigned long long icap = h->idx_cap;
+        switch (stage_shift) {
+            case 2: hipLaunchKernelGGL(k_hits_gather_staged<2>, dim3(ggrid), dim3(256), 0, st, w.raybuf, offs, nr, ctr, icap, indices); break;
+            case 3: hipLaunchKernelGGL(k_hits_gather_staged<3>, dim3(ggrid), dim3(256), 0, st, w.raybuf, offs, nr, ctr, icap, indices); break;
+            case 4: hipLaunchKernelGGL(k_hits_gather_staged<4>, dim3(ggrid), dim3(256), 0, st, w.raybuf, offs, nr, ctr, icap, indices); break;
+            default: hipLaunchKernelGGL(k_hits_gather_staged<5>, dim3(ggrid), dim3(256), 0, st, w.raybuf, offs, nr, ctr, icap, indices); break;
+        }
+    }
     if (use_wide) {
         const uint32_t* icnt = h->item_cnt.as<uint32_t>();
-#define SCATTER_WIDE(NV, L4) hipLaunchKernelGGL((k_hits_scatter_wide<T, NV, L4>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, offs, icnt, rmask, indices, vals)
+#define SCATTER_WIDE(NV, L4) hipLaunchKernelGGL((k_hits_scatter_wide<T, NV, L4>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, (unsigned long long)h->idx_cap, offs, icnt, rmask, indices, vals)
         if (nv == 3) { if (items_log4 == 2) SCATTER_WIDE(3, 2); else if (items_log4 == 1) SCATTER_WIDE(3, 1); else SCATTER_WIDE(3, 0); }
         else { if (items_log4 == 2) SCATTER_WIDE(0, 2); else if (items_log4 == 1) SCATTER_WIDE(0, 1); else SCATTER_WIDE(0, 0); }
 #undef SCATTER_WIDE
@@ -1618,11 +1767,16 @@ bool traverse_check(bvhgpu_hits* h) {
     }
     const unsigned long long used = pin[0];   // pool slots taken (whole chunks)
     const unsigned long long total = pin[3];  // sum of the per-ray counts = number of hits
-    if (used < total) throw HipFail{hipErrorUnknown, "hit pool / count scan mismatch", __LINE__};
+    if (used < total && !h->pend_staged) throw HipFail{hipErrorUnknown, "hit pool / count scan mismatch", __LINE__};
     if (total > 0xFFFFFFFFull) throw HipFail{hipErrorInvalidValue, "OVERFLOW", __LINE__};
     if (used > h->pool_cap) {  // pool too small: grow to the need (deterministic: same chunks on replay) and replay
         if (++h->pend_attempts > 3) throw HipFail{hipErrorUnknown, "hit pool did not converge", __LINE__};
         h->pool_cap = (size_t)used + (size_t)used / 8 + 1024;
+        return false;
+    }
+    if (total > h->idx_cap) {   // staged output: more hits than indices[] holds (the pool no longer sizes it) — grow and replay
+        if (++h->pend_attempts > 3) throw HipFail{hipErrorUnknown, "index array did not converge", __LINE__};
+        h->idx_cap = (size_t)total + (size_t)total / 8 + 1024;
         return false;
     }
     h->total = total;

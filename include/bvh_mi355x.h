@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BVHGPU_ABI_VERSION 3 /* 3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 11 */
+#define BVHGPU_ABI_VERSION 3 /* 3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 13 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
 #define BVHGPU_NONE 0xFFFFFFFFu /* u32::MAX marker (flat_bvh.rs:51-53, :124, :137) */
 
 typedef enum {
@@ -79,6 +79,10 @@ typedef enum { BVHGPU_HOST = 0, BVHGPU_DEVICE = 1 } bvhgpu_mem;
                                               farthest_traverse_iterator (bvh_impl.rs:145-176) = DistanceTraverseIterator
                                               (distance_traverse.rs:40-158), a best-first walk driven by a BinaryHeap, instead of
                                               the child-ordered depth-first iterator */
+#define BVHGPU_TRAVERSE_RAYS_READY 256u /* hint for bvhgpu_traverse_async_*: the rays were complete before the tree's asynchronous rebuild was
+                                          enqueued (resident ray buffers of a frame loop).  The engine may then read them while the build
+                                          is still running — the wide walk's per-ray item filter runs beside the build on a second
+                                          stream instead of in front of the walk.  Results never depend on it */
 #define BVHGPU_TRAVERSE_COHERENT 16u /* hint: neighbouring rays are similar (primary rays).  Only consulted for batches below the
                                         large-batch threshold (BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS); results never depend on it */
 
@@ -343,7 +347,14 @@ typedef enum {
     BVHGPU_TUNE_BUILD_LEVEL_LAUNCHES = 10, /* builder, level tier: 1 = one launch per tree level (k_level: split of level L-1 and binning of level L fused,
                                               the selection recomputed per tile: the shorter chain, more work per shape); 2 = two launches per level
                                               (k_bin, k_split); 0 (default) = by scene size: 1 up to 250 000 shapes, 2 above */
-    BVHGPU_TUNE_COUNT = 11
+    BVHGPU_TUNE_WIDE_EARLY_ITEMS = 11,     /* variant 3 with BVHGPU_TRAVERSE_RAYS_READY on a tree that is being rebuilt: 1 = cut the rays into items on a
+                                              side stream as soon as the build has split tree level 3; 0 (default) = in the walk's prologue.  Measured on
+                                              configs[1]: the walk shrinks by 10 µs, the two stream dependencies and the guest kernel cost the build as
+                                              much — kept selectable, off by default */
+    BVHGPU_TUNE_WIDE_STAGE_SHIFT = 12,     /* variant 3, whole rays (large batches), indices only: the first 2^v shapes of every ray are written straight to a
+                                              per-ray slot (4 bytes per hit) and gathered into the CSR; only later hits of a ray go through 12-byte pool
+                                              records.  -1 (default) = 3; 0 = off (every hit through the pool); 2 .. 4 */
+    BVHGPU_TUNE_COUNT = 13
 } bvhgpu_tune;
 int bvhgpu_set_tuning(bvhgpu_ctx *ctx, int knob, int value);
 int bvhgpu_get_tuning(const bvhgpu_ctx *ctx, int knob, int *value);

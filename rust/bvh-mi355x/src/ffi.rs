@@ -31,6 +31,7 @@ pub const BVHGPU_TRAVERSE_COHERENT: c_uint = 16;
 pub const BVHGPU_TRAVERSE_NEAREST_FIRST: c_uint = 32;
 pub const BVHGPU_TRAVERSE_FARTHEST_FIRST: c_uint = 64;
 pub const BVHGPU_TRAVERSE_BEST_FIRST: c_uint = 128;
+pub const BVHGPU_TRAVERSE_RAYS_READY: c_uint = 256;
 pub const BVHGPU_COMM_ID_BYTES: usize = 128;
 pub const BVHGPU_BCAST_TRIANGLES: c_uint = 1;
 

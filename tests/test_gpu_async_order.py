@@ -146,3 +146,69 @@ def test_exact_only_survives_scene_blob(eng, orc, dtype):
     imp2 = FlatBvh.scene_import(host_blob, len(host_blob), ctx)
     off3, idx3, _, _ = imp2.traverse_batch(rb)
     assert np.array_equal(off3, ooff) and np.array_equal(idx3, oidx)
+
+
+@pytest.mark.parametrize("cubes,R,early", [(10_000, 1_000_000, 1), (10_000, 1_000_000, 0), (3000, 300_000, 1), (400, 100_000, 1)])
+def test_early_item_filter_same_result(eng, orc, cubes, R, early):
+    """BVHGPU_TRAVERSE_RAYS_READY on a tree that is being rebuilt: the wide walk's item filter runs on a side stream beside the build
+    (k_wide_items) — same CSR as the oracle, step after step, whether the top of the tree qualifies (120 k / 36 k triangles) or
+    the kernel hands the filter back to the walk (4 800 triangles: tree level 4 is below the level tier)."""
+    import torch
+    from bvh_amd import Bvh, Context, RayBatch, testbase as tb
+    from bvh_amd._lib import RAY_F32, TRAVERSE_RAYS_READY, TUNE_WIDE_EARLY_ITEMS
+    from bvh_amd.api import _Hits
+    ctx = Context(0)
+    ctx.set_tuning(TUNE_WIDE_EARLY_ITEMS, early)
+    bounds = tb.default_bounds()
+    _, aabbs_np = tb.create_n_cubes(cubes)
+    aabbs = torch.from_numpy(aabbs_np).cuda()
+    buf = torch.empty(R * RAY_F32.itemsize, dtype=torch.uint8, device="cuda")
+    rays = RayBatch.generate(7, R, bounds, buf, np.float32, ctx)
+    tree = Bvh.from_aabbs(aabbs, ctx)
+    hits = _Hits(ctx)
+    oflat = orc.flatten(orc.build(aabbs_np).nodes)
+    ooff, oidx, _, _ = orc.traverse_flat(oflat, aabbs_np, orc.create_rays(7, R), threads=orc.max_threads())
+    for step in range(4):
+        tree.rebuild_async(aabbs)
+        st = tree.traverse_async(rays, hits, flags=TRAVERSE_RAYS_READY).wait()
+        off, idx = hits.fetch(R)
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx) and st["hits"] == len(oidx), step
+    # another scene into the same objects (the filter must follow the NEW tree's top, not the previous build's records)
+    _, other_np = tb.create_n_cubes(cubes, tb.default_bounds() * np.float32(0.5))
+    other = torch.from_numpy(other_np).cuda()
+    o2 = orc.flatten(orc.build(other_np).nodes)
+    ooff2, oidx2, _, _ = orc.traverse_flat(o2, other_np, orc.create_rays(7, R), threads=orc.max_threads())
+    for step in range(2):
+        tree.rebuild_async(other)
+        tree.traverse_async(rays, hits, flags=TRAVERSE_RAYS_READY).wait()
+        off, idx = hits.fetch(R)
+        assert np.array_equal(off, ooff2) and np.array_equal(idx, oidx2), step
+
+
+@pytest.mark.parametrize("shift", [-1, 0, 2, 4, 5])
+def test_staged_hit_output_growth_and_order(eng, orc, shift):
+    """Whole-ray wide walk with staged output (round 3): the first 2^shift shapes of a ray go to its own slot, later ones through
+    pool records — on a scene where EVERY ray hits 300 boxes in a row both halves, the growth of the index array (sized by the hit
+    total, no longer by the pool) and of the pool, and the per-ray order must all come out right, first batch and replayed batch."""
+    from bvh_amd import Bvh, Context, RayBatch
+    from bvh_amd._lib import TUNE_WIDE_ITEMS_LOG4, TUNE_WIDE_STAGE_SHIFT
+    ctx = Context(0)
+    ctx.set_tuning(TUNE_WIDE_ITEMS_LOG4, 0)                # whole rays also for this small batch
+    ctx.set_tuning(TUNE_WIDE_STAGE_SHIFT, shift)
+    m = 300
+    x = np.arange(m, dtype=np.float32) * np.float32(0.25)
+    lo = np.stack([x, np.zeros(m, np.float32), np.zeros(m, np.float32)], axis=1)
+    row = np.concatenate([lo, lo + np.float32(1.0)], axis=1)
+    R = 30_000
+    o = np.tile(np.array([-5, 0.5, 0.5], np.float32), (R, 1)); o[:, 1] += np.linspace(0, 0.4, R).astype(np.float32)
+    d = np.tile(np.array([1, 0, 0], np.float32), (R, 1))
+    d[::5] = [0, 1, 0]                                      # a fifth of the rays misses everything
+    o[1::5, 0] = 40.0                                       # another fifth starts half-way: fewer hits
+    rays = orc.make_rays(o, d)
+    flat = Bvh.from_aabbs(row, ctx).flatten()
+    ooff, oidx, _, _ = orc.traverse_flat(orc.flatten(orc.build(row).nodes), row, rays, threads=orc.max_threads())
+    assert len(oidx) > 4_000_000
+    rb = RayBatch(R, np.float32, host=rays)
+    for _ in range(2):
+        off, idx, _, _ = flat.traverse_batch(rb)
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
