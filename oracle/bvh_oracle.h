@@ -22,6 +22,17 @@
  * for those, "parity unpinned" — they are pinned only by this restatement and
  * by an independent second restatement (oracle/pyref.py) that must agree.
  *
+ * What a dump of the real crate (tools/golden_dump/, one `cargo run` where cargo
+ * exists; tests/test_reference_bins.py compares) would settle — the THREE places
+ * where this restatement assumes nalgebra / std semantics it cannot execute:
+ *   (1) Aabb::join / grow on +-0.0: nalgebra inf/sup -> simba simd_min/simd_max ->
+ *       f32::min/max leave the sign of a zero result open; here -0 < +0
+ *       (IEEE-754-2019 minimum/maximum).  Invisible to every comparison on the
+ *       path, visible only in the stored bit pattern of a bound.
+ *   (2) Aabb::largest_axis = size().imax(): first strict maximum on ties.
+ *   (3) Vector3::dot / norm_squared: (a0*b0 + a1*b1) + a2*b2, every product and
+ *       sum rounded once, this order, no FMA.
+ *
  * Arithmetic lives partly in nalgebra 0.34 (un-vendored, Cargo.toml:22, no
  * Cargo.lock).  Assumed semantics (published nalgebra source): inf/sup are
  * component-wise min/max; imax is first strict maximum; 3-vector dot is

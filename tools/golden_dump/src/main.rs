@@ -172,7 +172,7 @@ fn main() {
             }
         }
     }
-    manifest.push_str("  \"crate\": \"bvh 0.12.0\"\n}\n");
+    manifest.push_str("  \"_meta\": {\"crate\": \"bvh 0.12.0\"}\n}\n");
     std::fs::write(format!("{out}/manifest.json"), manifest).unwrap();
     println!("wrote {out}/manifest.json");
 }
