@@ -214,27 +214,12 @@ def run_workload(wl, args, env, steps, warmup, detailed):
             # (bvhgpu_bcast_known: the status header is composed on the device from the build's outcome) and its own walk; a peer
             # enqueues the receive and its walk.  The wait is the end of the step; BVHGPU_REBROADCAST (an unbalanced tree on a first
             # build: every rank sees it) repeats the exchange with the finished tree.
-            for attempt in range(3):
-                if rank == 0:
-                    if attempt == 0:
-                        bvh.rebuild_async(aabbs)
-                    comm.bcast(bvh, 0, wl.dtype_name, wl.n_tri)
-                    if attempt > 0:                      # rank 0's own batch was completed by the wait that raised
-                        return state["last_stats"]
-                    hits = bvh.traverse_async(rays, flags=flags)
-                else:
-                    state["peer"] = comm.bcast(state["peer"], 0, wl.dtype_name, wl.n_tri)
-                    hits = state["peer"].traverse_async(rays, flags=flags)
-                try:
-                    state["last_stats"] = hits.wait()
-                    return state["last_stats"]
-                except BvhGpuError as e:
-                    if e.status != REBROADCAST:
-                        raise
-                    state["rebroadcasts"] = state.get("rebroadcasts", 0) + 1
-                    if rank == 0:
-                        state["last_stats"] = hits.wait()   # (complete already: the wait that raised replayed it on the finished tree)
-            raise RuntimeError("the broadcast did not settle")
+            tree, st, reb = bdist.broadcast_step(comm, rank, bvh if rank == 0 else state["peer"], aabbs if rank == 0 else None, rays,
+                                                 wl.dtype_name, wl.n_tri, flags=flags)
+            if rank != 0:
+                state["peer"] = tree
+            state["rebroadcasts"] = state.get("rebroadcasts", 0) + reb
+            return st
         if plan == "bcast-torch":      # fallback transport: scene blob over torch.distributed (host round trips)
             if rank == 0:
                 bvh.rebuild(aabbs, flatten=True)

@@ -102,6 +102,43 @@ class Communicator:
             pass
 
 
+def broadcast_step(comm: "Communicator", rank: int, tree, aabbs, rays, dtype: str, n_shapes: int, hits=None, flags: int = 0, root: int = 0):
+    """One step of the sharded path with the tree rebuilt on `root` every step (bench.py's N > 1 step; one process per GPU):
+
+        root:  Bvh::build_par + flatten enqueued (rebuild_flat_async) → bvhgpu_bcast_known straight out of the tree's buffers (the
+               status header is composed on the device from the build's own outcome) → its own shard's walk enqueued
+        peer:  the receive enqueued → its shard's walk enqueued
+        all :  ONE host wait at the end — no host synchronisation before it on any rank.
+
+    `tree`: on the root the Bvh (rebuilt from `aabbs`, a device tensor or None to send the tree as it is); on a peer None or the FlatBvh
+    the previous step returned (its HBM is reused).  BVHGPU_REBROADCAST — the root's optimistic build needed the slow path, which
+    every rank sees at its wait — repeats the exchange with the finished tree (the root's own batch is complete by then).
+    Returns (tree, stats of this rank's batch, number of rebroadcasts)."""
+    from ._lib import REBROADCAST, BvhGpuError
+    rebroadcasts = 0
+    stats = None
+    for attempt in range(3):
+        if rank == root:
+            if attempt == 0 and aabbs is not None:
+                tree.rebuild_async(aabbs)
+            comm.bcast(tree, root, dtype, n_shapes)
+            if attempt > 0:                      # the root's batch was completed by the wait that raised
+                return tree, stats, rebroadcasts
+            h = tree.traverse_async(rays, hits, flags=flags)
+        else:
+            tree = comm.bcast(tree, root, dtype, n_shapes)
+            h = tree.traverse_async(rays, hits, flags=flags)
+        try:
+            return tree, h.wait(), rebroadcasts
+        except BvhGpuError as e:
+            if e.status != REBROADCAST:
+                raise
+            rebroadcasts += 1
+            if rank == root:
+                stats = h.wait()                 # (complete already: the wait that raised replayed it on the finished tree)
+    raise RuntimeError("the broadcast did not settle after two rebroadcasts")
+
+
 class LocalCommunicator:
     """bvhgpu_comm over several ctxs of ONE process (bvhgpu_comm_init_all = ncclCommInitAll): ctx i is rank i.  `bcast`
     takes one tree per ctx — the root's is the source, a peer's entry is None or a FlatBvh an earlier bcast returned — and

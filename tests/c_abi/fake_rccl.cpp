@@ -4,23 +4,35 @@
 // has — real RCCL refuses two ranks on one device, and this container can reach no multi-GPU node.  It does not test
 // RCCL itself: a broadcast here is a device-to-device copy ordered with events (root stream → peer stream → root stream).
 //
-//   ncclCommInitAll(comms, ndev, devs)   ndev ranks of one world, any devices (also all the same one)
-//   ncclCommInitRank(..., nranks == 1)   a world of one (more ranks would need other processes: ncclInvalidUsage)
+//   ncclCommInitAll(comms, ndev, devs)   ndev ranks of one world driven by ONE thread, any devices (also all the same one)
+//   ncclCommInitRank(nranks, id, rank)   one rank per THREAD of this process (the process-per-GPU form of the C ABI, with threads
+//                                        standing in for processes): the ranks that present the same unique id form a world; a
+//                                        group's collectives run when every rank of the world has closed its group (a barrier)
 //   ncclGroupStart / ncclGroupEnd        the k-th broadcast each rank enqueued in the group forms the k-th collective
-//   ncclBroadcast                        inside a group: recorded; outside: only meaningful for a world of one
+//   ncclBroadcast                        inside a group: recorded; outside: a group of one call
 // Mismatched collectives (different counts / roots / number of calls across the ranks of a group) return
 // ncclInvalidUsage — what would be a hang or corruption with the real library is a test failure here.
 // build: hipcc -shared -fPIC -o libfakerccl.so fake_rccl.cpp   (tests/conftest.py does it)
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <string>
 #include <vector>
 
 namespace {
-struct World { int nranks; int live; };
+struct Op;
+struct World {
+    int nranks; int live;
+    bool threaded = false;                      // ranks are threads (ncclCommInitRank): groups meet at a barrier
+    std::mutex mu; std::condition_variable cv;
+    std::vector<std::vector<Op>> pending;       // per rank: the ops of the group it has closed
+    int arrived = 0; unsigned long long round = 0; ncclResult_t result = ncclSuccess;
+};
 struct Comm { World* world; int rank; int device; };
 struct Op { Comm* comm; const void* send; void* recv; size_t bytes; int root; hipStream_t stream; };
 thread_local int g_depth = 0;
@@ -82,40 +94,79 @@ ncclResult_t run_ops(std::vector<Op>& ops) {
 
 extern "C" {
 
+static std::mutex g_mu;
+static std::map<std::string, World*> g_worlds;   // unique id → world being formed by ncclCommInitRank
+static unsigned long long g_ids = 0;
+
 ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
     if (!id) return ncclInvalidArgument;
+    std::lock_guard<std::mutex> lk(g_mu);
     std::memset(id, 0, sizeof *id);
-    std::memcpy(id->internal, "fake_rccl", 9);
+    snprintf(id->internal, sizeof id->internal, "fake_rccl-%llu", ++g_ids);
     return ncclSuccess;
 }
-ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId, int rank) {
-    if (!comm || nranks != 1 || rank != 0) { fprintf(stderr, "fake_rccl: ncclCommInitRank supports one rank only (one process)\n"); return ncclInvalidUsage; }
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank) {
+    if (!comm || nranks < 1 || rank < 0 || rank >= nranks) return ncclInvalidArgument;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return ncclUnhandledCudaError;
-    World* w = new World{1, 1};
-    *comm = reinterpret_cast<ncclComm_t>(new Comm{w, 0, dev});
+    std::lock_guard<std::mutex> lk(g_mu);
+    const std::string key(id.internal, sizeof id.internal);
+    World*& w = g_worlds[key];
+    if (!w) { w = new World(); w->nranks = nranks; w->live = nranks; w->threaded = nranks > 1; w->pending.resize(nranks); }
+    if (w->nranks != nranks) return ncclInvalidUsage;
+    *comm = reinterpret_cast<ncclComm_t>(new Comm{w, rank, dev});
     return ncclSuccess;
 }
 ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devs) {
     if (!comms || ndev < 1) return ncclInvalidArgument;
-    World* w = new World{ndev, ndev};
+    World* w = new World();
+    w->nranks = ndev; w->live = ndev;
     for (int i = 0; i < ndev; i++) comms[i] = reinterpret_cast<ncclComm_t>(new Comm{w, i, devs ? devs[i] : i});
     return ncclSuccess;
 }
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
     Comm* c = reinterpret_cast<Comm*>(comm);
     if (!c) return ncclInvalidArgument;
-    if (--c->world->live == 0) delete c->world;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (--c->world->live == 0) {
+        for (auto it = g_worlds.begin(); it != g_worlds.end(); ++it) if (it->second == c->world) { g_worlds.erase(it); break; }
+        delete c->world;
+    }
     delete c;
     return ncclSuccess;
 }
 ncclResult_t ncclGroupStart() { g_depth++; return ncclSuccess; }
+// a closed group: single-thread worlds run at once; a threaded world's ranks meet here — the last one to arrive runs everybody's ops
+static ncclResult_t close_group(std::vector<Op>& ops) {
+    std::vector<Op> local;
+    std::map<World*, std::vector<Op>> threaded;
+    for (auto& o : ops) (o.comm->world->threaded ? threaded[o.comm->world] : local).push_back(o);
+    ncclResult_t rc = local.empty() ? ncclSuccess : run_ops(local);
+    for (auto& kv : threaded) {
+        World* w = kv.first;
+        const int rank = kv.second[0].comm->rank;
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->pending[rank] = kv.second;
+        const unsigned long long my_round = w->round;
+        if (++w->arrived == w->nranks) {
+            std::vector<Op> all;
+            for (auto& v : w->pending) { all.insert(all.end(), v.begin(), v.end()); v.clear(); }
+            w->result = run_ops(all);
+            w->arrived = 0; w->round++;
+            w->cv.notify_all();
+        } else {
+            w->cv.wait(lk, [&] { return w->round != my_round; });
+        }
+        if (w->result != ncclSuccess) rc = w->result;
+    }
+    return rc;
+}
 ncclResult_t ncclGroupEnd() {
     if (g_depth <= 0) return ncclInvalidUsage;
     if (--g_depth > 0) return ncclSuccess;
     std::vector<Op> ops;
     ops.swap(g_ops);
-    return run_ops(ops);
+    return close_group(ops);
 }
 ncclResult_t ncclBroadcast(const void* send, void* recv, size_t count, ncclDataType_t type, int root, ncclComm_t comm, hipStream_t stream) {
     Comm* c = reinterpret_cast<Comm*>(comm);
@@ -124,7 +175,7 @@ ncclResult_t ncclBroadcast(const void* send, void* recv, size_t count, ncclDataT
     if (g_depth > 0) return ncclSuccess;
     std::vector<Op> ops;
     ops.swap(g_ops);
-    return run_ops(ops);
+    return close_group(ops);
 }
 const char* ncclGetErrorString(ncclResult_t r) {
     switch (r) {

@@ -44,6 +44,28 @@ def test_multi_rank_protocol_on_one_gpu(K):
     assert out["exact_only_hits"] > 0 and all(out["exact_only_travels"].values()), out["exact_only_travels"]
 
 
+@pytest.mark.parametrize("K", [2, 4, 8])
+def test_rank_per_thread_protocol(K):
+    """The process-per-GPU form (bvhgpu_comm_init_rank; every peer's root is REMOTE) with K threads as the K processes of torchrun
+    and the stand-in library's barrier in ncclGroupEnd: bench.py's N > 1 step, the header form, a wrong announcement, the
+    rebroadcast of an unbalanced first build."""
+    import bvh_amd
+    if bvh_amd.device_count() <= 0:
+        pytest.fail("GPU test selected but no HIP device is visible (no CPU fallback exists)")
+    _build_fake()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multi_thread_driver.py"), str(K)], cwd=ROOT, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert not out["errors"] and not any(out["hung"]), out
+    inv, reb = out["expect"]["INVALID_ARG"], out["expect"]["REBROADCAST"]
+    for r, o in enumerate(out["ranks"]):
+        assert o["async_step_equal"] and o["header_form_equal"], (r, o)
+        assert o["wrong_announcement"] == inv, (r, o)
+        assert o["unbalanced"] == [reb, 0, True], (r, o)
+        assert o["unbalanced_steady"] == [0, True], (r, o)
+
+
 def test_rccl_is_loaded_lazily():
     """libbvh_mi355x.so has no link-time dependency on librccl: single-GPU consumers load and run without it, and
     a process without any RCCL gets BVHGPU_RCCL_ERROR from the communicator calls instead of a loader failure."""
