@@ -105,7 +105,7 @@ class Workload:
             self.label = (f"procedural atrium STAND-IN for media/sponza.obj (absent from the reference checkout), "
                           f"{len(self.aabbs_np)} triangles through the OBJ loader")
             if name == "standin-primary":
-                self.config_id, per, self.coherent = 2, rays or 10_000_000, False   # (the engine picks the walk; the COHERENT hint is not needed)
+                self.config_id, per, self.coherent = 2, rays or 10_000_000, True    # primary rays: BVHGPU_TRAVERSE_COHERENT (how the walk hands its hits over)
                 self.scaling = scaling or "weak"
                 c = (self.bounds[:3] + self.bounds[3:]) * 0.5   # pinhole at the scene-bounds centre
                 self.cam = camera(c, c + np.array([1.0, -0.15, 0.25]), fov_y_deg=70.0, aspect=4000 / 2500)

@@ -46,7 +46,7 @@ struct bvhgpu_ctx {
     bool own_stream = false;
     std::string err;
     int n_cu = 256;
-    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0, 0, -1};  // bvhgpu_set_tuning defaults
+    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0, 0, -1, 1};  // bvhgpu_set_tuning defaults
     // timing
     bool timing = false;
     hipEvent_t ev[8] = {};
@@ -147,6 +147,7 @@ struct bvhgpu_hits {
     size_t idx_cap = 0;      // capacity of indices[] in entries (>= pool_cap; staged output sizes it by the hit total)
     bvhgpu::DevBuf raybuf;   // staged output of the wide walk: 2^shift shape indices per ray (traverse.hip WalkOut::raybuf)
     bool pend_staged = false;
+    bool pend_rec8 = false, no_rec8 = false;   // 8-byte pool records in the batch in flight / never again for this result object
     bool ctr_clean = false;  // the counters were zeroed behind the previous call's readback
     int ctr_set = 0;         // which of the two counter sets the next batch uses
     int bsum_set = 0;        // likewise for the wide walk's scan-block sums

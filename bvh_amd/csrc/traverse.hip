@@ -73,6 +73,8 @@ template <typename T> struct WalkOut {
     uint32_t* item_cnt;          // wide walk with several items per ray: hits of item (ray, j), written only when non-zero
     uint32_t* ray_items;         // ... and per ray the set of j that wrote one (kept all-zero between batches like counts)
     uint32_t* scan_sums;         // wide walk: hits per SCAN_BLOCK rays, added up by the workgroups as they finish (a zeroed set; NULL: k_scan_reduce does the sums)
+    uint2* pool8;                // wide walk, whole rays, indices only: 8-byte records {ray, k << 25 | shape} in the pool's memory instead of the 12-byte
+                                 // HitRec (k < 128 and shape < 2^25, else overflow bit 3 and the host replays with HitRec).  NULL: HitRec
     uint32_t* raybuf;            // wide walk, whole rays, indices only: the first 2^stage_shift shapes of ray r go straight to raybuf[r << stage_shift | k]
     uint32_t stage_shift;        // (4 bytes per hit, no record, no atomic); only later hits of a ray become pool records.  NULL: everything through the pool
 };
@@ -204,6 +206,40 @@ __device__ __forceinline__ void report(bool rec, uint32_t shape, T t0, T t1, Lan
 #pragma unroll
             for (int k = 0; k < NV; k++) w.pool_v[NV * slot + k] = vals[k];
         }
+        ray.cnt++;
+    }
+    pc.pos += h; pc.left -= h;
+}
+
+// The same for the 8-byte record of whole-ray index batches (WalkOut::pool8): a third less to write, and to read back in the scatter —
+// the CSR assembly of a hit-heavy batch is bound by exactly these bytes (457 M records for configs[3]'s 100 M rays).
+constexpr uint32_t REC8_SHAPE_BITS = 25;
+__device__ __forceinline__ void pool_invalidate_tail8(uint2* pool, unsigned long long pool_cap, const PoolCursor& pc, int lane) {
+    for (uint32_t j = (uint32_t)lane; j < pc.left; j += WAVE)
+        if (pc.pos + j < pool_cap) pool[pc.pos + j].x = NONE;
+}
+template <typename RAY>
+__device__ __forceinline__ void report8(bool rec, uint32_t shape, RAY& ray, uint2* pool, unsigned long long pool_cap, unsigned long long* ctr,
+                                        PoolCursor& pc, int lane, unsigned long long lt, bool& too_big) {
+    const unsigned long long m = __ballot(rec);
+    if (!m) return;
+    const uint32_t h = (uint32_t)__popcll(m);
+    if (h > pc.left) {   // wave-uniform: start a new chunk, invalidate what is left of the old one
+        pool_invalidate_tail8(pool, pool_cap, pc, lane);
+        unsigned int blo = 0, bhi = 0;
+        if (lane == 0) {
+            unsigned long long b = atomicAdd(&ctr[0], (unsigned long long)pc.next);
+            blo = (unsigned int)b; bhi = (unsigned int)(b >> 32);
+        }
+        blo = __builtin_amdgcn_readfirstlane(blo); bhi = __builtin_amdgcn_readfirstlane(bhi);
+        pc.pos = ((unsigned long long)bhi << 32) | blo;
+        pc.left = pc.next;
+        pc.next = pc.next < POOL_CHUNK_MAX ? pc.next * 2 : POOL_CHUNK_MAX;
+    }
+    if (rec) {
+        const unsigned long long slot = pc.pos + __popcll(m & lt);
+        too_big = too_big || (ray.cnt >> (32u - REC8_SHAPE_BITS)) != 0u || (shape >> REC8_SHAPE_BITS) != 0u;
+        if (slot < pool_cap) pool[slot] = make_uint2(ray.r, (ray.cnt << REC8_SHAPE_BITS) | (shape & ((1u << REC8_SHAPE_BITS) - 1u)));
         ray.cnt++;
     }
     pc.pos += h; pc.left -= h;
@@ -1022,7 +1058,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     ray.clear();
     uint32_t cur = CUR_NONE, sp = 0, item = NONE;
     bool exhausted = wg_begin >= wg_end;   // wave-uniform: the workgroup's range has been handed out
-    bool ovf = false;
+    bool ovf = false, rec8_big = false;
     PoolCursor pc;
     auto push_slow = [&](uint32_t v) {
         if (sp < stack_lds) s_stack[__umul24(sp, bd) + tid] = v;
@@ -1129,11 +1165,17 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                     rec = false;
                 }
             }
-            report<T, MODE>(rec, shape, (T)0, (T)0, ray, w, pc, lane, lt);
+            if (MODE == MODE_INDICES && ITEMS_LOG4 == 0 && w.pool8) report8(rec, shape, ray, w.pool8, w.pool_cap, w.ctr, pc, lane, lt, rec8_big);   // (wave-uniform)
+            else report<T, MODE>(rec, shape, (T)0, (T)0, ray, w, pc, lane, lt);
         }
         if (ovf) { cur = CUR_NONE; sp = 0; }
     }
     if (__any(ovf) && lane == 0) atomicOr(overflow, 4u);
+    if (MODE == MODE_INDICES && ITEMS_LOG4 == 0 && w.pool8) {
+        if (__any(rec8_big) && lane == 0) atomicOr(overflow, 8u);   // a hit did not fit the 8-byte record: the host replays with HitRec
+        pool_invalidate_tail8(w.pool8, w.pool_cap, pc, lane);
+        pc.left = 0;                                                // (nothing left for the epilogue's HitRec form to invalidate)
+    }
     walk_epilogue<T, MODE>(w, pc, lane, false, 0, 0, 0, 0);
     if (MODE != MODE_CLOSEST && w.scan_sums) {   // every wave of the workgroup gets here: all items of its rays have retired
         __syncthreads();
@@ -1338,6 +1380,20 @@ __global__ __launch_bounds__(256) void k_hits_scatter_wide(const HitRec* __restr
     }
 }
 
+// the 8-byte records of a whole-ray index batch (WalkOut::pool8) → indices[offsets[ray] + k]
+__global__ __launch_bounds__(256) void k_hits_scatter8(const uint2* __restrict__ pool, const unsigned long long* __restrict__ ctr,
+                                                       unsigned long long pool_cap, unsigned long long idx_cap, const uint32_t* __restrict__ offsets,
+                                                       uint32_t* __restrict__ indices) {
+    const unsigned long long n = ctr[0];
+    if (n > pool_cap || ctr[3] > idx_cap || (ctr[7] & 8ull)) return;   // too small / a record did not fit: the host grows / switches and replays
+    for (unsigned long long j = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; j < n;
+         j += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint2 h = pool[j];
+        if (h.x == NONE) continue;   // unused tail of a per-wave chunk
+        indices[offsets[h.x] + (h.y >> REC8_SHAPE_BITS)] = h.y & ((1u << REC8_SHAPE_BITS) - 1u);
+    }
+}
+
 // Staged hits (WalkOut::raybuf) → CSR: one thread per ray copies the ray's first min(count, 2^shift) shapes from its own 2^shift-word
 // slot to indices[offsets[ray] ..]: reads of whole 16-byte quads of the slot, writes that neighbouring threads make contiguous.  The later
 // hits of a ray (k >= 2^shift) are pool records and go through k_hits_scatter_wide as before.  Together they replace the
@@ -1503,9 +1559,8 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
                    : (flags & BVHGPU_TRAVERSE_T_SLICE) ? MODE_T_SLICE : MODE_INDICES;
     const int nv = mode == MODE_T_SLICE ? 2 : (mode == MODE_TRIANGLES ? 3 : 0);
     const int variant = ctx->tune[BVHGPU_TUNE_TRAVERSE_VARIANT];
-    // (the COHERENT hint only matters below the large-batch threshold: on 10 M primary rays the wide walk takes 1.8 ms, the
-    //  persistent binary walk 2.2 ms and one ray per lane per launch 5.4 ms)
-    (void)coherent;
+    // (the COHERENT hint does not choose the walk kernel — on 10 M primary rays the wide walk takes 1.5 ms, the persistent binary walk 2.2 ms
+    //  and one ray per lane per launch 5.4 ms — it chooses how the wide walk hands over its hits: see `staged` below)
     const bool big_batch = !ordered && n_rays >= (size_t)ctx->tune[BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS];
     // walk kernel: wide walk (see k_traverse_wide for what it needs), else persistent workgroups over the binary array with
     // its top in LDS, else one ray per lane per launch
@@ -1540,7 +1595,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     WalkOut<T> w;
     w.counts = nullptr; w.pool = nullptr; w.pool_v = nullptr; w.pool_cap = 0; w.ctr = ctr;
     w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr; w.item_cnt = nullptr; w.ray_items = nullptr; w.scan_sums = nullptr;
-    w.raybuf = nullptr; w.stage_shift = 0;
+    w.raybuf = nullptr; w.stage_shift = 0; w.pool8 = nullptr;
 
     uint32_t* ovf_flag = reinterpret_cast<uint32_t*>(ctr + 7);   // bit 0 ordered-iterator stack, bit 1 heap workspace, bit 2 wide-walk stack
     const bool best_first = ordered && (flags & BVHGPU_TRAVERSE_BEST_FIRST) != 0;
@@ -1627,13 +1682,22 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         return;
     }
     // staged output (WalkOut::raybuf): whole rays, indices only — the hit-heavy large batches; stage_shift 3 = eight shapes per ray
-    const int stage_shift = ctx->tune[BVHGPU_TUNE_WIDE_STAGE_SHIFT] < 0 ? 3 : std::min(ctx->tune[BVHGPU_TUNE_WIDE_STAGE_SHIFT], 5);
+    // Default: for batches the caller calls COHERENT (primary rays).  Measured on the stand-in scene: 10 M coherent rays 2.60 → 2.17 ms per
+    // step (the walk itself 1.79 → 1.54: no chunk atomics, a third of the bytes; neighbouring rays' slots are written close in time and
+    // merge in L2); 12.5 M incoherent rays 3.30 → 3.23; 100 M incoherent rays 21.1 → 22.0 (the walk 16.3 → 18.4: every hit of a
+    // wave lands on a line of its own) — so incoherent batches keep the pool, whose records a wave writes contiguously.
+    const int stage_knob = ctx->tune[BVHGPU_TUNE_WIDE_STAGE_SHIFT];
+    const int stage_shift = stage_knob < 0 ? (coherent ? 3 : 0) : std::min(stage_knob, 5);
     const bool staged = use_wide && items_log4 == 0 && mode == MODE_INDICES && stage_shift >= 2;
     h->pend_staged = staged;
     if (h->idx_cap < h->pool_cap) h->idx_cap = h->pool_cap;
     h->pool.reserve(h->pool_cap * sizeof(HitRec));
     h->indices.reserve(h->idx_cap * 4);
     if (staged) { h->raybuf.reserve(((size_t)n_rays << stage_shift) * 4 + 64); w.raybuf = h->raybuf.as<uint32_t>(); w.stage_shift = (uint32_t)stage_shift; }
+    // 8-byte pool records for whole-ray index batches, unless this result object has met a batch that did not fit them
+    const bool rec8 = use_wide && items_log4 == 0 && mode == MODE_INDICES && !h->no_rec8 && t->n <= ((size_t)1 << REC8_SHAPE_BITS) &&
+                      ctx->tune[BVHGPU_TUNE_WIDE_REC8] != 0;
+    h->pend_rec8 = rec8;
     if (nv) {
         h->pool_t.reserve(h->pool_cap * nv * sizeof(T));
         (mode == MODE_T_SLICE ? h->tslice : h->isect).reserve(h->pool_cap * nv * sizeof(T));
@@ -1672,6 +1736,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         counts = h->counts.as<uint32_t>();
     }
     w.counts = counts; w.pool = h->pool.as<HitRec>(); w.pool_v = h->pool_t.as<T>(); w.pool_cap = cap;
+    w.pool8 = rec8 ? h->pool.as<uint2>() : nullptr;
     if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
     DISPATCH_WALK();
     if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); }
@@ -1711,7 +1776,9 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
             default: hipLaunchKernelGGL(k_hits_gather_staged<5>, dim3(ggrid), dim3(256), 0, st, w.raybuf, offs, nr, ctr, icap, indices); break;
         }
     }
-    if (use_wide) {
+    if (rec8) {
+        hipLaunchKernelGGL(k_hits_scatter8, dim3(sgrid), dim3(256), 0, st, w.pool8, ctr, cap, (unsigned long long)h->idx_cap, offs, indices);
+    } else if (use_wide) {
         const uint32_t* icnt = h->item_cnt.as<uint32_t>();
 #define SCATTER_WIDE(NV, L4) hipLaunchKernelGGL((k_hits_scatter_wide<T, NV, L4>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, (unsigned long long)h->idx_cap, offs, icnt, rmask, indices, vals)
         if (nv == 3) { if (items_log4 == 2) SCATTER_WIDE(3, 2); else if (items_log4 == 1) SCATTER_WIDE(3, 1); else SCATTER_WIDE(3, 0); }
@@ -1750,6 +1817,9 @@ bool traverse_check(bvhgpu_hits* h) {
         h->heap_cap *= 2; return false;
     }
     if (ordered && (pin[7] & 1ull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
+    if (h->pend_rec8 && (pin[7] & 8ull)) {   // a ray with 128+ hits (or a shape index beyond 2^25): this result object goes back to 12-byte records
+        h->no_rec8 = true; h->wcounts_clean = false; return false;
+    }
     if (h->pend_wide && (pin[7] & 4ull)) {   // a lane's stack outgrew LDS + workspace: the binary walks need no stack
         h->force_binary = true; h->wcounts_clean = false; h->bs_clean = false; h->ray_items.release(); return false;
     }

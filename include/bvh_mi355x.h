@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BVHGPU_ABI_VERSION 3 /* 3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 13 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
+#define BVHGPU_ABI_VERSION 3 /* 3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 14 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT, 13 = WIDE_REC8), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
 #define BVHGPU_NONE 0xFFFFFFFFu /* u32::MAX marker (flat_bvh.rs:51-53, :124, :137) */
 
 typedef enum {
@@ -83,8 +83,8 @@ typedef enum { BVHGPU_HOST = 0, BVHGPU_DEVICE = 1 } bvhgpu_mem;
                                           enqueued (resident ray buffers of a frame loop).  The engine may then read them while the build
                                           is still running — the wide walk's per-ray item filter runs beside the build on a second
                                           stream instead of in front of the walk.  Results never depend on it */
-#define BVHGPU_TRAVERSE_COHERENT 16u /* hint: neighbouring rays are similar (primary rays).  Only consulted for batches below the
-                                        large-batch threshold (BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS); results never depend on it */
+#define BVHGPU_TRAVERSE_COHERENT 16u /* hint: neighbouring rays are similar (primary rays).  Large whole-ray batches then hand their hits over
+                                        through per-ray slots instead of pool records (BVHGPU_TUNE_WIDE_STAGE_SHIFT); results never depend on it */
 
 /* ---- POD layouts (little-endian, natural alignment, no packing pragmas) ---- */
 
@@ -353,8 +353,11 @@ typedef enum {
                                               much — kept selectable, off by default */
     BVHGPU_TUNE_WIDE_STAGE_SHIFT = 12,     /* variant 3, whole rays (large batches), indices only: the first 2^v shapes of every ray are written straight to a
                                               per-ray slot (4 bytes per hit) and gathered into the CSR; only later hits of a ray go through 12-byte pool
-                                              records.  -1 (default) = 3; 0 = off (every hit through the pool); 2 .. 4 */
-    BVHGPU_TUNE_COUNT = 13
+                                              records.  -1 (default) = 3 for batches flagged BVHGPU_TRAVERSE_COHERENT, off otherwise; 0 = off (every hit
+                                              through the pool); 2 .. 5 = on for every such batch */
+    BVHGPU_TUNE_WIDE_REC8 = 13,            /* variant 3, whole rays, indices only: pool records of 8 bytes {ray, k << 25 | shape} instead of 12 (a ray with 128+
+                                              hits or a scene beyond 2^25 shapes falls back by itself); 1 (default) on, 0 off */
+    BVHGPU_TUNE_COUNT = 14
 } bvhgpu_tune;
 int bvhgpu_set_tuning(bvhgpu_ctx *ctx, int knob, int value);
 int bvhgpu_get_tuning(const bvhgpu_ctx *ctx, int knob, int *value);

@@ -210,5 +210,5 @@ def test_staged_hit_output_growth_and_order(eng, orc, shift):
     assert len(oidx) > 4_000_000
     rb = RayBatch(R, np.float32, host=rays)
     for _ in range(2):
-        off, idx, _, _ = flat.traverse_batch(rb)
+        off, idx, _, _ = flat.traverse_batch(rb, coherent=True)   # (the default stages only batches flagged COHERENT)
         assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)

@@ -154,12 +154,12 @@ def test_config3_incoherent_rays_shard(eng, orc, atrium):
 
 
 # ---- round 3: EVERY ray of configs[2] / [3] diffed against the oracle, at the bench's scene size ----------
-def _full_csr_diff(eng, orc, flat, aabbs, rb, oracle_rays, n, chunk=1_000_000):
+def _full_csr_diff(eng, orc, flat, aabbs, rb, oracle_rays, n, chunk=1_000_000, coherent=False):
     """ONE GPU traversal of the whole batch (the walk the bench times: the wide walk with whole rays above ~2 M rays), CSR fetched
     once; the oracle goes through the rays in 1 M-ray chunks and each chunk is compared with its slice — offsets, indices (i.e.
     the per-ray ORDER of flat_bvh.rs:396-431) — and the reference-equivalent visit counters with a STATS pass."""
     import hashlib
-    off, idx, _, _ = flat.traverse_batch(rb)
+    off, idx, _, _ = flat.traverse_batch(rb, coherent=coherent)   # (coherent: hits handed over through per-ray slots, as bench.py's configs[2] does)
     st = flat.traverse_batch(rb, stats=True, fetch=False)[3]
     oflat = orc.flatten(orc.build(aabbs).nodes)
     V = VL = H = 0
@@ -195,7 +195,7 @@ def test_config2_all_10m_primary_rays_against_oracle(eng, orc, atrium16):
     flat = eng.Bvh.from_aabbs(aabbs, ctx).flatten()
     buf = torch.empty(W * H * RAY_F32.itemsize, dtype=torch.uint8, device="cuda")
     rb = eng.RayBatch.primary(cam, W, H, 0, W * H, buf, np.float32, ctx)
-    hits = _full_csr_diff(eng, orc, flat, aabbs, rb, lambda c0, m: orc.primary_rays(cam, W, H, c0, m), W * H)
+    hits = _full_csr_diff(eng, orc, flat, aabbs, rb, lambda c0, m: orc.primary_rays(cam, W, H, c0, m), W * H, coherent=True)
     assert hits > 3 * W * H
 
 
