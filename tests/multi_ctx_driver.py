@@ -212,9 +212,22 @@ def main():
     out["exact_only_travels"] = res
     out["exact_only_hits"] = int(len(fidx))
 
-    if not real:
-        import ctypes as C
-        out["fake_collectives"] = int(C.CDLL(os.environ["BVHGPU_RCCL_LIB"]).fake_rccl_collectives()) if False else None
+    # ---- 7. the triangle vertices travel when asked for: every rank's fused closest hit == the harness loop of the oracle ------
+    tris, _ = tb.create_n_cubes(2500)
+    root.rebuild(aabbs_dev, flatten=True)
+    root.set_triangles(torch.from_numpy(tris.reshape(-1, 9)).to(dev_of(0)))
+    _, oclosest, oprim = orc.triangle_stage(tris, orc.create_rays(0, T), ooff, oidx)
+    res = {}
+    for form in ("header", "known"):
+        trees7 = comm.bcast([root] + [None] * (K - 1), 0, *(() if form == "header" else ("f32", n)), triangles=True)
+        ok = True
+        for i, (first, cnt) in enumerate(shards):
+            cl, prim, _ = trees7[i].closest_hits(rays[i])
+            ok = ok and cl.tobytes() == oclosest[first:first + cnt].tobytes() and bool(np.array_equal(prim, oprim[first:first + cnt]))
+        res[form] = bool(ok)
+        for t in trees7[1:]:
+            t.close()
+    out["triangles_travel"] = res
     for h in hits:
         h.close()
     comm.close()

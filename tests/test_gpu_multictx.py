@@ -42,6 +42,7 @@ def test_multi_rank_protocol_on_one_gpu(K):
     assert out["unbalanced_rebroadcast_ok"], out["unbalanced_first_statuses"]
     assert out["unbalanced_steady_state_ok"]
     assert out["exact_only_hits"] > 0 and all(out["exact_only_travels"].values()), out["exact_only_travels"]
+    assert all(out["triangles_travel"].values()), out["triangles_travel"]
 
 
 @pytest.mark.parametrize("K", [2, 4, 8])
