@@ -134,7 +134,7 @@ void finish_hits(bvhgpu_hits* h) {
 // Before a tree's arrays are overwritten or freed (rebuild, refit, import, broadcast receive, destroy): the asynchronous batches
 // that were enqueued on it are completed first, so that a replay never runs on the wrong tree and no result object keeps a
 // dangling pointer.  A failure is kept in the result object and returned by its own bvhgpu_hits_wait.
-void settle_waiters(bvhgpu_tree* t) {
+void settle_waiters_impl(bvhgpu_tree* t) {
     while (!t->waiters.empty()) {
         bvhgpu_hits* h = t->waiters.back();
         bvhgpu_ctx* hc = h->ctx;
@@ -155,7 +155,7 @@ template <typename T> int do_build(bvhgpu_tree* t, const T* aabbs, size_t n, int
     use_device(ctx);
     try { ensure_built(t); }   // a previous asynchronous build of this tree (its outcome no longer matters: everything is rebuilt)
     catch (const HipFail& e) { if (!e.what || (std::strcmp(e.what, "REBROADCAST") != 0 && std::strcmp(e.what, "NONFINITE") != 0 && std::strncmp(e.what, "RECV_", 5) != 0)) throw; }
-    settle_waiters(t);
+    settle_waiters_impl(t);
     if (ctx->timing) BVH_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
     const T* dev = aabbs;
     if (n && mem == BVHGPU_HOST) {  // upload straight into the tree's own copy
@@ -175,7 +175,7 @@ template <typename T> int do_refit(bvhgpu_tree* t, const T* aabbs, size_t n, int
     bvhgpu_ctx* ctx = t->ctx;
     use_device(ctx);
     ensure_built(t);
-    settle_waiters(t);
+    settle_waiters_impl(t);
     if (!t->built) return fail(ctx, BVHGPU_INVALID_ARG, "refit needs a tree that was built here (imported scenes carry no BvhNode array)");
     if (n != t->n) return fail(ctx, BVHGPU_INVALID_ARG, "refit: the number of shapes differs from the tree's (build again)");
     if (n && !aabbs) return fail(ctx, BVHGPU_INVALID_ARG, "aabbs is NULL");
@@ -420,6 +420,10 @@ int do_nearest(bvhgpu_tree* t, const T* points, size_t n, int mem, int kind, uin
 
 }  // namespace
 
+namespace bvhgpu {
+void settle_waiters(bvhgpu_tree* t) { settle_waiters_impl(t); }   // (comm.hip: a peer's tree is about to be overwritten by a broadcast)
+}
+
 #ifdef BVH_PROFILE_MID
 namespace bvhgpu { void debug_mid_prof(unsigned long long* out, bool reset); }
 #endif
@@ -615,7 +619,7 @@ void bvhgpu_tree_destroy(bvhgpu_tree* t) {
     if (t->ctx) { (void)hipSetDevice(t->ctx->device); (void)hipStreamSynchronize(t->ctx->stream); }
     if (!t->waiters.empty()) {   // asynchronous batches still refer to this tree: complete them while it exists
         (void)settle(t);
-        settle_waiters(t);
+        settle_waiters_impl(t);
     }
     free_tree_buffers(t);
     delete t;
@@ -752,7 +756,7 @@ int bvhgpu_scene_import(bvhgpu_ctx* ctx, const void* src, size_t nbytes, int mem
     if (given && given->ctx == ctx && (given->pending_build || given->pending_recv)) (void)settle(given);   // whatever was in flight is replaced
     if (given && (given->built || given->pending_build || given->ctx != ctx))
         return fail(ctx, BVHGPU_INVALID_ARG, "*out must be NULL or a tree from bvhgpu_scene_import on this ctx");
-    if (given) settle_waiters(given);
+    if (given) settle_waiters_impl(given);
     bvhgpu_tree* t = given ? given : new bvhgpu_tree();
     t->ctx = ctx;
     int rc = guarded(ctx, [&] {
@@ -863,6 +867,7 @@ static int set_triangles(bvhgpu_tree* t, const void* verts, size_t n, int mem, i
     return guarded(ctx, [&] {
         use_device(ctx);
         const size_t bytes = n * 9 * (dtype == BVHGPU_F32 ? 4 : 8);
+        settle_waiters_impl(t);   // (a replay of a batch in flight must see the vertices it was enqueued with)
         t->tris.reserve(bytes + 16);
         if (bytes) {
             BVH_HIP(hipMemcpyAsync(t->tris.p, verts, bytes, mem == BVHGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));

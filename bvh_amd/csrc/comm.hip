@@ -265,6 +265,7 @@ void prepare_trees(bvhgpu_comm* c, bvhgpu_tree** trees, int root, PeerPlan& plan
             catch (...) { t->pending_build = false; t->pending_recv = false; }
         }
         if (t && (t->built || t->ctx != c->ctxs[i])) { plan.bad = i; t = nullptr; }
+        if (t && !t->waiters.empty()) settle_waiters(t);   // batches still in flight on the peer's old tree are completed on it first
         if (!t) {
             trees[i] = new bvhgpu_tree();
             trees[i]->ctx = c->ctxs[i];

@@ -195,6 +195,8 @@ constexpr int BUILD_CTR_TOPMASK = 5;   // u32 slot of the build counters: bit h 
 template <typename T> void wide_from_trav(bvhgpu_tree* t);   // wide nodes + their LDS slot table from trav + slot_entry
 // comm.hip: completes a broadcast that was received on the stream (reads the status header; throws RECV_* on a bad one)
 void recv_finalize(bvhgpu_tree* t);
+// capi.hip: completes the asynchronous batches still in flight on a tree whose arrays are about to be overwritten or freed
+void settle_waiters(bvhgpu_tree* t);
 // refit.hip
 template <typename T> void refit_tree(bvhgpu_tree* t, const T* aabbs_dev);
 // traverse.hip
