@@ -2063,7 +2063,8 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
         if (fixed > MAXLV - 4) fixed = MAXLV - 4;
         for (; level < fixed; level++) {
             run_level<T>(t, a, g, level);
-            if (level == 3) {   // tree levels 0..3 are split: their BvhNode records (and with them the boxes of the 16 subtrees the wide
+            if (level == 3 && ctx->tune[BVHGPU_TUNE_WIDE_EARLY_ITEMS] != 0) {   // (only when the early item filter is switched on: an event record costs the level chain a gap)
+                // tree levels 0..3 are split: their BvhNode records (and with them the boxes of the 16 subtrees the wide
                                 // walk cuts its rays into) are final — a batch enqueued behind this build may filter its rays from here on
                 if (!t->ev_top) BVH_HIP(hipEventCreateWithFlags(&t->ev_top, hipEventDisableTiming));
                 BVH_HIP(hipEventRecord(t->ev_top, st));
