@@ -1719,8 +1719,18 @@ __device__ __forceinline__ double push_lane(double v, int dst) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+#ifdef BVH_SMALL_PROFILE   // developer build (tools/small_prof.py): 100 MHz wall-clock stamps per wave of k_small
+__device__ unsigned long long g_small_prof[20 * 8192];   // [0] entry, [1] item + shapes loaded, [2 + L] level L finished (L < 16), [18] exit, [19] shapes
+void debug_small_prof(unsigned long long* out, size_t n) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_prof), sizeof(unsigned long long) * n);
+}
+#endif
 template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T> a, uint32_t first) {
     using Tr = Traits<T>;
+#ifdef BVH_SMALL_PROFILE
+    const unsigned long long sp_t0 = wall_clock64();
+#endif
     const uint32_t n_small = a.ctr[CTR_SMALL];
     const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -1749,8 +1759,22 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
 #pragma unroll
     for (int k = 0; k < 6; k++) { Cb[k] = it->C[k]; A0[k] = it->A[k]; }
     T saA = surface_area(A0);
+#ifdef BVH_SMALL_PROFILE
+    int sp_level = 0;
+    const bool sp_on = wave < 8192 && wave == first + wave0 && lane == 0;
+    if (sp_on) {
+        g_small_prof[20 * wave] = sp_t0;
+        g_small_prof[20 * wave + 1] = wall_clock64() + (unsigned long long)(box[0] != box[0] ? 1 : 0);   // (after the shape loads have landed)
+        g_small_prof[20 * wave + 19] = (unsigned long long)n;
+        for (int i = 2; i < 19; i++) g_small_prof[20 * wave + i] = 0;
+    }
+#endif
 
     while (true) {
+#ifdef BVH_SMALL_PROFILE
+        if (sp_on && sp_level > 0 && sp_level <= 16) g_small_prof[20 * wave + 1 + sp_level] = wall_clock64();
+        sp_level++;
+#endif
         int segn = hi - lo;
         if (!done && segn == 1) {  // bvh_node.rs:95-104
             typename Tr::Node* nd = &a.nodes[ni];
@@ -1878,6 +1902,9 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
             for (int k = 0; k < 6; k++) Cb[k] = Cn[k];
         }
     }
+#ifdef BVH_SMALL_PROFILE
+    if (sp_on) g_small_prof[20 * wave + 18] = wall_clock64();
+#endif
     }
 }
 

@@ -430,8 +430,11 @@ namespace bvhgpu { void debug_mid_prof(unsigned long long* out, bool reset); }
 #ifdef BVH_LEVEL_PROFILE
 namespace bvhgpu { void debug_level_prof(unsigned long long* out, size_t n); }
 #endif
+#ifdef BVH_SMALL_PROFILE
+namespace bvhgpu { void debug_small_prof(unsigned long long* out, size_t n); }
+#endif
 #ifdef BVH_WIDE_PROFILE
-namespace bvhgpu { void debug_wide_prof(unsigned long long* out, size_t n); }
+namespace bvhgpu { void debug_wide_prof(unsigned long long* out, size_t n); void debug_wide_util(unsigned long long* out, size_t n); }
 #endif
 
 extern "C" {
@@ -990,6 +993,10 @@ void bvhgpu_debug_level_prof(unsigned long long* out, size_t n) { bvhgpu::debug_
 #endif
 #ifdef BVH_WIDE_PROFILE
 void bvhgpu_debug_wide_prof(unsigned long long* out, size_t n) { bvhgpu::debug_wide_prof(out, n); }
+void bvhgpu_debug_wide_util(unsigned long long* out, size_t n) { bvhgpu::debug_wide_util(out, n); }
+#endif
+#ifdef BVH_SMALL_PROFILE
+void bvhgpu_debug_small_prof(unsigned long long* out, size_t n) { bvhgpu::debug_small_prof(out, n); }
 #endif
 #ifdef BVH_PROFILE_MID
 void bvhgpu_debug_mid_prof(unsigned long long* out, int reset) { bvhgpu::debug_mid_prof(out, reset != 0); }

@@ -214,6 +214,9 @@ __device__ __forceinline__ void report(bool rec, uint32_t shape, T t0, T t1, Lan
 // The same for the 8-byte record of whole-ray index batches (WalkOut::pool8): a third less to write, and to read back in the scatter —
 // the CSR assembly of a hit-heavy batch is bound by exactly these bytes (457 M records for configs[3]'s 100 M rays).
 constexpr uint32_t REC8_SHAPE_BITS = 25;
+#ifndef SCATTER8_UNROLL
+#define SCATTER8_UNROLL 16
+#endif
 __device__ __forceinline__ void pool_invalidate_tail8(uint2* pool, unsigned long long pool_cap, const PoolCursor& pc, int lane) {
     for (uint32_t j = (uint32_t)lane; j < pc.left; j += WAVE)
         if (pc.pos + j < pool_cap) pool[pc.pos + j].x = NONE;
@@ -969,6 +972,11 @@ __global__ __launch_bounds__(256) void k_wide_items(const typename Traits<T>::No
 
 #ifdef BVH_WIDE_PROFILE   // developer build: per-wave timestamps (100 MHz wall clock) of the wide walk's phases
 __device__ unsigned long long g_wide_prof[4 * 16384];
+// lane-utilisation counts per wave (16 per wave): [0] wave-steps, [1] lanes on an inner node, [2] steps with a resident fetch,
+// [3] steps with a non-resident fetch, [4] steps with a lane on the slow push path, [5] lanes on it, [6] lanes reporting a leaf,
+// [7] steps with a report, [8] lanes holding an item (x steps), [9] refill rounds, [10] rounds on the exact (non-finite) path,
+// [11] steps with a pop from the HBM part of the stack, [12] boxes hit (sum of popc(m)), [13] lanes whose node had no hit
+__device__ unsigned long long g_wide_util[16 * 16384];
 #endif
 // ITEMS_LOG4 = 0: one item per ray, drawn by ray number.  1 / 2: every workgroup first cuts ITS rays into live items (its
 // region of `list`, filled through an LDS counter — no global atomic: one address only takes ~88 atomics per µs on this
@@ -998,6 +1006,9 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
 #ifdef BVH_WIDE_PROFILE
     const unsigned long long prof_t0 = wall_clock64();
     unsigned long long prof_steps = 0;
+    unsigned long long pu[16];
+    for (int i = 0; i < 16; i++) pu[i] = 0;
+    uint32_t pl_boxes = 0, pl_nohit = 0;
 #endif
     // This workgroup's rays: the 64-ray blocks b, b + grid, b + 2 grid, ... of the batch.  (Contiguous ranges per workgroup
     // put all of a stream's expensive stretch — the BASELINE stream's first 5 000 rays start inside a cube — on a few
@@ -1131,8 +1142,23 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
         const bool fast = !__any(run && !ray.fin);   // wave-uniform
 #ifdef BVH_WIDE_PROFILE
         prof_steps += WIDE_INNER_STEPS;
+        pu[9]++; pu[10] += fast ? 0 : 1;
+        pu[8] += WIDE_INNER_STEPS * (unsigned long long)__popcll(__ballot(run));
 #endif
         for (int s = 0; s < WIDE_INNER_STEPS; s++) {
+#ifdef BVH_WIDE_PROFILE
+            {
+                const bool in = (cur & WIDE_INNER) != 0u;
+                pu[0]++; pu[1] += __popcll(__ballot(in));
+                pu[2] += __any(in && (cur & WIDE_RESIDENT)) ? 1 : 0;
+                pu[3] += __any(in && !(cur & WIDE_RESIDENT)) ? 1 : 0;
+                const bool slow = in && sp + 3u > stack_lds;
+                pu[4] += __any(slow) ? 1 : 0; pu[5] += __popcll(__ballot(slow));
+                const bool lf = !in && cur < CUR_NONE;
+                pu[6] += __popcll(__ballot(lf)); pu[7] += __any(lf) ? 1 : 0;
+                pu[11] += __any((in || lf) && sp > stack_lds) ? 1 : 0;
+            }
+#endif
             if (cur & WIDE_INNER) {   // (CUR_NONE and shape indices have bit 31 clear)
                 const uint32_t id = cur & (WIDE_RESIDENT - 1u);
                 WideRegs<T> nd;
@@ -1142,6 +1168,9 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                 // the lowest hit slot is visited now, the others wait on the stack, highest slot first
                 const uint32_t first = m & (0u - m);
                 const uint32_t rest = m ^ first;
+#ifdef BVH_WIDE_PROFILE
+                pl_boxes += (uint32_t)__popc(m); pl_nohit += m == 0u ? 1u : 0u;
+#endif
                 const uint32_t s0 = (rest & 8u) ? nd.ref[3] : ((rest & 4u) ? nd.ref[2] : nd.ref[1]);
                 const uint32_t s1 = ((rest & 12u) == 12u) ? nd.ref[2] : nd.ref[1];
                 if (sp + 3u <= stack_lds) {   // room for three: store them all, count what is real
@@ -1187,8 +1216,14 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
 #ifdef BVH_WIDE_PROFILE
     if (lane == 0) {
         const size_t wv = gid >> 6;
-        if (wv < 16384) { g_wide_prof[4 * wv] = prof_t0; g_wide_prof[4 * wv + 1] = prof_t1; g_wide_prof[4 * wv + 2] = wall_clock64(); g_wide_prof[4 * wv + 3] = prof_steps; }
+        if (wv < 16384) {
+            g_wide_prof[4 * wv] = prof_t0; g_wide_prof[4 * wv + 1] = prof_t1; g_wide_prof[4 * wv + 2] = wall_clock64(); g_wide_prof[4 * wv + 3] = prof_steps;
+            for (int i = 0; i < 12; i++) g_wide_util[16 * wv + i] = pu[i];
+            g_wide_util[16 * wv + 12] = 0; g_wide_util[16 * wv + 13] = 0;
+        }
     }
+    __syncthreads();
+    if ((gid >> 6) < 16384) { atomicAdd(&g_wide_util[16 * (gid >> 6) + 12], (unsigned long long)pl_boxes); atomicAdd(&g_wide_util[16 * (gid >> 6) + 13], (unsigned long long)pl_nohit); }
 #endif
 }
 
@@ -1381,17 +1416,34 @@ __global__ __launch_bounds__(256) void k_hits_scatter_wide(const HitRec* __restr
 }
 
 // the 8-byte records of a whole-ray index batch (WalkOut::pool8) → indices[offsets[ray] + k]
+__device__ __forceinline__ void scatter8_role(uint32_t block, uint32_t nblocks, const uint2* __restrict__ pool, const unsigned long long* __restrict__ ctr,
+                                              unsigned long long pool_cap, unsigned long long idx_cap, const uint32_t* __restrict__ offsets,
+                                              uint32_t* __restrict__ indices) {
+    const unsigned long long n = ctr[0];
+    if (n > pool_cap || ctr[3] > idx_cap || (ctr[7] & 8ull)) return;   // too small / a record did not fit: the host grows / switches and replays
+    // SCATTER8_UNROLL records per thread and round, loads first: a record costs two dependent reads (the record, then its ray's offset)
+    // and the kernel is latency-bound (PMC: 0.40 of the HBM rate, 82 % of wave-time waiting with one record in flight per thread)
+    constexpr uint32_t U = SCATTER8_UNROLL;
+    const unsigned long long span = (unsigned long long)blockDim.x * U;
+    for (unsigned long long j0 = block * span + threadIdx.x; j0 < n; j0 += (unsigned long long)nblocks * span) {
+        uint2 h[U];
+        uint32_t o[U];
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const unsigned long long j = j0 + (unsigned long long)u * blockDim.x;
+            h[u] = j < n ? pool[j] : make_uint2(NONE, 0u);   // (NONE also marks the unused tail of a per-wave chunk)
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++) o[u] = h[u].x != NONE ? offsets[h[u].x] : 0u;
+#pragma unroll
+        for (uint32_t u = 0; u < U; u++)
+            if (h[u].x != NONE) indices[o[u] + (h[u].y >> REC8_SHAPE_BITS)] = h[u].y & ((1u << REC8_SHAPE_BITS) - 1u);
+    }
+}
 __global__ __launch_bounds__(256) void k_hits_scatter8(const uint2* __restrict__ pool, const unsigned long long* __restrict__ ctr,
                                                        unsigned long long pool_cap, unsigned long long idx_cap, const uint32_t* __restrict__ offsets,
                                                        uint32_t* __restrict__ indices) {
-    const unsigned long long n = ctr[0];
-    if (n > pool_cap || ctr[3] > idx_cap || (ctr[7] & 8ull)) return;   // too small / a record did not fit: the host grows / switches and replays
-    for (unsigned long long j = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; j < n;
-         j += (unsigned long long)gridDim.x * blockDim.x) {
-        const uint2 h = pool[j];
-        if (h.x == NONE) continue;   // unused tail of a per-wave chunk
-        indices[offsets[h.x] + (h.y >> REC8_SHAPE_BITS)] = h.y & ((1u << REC8_SHAPE_BITS) - 1u);
-    }
+    scatter8_role(blockIdx.x, gridDim.x, pool, ctr, pool_cap, idx_cap, offsets, indices);
 }
 
 // Staged hits (WalkOut::raybuf) → CSR: one thread per ray copies the ray's first min(count, 2^shift) shapes from its own 2^shift-word
@@ -1400,25 +1452,38 @@ __global__ __launch_bounds__(256) void k_hits_scatter8(const uint2* __restrict__
 // 12-byte-record round trip (write, read, scatter) that cost configs[2] 0.42 ms for 58.8 M hits.  (Fusing this copy into
 // k_scan_final — the thread that computes a ray's offset copies its shapes — was measured and dropped: four rays per thread
 // break the contiguity of the writes, 0.31 ms against 0.13 + 0.03.)
+#ifndef GATHER_RAYS
+#define GATHER_RAYS 1
+#endif
 template <int SHIFT>
 __global__ __launch_bounds__(256) void k_hits_gather_staged(const uint32_t* __restrict__ raybuf, const uint32_t* __restrict__ offsets, uint32_t n_rays,
                                                             const unsigned long long* __restrict__ ctr, unsigned long long idx_cap,
                                                             uint32_t* __restrict__ indices) {
-    constexpr uint32_t CAP = 1u << SHIFT;
+    constexpr uint32_t CAP = 1u << SHIFT, R = GATHER_RAYS;   // R rays per thread, their loads issued together (the copy is latency-bound: 0.49 of the HBM rate)
     if (ctr[3] > idx_cap) return;   // more hits than indices[] holds: the host grows it and replays
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rays) return;
-    const uint32_t o0 = offsets[r], cnt = offsets[r + 1] - o0;
-    if (!cnt) return;
-    const uint4* src = reinterpret_cast<const uint4*>(raybuf + ((size_t)r << SHIFT));
-    uint32_t v[CAP];
+    uint32_t o0[R], cnt[R];
 #pragma unroll
-    for (uint32_t q = 0; q < CAP / 4; q++) {
-        if (4u * q < cnt) { const uint4 x = src[q]; v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w; }
+    for (uint32_t u = 0; u < R; u++) {
+        const uint32_t r = (blockIdx.x * R + u) * blockDim.x + threadIdx.x;
+        o0[u] = 0u; cnt[u] = 0u;
+        if (r < n_rays) { o0[u] = offsets[r]; cnt[u] = offsets[r + 1] - o0[u]; }
+    }
+    uint32_t v[R][CAP];
+#pragma unroll
+    for (uint32_t u = 0; u < R; u++) {
+        const uint32_t r = (blockIdx.x * R + u) * blockDim.x + threadIdx.x;
+        const uint4* src = reinterpret_cast<const uint4*>(raybuf + ((size_t)r << SHIFT));
+#pragma unroll
+        for (uint32_t q = 0; q < CAP / 4; q++) {
+            if (4u * q < cnt[u]) { const uint4 x = src[q]; v[u][4 * q] = x.x; v[u][4 * q + 1] = x.y; v[u][4 * q + 2] = x.z; v[u][4 * q + 3] = x.w; }
+        }
     }
 #pragma unroll
-    for (uint32_t k = 0; k < CAP; k++)
-        if (k < cnt) indices[o0 + k] = v[k];
+    for (uint32_t u = 0; u < R; u++) {
+#pragma unroll
+        for (uint32_t k = 0; k < CAP; k++)
+            if (k < cnt[u]) indices[o0[u] + k] = v[u][k];
+    }
 }
 
 // The 8 walk / scan counters go to the context's pinned host page and are zeroed for the next call: one 64-thread
@@ -1767,7 +1832,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     T* vals = mode == MODE_T_SLICE ? h->tslice.as<T>() : h->isect.as<T>();
     uint32_t* indices = h->indices.as<uint32_t>();
     if (staged) {   // the rays' first 2^shift shapes, straight from their slots; the pool records (later hits) follow below
-        const unsigned ggrid = (unsigned)((n_rays + 255) / 256);
+        const unsigned ggrid = (unsigned)((n_rays + 256 * GATHER_RAYS - 1) / (256 * GATHER_RAYS));
         const unsigned long long icap = h->idx_cap;
         switch (stage_shift) {
             case 2: hipLaunchKernelGGL(k_hits_gather_staged<2>, dim3(ggrid), dim3(256), 0, st, w.raybuf, offs, nr, ctr, icap, indices); break;
@@ -1879,6 +1944,10 @@ void traverse_batch(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, siz
 void debug_wide_prof(unsigned long long* out, size_t n) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_prof), sizeof(unsigned long long) * n);
+}
+void debug_wide_util(unsigned long long* out, size_t n) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_util), sizeof(unsigned long long) * n);
 }
 #endif
 

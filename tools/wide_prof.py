@@ -41,6 +41,15 @@ print(f"wave start      : mean {start.mean():7.2f}  max {start.max():7.2f} us")
 print(f"prologue end    : mean {pro.mean():7.2f}  max {pro.max():7.2f} us   (duration mean {(pro - start).mean():6.2f})")
 print(f"wave end        : mean {end.mean():7.2f}  p50 {np.percentile(end, 50):7.2f}  p90 {np.percentile(end, 90):7.2f}  max {end.max():7.2f} us")
 print(f"walk steps/wave : mean {steps.mean():6.1f}  max {steps.max():6.0f};  walk time per step (mean over waves) {((end - pro) / np.maximum(steps, 1)).mean():6.3f} us")
+util = (C.c_ulonglong * (16 * n_waves))()
+lib.bvhgpu_debug_wide_util(util, 16 * n_waves)
+u = np.array(util[:], dtype=np.float64).reshape(-1, 16)
+u = u[u[:, 0] > 0].sum(axis=0)
+ws = u[0]
+print(f"lane utilisation over {ws:.0f} wave-steps (last launch): lanes on an inner node {u[1] / ws:5.1f} of 64, lanes holding an item {u[8] / ws:5.1f}; "
+      f"steps with a resident fetch {u[2] / ws:.2f}, with a non-resident fetch {u[3] / ws:.2f}, with a slow push {u[4] / ws:.2f} ({u[5] / ws:.1f} lanes), "
+      f"with a leaf report {u[7] / ws:.2f} ({u[6] / ws:.2f} lanes), with a pop from the HBM stack part {u[11] / ws:.3f}; "
+      f"rounds on the exact path {u[10] / max(u[9], 1):.3f}; boxes hit per tested node {u[12] / max(u[1], 1):.2f}, nodes with no hit {u[13] / max(u[1], 1):.2f}")
 wg_end = end.reshape(-1, 16).max(axis=1) if len(end) % 16 == 0 else end
 wg_pro = pro.reshape(-1, 16).max(axis=1) if len(pro) % 16 == 0 else pro
 print(f"per subtree (wg % 16) end: " + " ".join(f"{wg_end[j::16].mean():.0f}" for j in range(16)))
