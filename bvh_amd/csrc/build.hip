@@ -1261,14 +1261,14 @@ template <typename T, int N> __device__ __forceinline__ void join12(T (&a)[N], c
 template <typename T, int D, int N> __device__ __forceinline__ void seg_prefix_step(T (&P)[N], int lane, int lo) {
     T u[N];
 #pragma unroll
-    for (int k = 0; k < N; k++) u[k] = dpp_fetch<0x110 + D>(P[k]);
-    if (lane - D >= lo) join12<T, N>(P, u);
+    for (int k = 0; k < N; k++) u[k] = dpp_fetch_raw<0x110 + D>(P[k]);
+    if (lane - D >= lo && (lane & 15) >= D) join12<T, N>(P, u);   // (source inside the run and inside the row)
 }
 template <typename T, int D, int N> __device__ __forceinline__ void seg_suffix_step(T (&S)[N], int lane, int hi) {
     T u[N];
 #pragma unroll
-    for (int k = 0; k < N; k++) u[k] = dpp_fetch<0x100 + D>(S[k]);
-    if (lane + D < hi) join12<T, N>(S, u);
+    for (int k = 0; k < N; k++) u[k] = dpp_fetch_raw<0x100 + D>(S[k]);
+    if (lane + D < hi && (lane & 15) + D < 16) join12<T, N>(S, u);
 }
 template <typename T, int N> __device__ __forceinline__ void seg_prefix_scan(T (&P)[N], int lane, int lo, int span) {
     if (span > 1) seg_prefix_step<T, 1, N>(P, lane, lo);
@@ -1279,10 +1279,10 @@ template <typename T, int N> __device__ __forceinline__ void seg_prefix_scan(T (
     if (__any(lo < row0)) {        // a run that began in an earlier row takes the finished prefix of the row below
         T u[N];
 #pragma unroll
-        for (int k = 0; k < N; k++) u[k] = dpp_fetch<0x142, 0xA>(P[k]);   // rows 1 and 3 from lanes 15 / 47
+        for (int k = 0; k < N; k++) u[k] = dpp_fetch_raw<0x142, 0xA>(P[k]);   // rows 1 and 3 from lanes 15 / 47
         if ((lane & 16) && lo < row0) join12<T, N>(P, u);
 #pragma unroll
-        for (int k = 0; k < N; k++) u[k] = dpp_fetch<0x143, 0xC>(P[k]);   // rows 2 and 3 from lane 31 (complete by now)
+        for (int k = 0; k < N; k++) u[k] = dpp_fetch_raw<0x143, 0xC>(P[k]);   // rows 2 and 3 from lane 31 (complete by now)
         if (lane >= 32 && lo < 32) join12<T, N>(P, u);
     }
 }

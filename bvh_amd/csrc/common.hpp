@@ -333,6 +333,17 @@ template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ double dpp_fe
     const int h2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
     return __longlong_as_double(((long long)h2 << 32) | (unsigned int)l2);
 }
+// the same without a defined value for lanes whose source lies outside the row (or whose row the mask leaves out): the caller masks those lanes itself (no copy of v
+// into the destination first — the segmented scans of the builder's wave tier are bound by issue slots)
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ float dpp_fetch_raw(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF> __device__ __forceinline__ double dpp_fetch_raw(double v) {
+    const long long b = __double_as_longlong(v);
+    const int l2 = __builtin_amdgcn_mov_dpp((int)(b & 0xFFFFFFFFll), CTRL, ROW_MASK, 0xF, false);
+    const int h2 = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, ROW_MASK, 0xF, false);
+    return __longlong_as_double(((long long)h2 << 32) | (unsigned int)l2);
+}
 // value of one (compile-time) lane in every lane, through an SGPR
 template <int LANE> __device__ __forceinline__ float lane_bcast(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), LANE)); }
 template <int LANE> __device__ __forceinline__ double lane_bcast(double v) {
