@@ -1844,8 +1844,10 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
 #pragma unroll
         for (int s2 = 0; s2 < NUM_BUCKETS - 1; s2++) {   // the 10 fetches first, the costs afterwards
             const int q2 = lo + cumv[s2];
-            salv[s2] = lane_fetch(saP, min(max(q2 - 1, 0), 63) << 2);
-            sarv[s2] = lane_fetch(saS, min(max(q2, 0), 63) << 2);
+            // (no clamps: ds_bpermute takes the lane modulo 64, and a position outside the segment — q2 - 1 < lo or q2 >= hi — only
+            //  arises for a side without shapes, which the non-degenerate selection cannot produce: bucket 0 and bucket 5 are never empty)
+            salv[s2] = lane_fetch(saP, (q2 - 1) << 2);
+            sarv[s2] = lane_fetch(saS, q2 << 2);
         }
         int nl = cnt[0];
         bool taken = false;  // no winner (NaN/inf costs) → min_bucket 0 with EMPTY child bounds (:225-230)
@@ -1860,7 +1862,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
             if (take) { min_cost = cost; nl = cumv[s2]; taken = true; }
         }
         const int q = lo + nl;
-        const int ql4 = min(max(q - 1, 0), 63) << 2, qr4 = min(max(q, 0), 63) << 2;
+        const int ql4 = (q - 1) << 2, qr4 = q << 2;   // (an empty side only without a winner: its bounds are replaced below)
         T AL[6], AR[6], Cn[6];
         const bool left = lane < q;
         {
@@ -1874,7 +1876,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
 #pragma unroll
             for (int k = 0; k < 3; k++) { Cq[k] = c[k]; Cq[3 + k] = c[k]; }
             seg_prefix_scan<T, 6>(Cq, lane, nlo, span);
-            const int last4 = min(max(nhi - 1, 0), 63) << 2;
+            const int last4 = (nhi - 1) << 2;
 #pragma unroll
             for (int k = 0; k < 6; k++) Cn[k] = lane_fetch(Cq[k], last4);
         }

@@ -1000,6 +1000,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     uint4* nodes = wsmem + 5;
     uint32_t* s_stack = reinterpret_cast<uint32_t*>(nodes + (size_t)CH * K);
     const uint32_t bd = blockDim.x, tid = threadIdx.x;
+    constexpr uint32_t SB = MAX_THREADS;   // stride of the LDS stack's entry planes: a constant, so that the three stores of a push share one address register
     const size_t G = (size_t)gridDim.x * bd, gid = (size_t)blockIdx.x * bd + tid;
     const int lane = lane_id();
     const unsigned long long lt = lanemask_lt();
@@ -1072,7 +1073,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     bool ovf = false, rec8_big = false;
     PoolCursor pc;
     auto push_slow = [&](uint32_t v) {
-        if (sp < stack_lds) s_stack[__umul24(sp, bd) + tid] = v;
+        if (sp < stack_lds) s_stack[sp * SB + tid] = v;
         else if (sp - stack_lds < gstack_cap) gstack[(size_t)(sp - stack_lds) * G + gid] = v;
         else ovf = true;
         sp++;
@@ -1080,7 +1081,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     auto pop_or_none = [&]() -> uint32_t {
         if (sp == 0) return CUR_NONE;
         sp--;
-        if (sp < stack_lds) return s_stack[__umul24(sp, bd) + tid];
+        if (sp < stack_lds) return s_stack[sp * SB + tid];
         return sp - stack_lds < gstack_cap ? gstack[(size_t)(sp - stack_lds) * G + gid] : CUR_NONE;
     };
     while (true) {
@@ -1174,8 +1175,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                 const uint32_t s0 = (rest & 8u) ? nd.ref[3] : ((rest & 4u) ? nd.ref[2] : nd.ref[1]);
                 const uint32_t s1 = ((rest & 12u) == 12u) ? nd.ref[2] : nd.ref[1];
                 if (sp + 3u <= stack_lds) {   // room for three: store them all, count what is real
-                    uint32_t* at = s_stack + __umul24(sp, bd) + tid;
-                    at[0] = s0; at[bd] = s1; at[2 * bd] = nd.ref[1];
+                    uint32_t* at = s_stack + sp * SB + tid;
+                    at[0] = s0; at[SB] = s1; at[2 * SB] = nd.ref[1];
                     sp += (uint32_t)__popc(rest);
                 } else {
                     if (rest & 8u) push_slow(nd.ref[3]);
@@ -1553,12 +1554,13 @@ template <typename T> struct WideGeom {
         stack_lds = (uint32_t)std::max(0, std::min(ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] >= 0 ? ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] : 6, 32));   // 4 / 6 / 8 / 10 / 12 measured: 6
         // static LDS of the kernel: item table (448 / 832 bytes) + block sums (512 bytes)
         const size_t budget = (size_t)(160 * 1024) / wg_per_cu - (f64 ? 1536 : 1024);
-        const size_t fixed = 80 + (size_t)stack_lds * threads * 4;
+        const size_t stack_stride = f64 ? 512 : 1024;   // (the kernel's MAX_THREADS: its stack planes have a fixed stride)
+        const size_t fixed = 80 + (size_t)stack_lds * stack_stride * 4;
         const size_t per_slot = (size_t)WideIo<T>::CHUNKS * 16;
         size_t k = budget > fixed + per_slot ? (budget - fixed) / per_slot : 1;
         if (ctx->tune[BVHGPU_TUNE_WIDE_SLOTS] > 0) k = std::min<size_t>(k, (size_t)ctx->tune[BVHGPU_TUNE_WIDE_SLOTS]);
         K = (uint32_t)std::max<size_t>(1, std::min<size_t>(k, WIDE_SLOTS));
-        lds_bytes = 80 + (size_t)K * per_slot + (size_t)stack_lds * threads * 4;
+        lds_bytes = 80 + (size_t)K * per_slot + (size_t)stack_lds * stack_stride * 4;
     }
 };
 constexpr uint32_t WIDE_GSTACK = 24;   // stack entries per lane beyond the LDS part, in HBM (a walk pushes at most 3 per wide level)
