@@ -1606,6 +1606,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
                 sah_select_wave<T>(s_keys + sn * NUM_BUCKETS * STAT_KEYS, s_cin[sn], A, m->degen != 0, &s_sel[sn], s_sahscr[wv], lane);
             }
             __syncthreads();
+            MID_T(6);
             // ---- phase 4b: nodes and children (wave 0; lane s owns sub-node s)
             if (wv == 0) {
                 const bool has = (uint32_t)lane < nsub;
@@ -1644,10 +1645,17 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
                 const uint32_t nsmall = (uint32_t)(__popcll(qL) + __popcll(qR));
                 const uint32_t nmid2 = (uint32_t)(__popcll(wL) + __popcll(wR));
                 uint32_t sbase = 0, wbase = 0;
+#ifdef BVH_PROFILE_MID
+                const long long _ta = clock64();
+#endif
                 if (lane == 0 && nsmall) sbase = atomicAdd(&a.ctr[CTR_SMALL], nsmall);
                 if (lane == 0 && nmid2) wbase = atomicAdd(&a.ctr[CTR_MID2], nmid2);
                 sbase = __shfl(sbase, 0);
                 wbase = __shfl(wbase, 0);
+#ifdef BVH_PROFILE_MID
+                asm volatile("" ::"v"(sbase), "v"(wbase));
+                if (tid == 0 && blockIdx.x == 0) atomicAdd(&g_mid_prof[7], (unsigned long long)(clock64() - _ta));   // the queue-slot atomics' round trip
+#endif
                 const uint32_t slL = sbase + (uint32_t)(__popcll(qL & lt) + __popcll(qR & lt));
                 const uint32_t slR = slL + (smL ? 1u : 0u);
                 const uint32_t w2L = wbase + (uint32_t)(__popcll(wL & lt) + __popcll(wR & lt));

@@ -725,7 +725,12 @@ constexpr uint32_t CUR_NONE = 0x7FFFFFFFu;   // neither a shape index (< 2^28) n
 #ifndef BVH_WIDE_INNER_STEPS
 #define BVH_WIDE_INNER_STEPS 4
 #endif
-constexpr int WIDE_INNER_STEPS = BVH_WIDE_INNER_STEPS;   // walk steps between two refill phases
+#ifndef BVH_WIDE_INNER_STEPS_WHOLE
+#define BVH_WIDE_INNER_STEPS_WHOLE 8
+#endif
+// walk steps between two refill phases: items of a ray cut into 16 are short (2 / 3 / 4 / 6 steps: 0.1225 / 0.1220 / 0.1219 / 0.1252 ms on
+// configs[1]), whole rays walk for hundreds of steps (4 / 6 / 8: 1.50 / 1.45 / 1.42 ms for 10 M primary rays on the stand-in scene)
+template <int ITEMS_LOG4> struct WideSteps { static constexpr int N = ITEMS_LOG4 == 0 ? BVH_WIDE_INNER_STEPS_WHOLE : BVH_WIDE_INNER_STEPS; };
 #ifndef BVH_WIDE_MIN_WAVES_F32
 #define BVH_WIDE_MIN_WAVES_F32 8   // __launch_bounds__: waves per SIMD the f32 kernel must allow (8 = two 1024-thread workgroups per CU)
 #endif
@@ -1000,6 +1005,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     uint4* nodes = wsmem + 5;
     uint32_t* s_stack = reinterpret_cast<uint32_t*>(nodes + (size_t)CH * K);
     const uint32_t bd = blockDim.x, tid = threadIdx.x;
+    constexpr int WIDE_INNER_STEPS = WideSteps<ITEMS_LOG4>::N;
     constexpr uint32_t SB = MAX_THREADS;   // stride of the LDS stack's entry planes: a constant, so that the three stores of a push share one address register
     const size_t G = (size_t)gridDim.x * bd, gid = (size_t)blockIdx.x * bd + tid;
     const int lane = lane_id();
@@ -1545,13 +1551,16 @@ static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
 template <typename T> struct WideGeom {
     uint32_t threads, wg_per_cu, stack_lds, K;
     size_t lds_bytes;
-    WideGeom(const bvhgpu_ctx* ctx) {
+    WideGeom(const bvhgpu_ctx* ctx, bool whole_rays) {
         const bool f64 = sizeof(T) == 8;
         const int want_threads = ctx->tune[BVHGPU_TUNE_WIDE_THREADS] > 0 ? ctx->tune[BVHGPU_TUNE_WIDE_THREADS] : (f64 ? 512 : 1024);
         threads = (uint32_t)std::min(f64 ? 512 : 1024, std::max(64, want_threads & ~63));
         wg_per_cu = (uint32_t)std::max(1, std::min(ctx->tune[BVHGPU_TUNE_WIDE_WG_PER_CU] > 0 ? ctx->tune[BVHGPU_TUNE_WIDE_WG_PER_CU] : 2,
                                                    (int)(2048 / threads)));
-        stack_lds = (uint32_t)std::max(0, std::min(ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] >= 0 ? ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] : 6, 32));   // 4 / 6 / 8 / 10 / 12 measured: 6
+        // 16 items per ray (short walks below tree level 4): 4 / 6 / 8 / 10 / 12 entries measured, 6; whole rays on the stand-in scene (a lane on the
+        // slow push path in 68-93 % of the steps with 6): 4 / 6 / 8 / 10 / 12 / 16 → 1.71 / 1.58 / 1.50 / 1.48 / 1.47 / 1.50 ms for 10 M primary rays,
+        // 2.79 / 2.46 / 2.28 / 2.31 / 2.39 / 2.60 ms for a 12.5 M-ray incoherent shard: 8
+        stack_lds = (uint32_t)std::max(0, std::min(ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] >= 0 ? ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] : (whole_rays ? 8 : 6), 32));
         // static LDS of the kernel: item table (448 / 832 bytes) + block sums (512 bytes)
         const size_t budget = (size_t)(160 * 1024) / wg_per_cu - (f64 ? 1536 : 1024);
         const size_t stack_stride = f64 ? 512 : 1024;   // (the kernel's MAX_THREADS: its stack planes have a fixed stride)
@@ -1570,7 +1579,7 @@ static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
                         uint32_t* ovf_flag, bool early_items) {
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
-    const WideGeom<T> g(ctx);
+    const WideGeom<T> g(ctx, ITEMS_LOG4 == 0);
     const size_t full = (n_rays + g.threads - 1) / g.threads;
     const dim3 grid((unsigned)std::min<size_t>(std::max<size_t>(full, 1), (size_t)ctx->n_cu * g.wg_per_cu));
     uint32_t* list = nullptr;
@@ -1786,7 +1795,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         counts = h->wcounts.as<uint32_t>();
         // the walk's workgroups leave the hits per 64-ray block (their own blocks: LDS sums): no reduce pass for the scan
         {
-            const WideGeom<T> g(ctx);
+            const WideGeom<T> g(ctx, items_log4 == 0);
             const size_t full = (n_rays + g.threads - 1) / g.threads;
             const size_t grid = std::min<size_t>(std::max<size_t>(full, 1), (size_t)ctx->n_cu * g.wg_per_cu);   // launch_wide: the same
             const size_t n_blocks = (n_rays + 63) / 64;

@@ -1,8 +1,8 @@
-"""developer tool: per-phase cycle counts inside k_mid (build with -DBVH_PROFILE_MID into /tmp/libbvh_prof.so)."""
+"""developer tool: per-phase cycle counts inside k_mid (python bvh_amd/build_ext.py --variant /root/repo/tools/libbvh_midprof.so BVH_PROFILE_MID=1)."""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = os.path.join(ROOT, "gpurun_out", "libbvh_prof.so") if len(sys.argv) < 2 else sys.argv[1]
+so = os.path.join(ROOT, "tools", "libbvh_midprof.so") if len(sys.argv) < 2 else sys.argv[1]
 os.environ["BVH_AMD_SO"] = so
 import numpy as np
 from bvh_amd import Bvh, testbase as tb, _lib
@@ -16,5 +16,5 @@ for _ in range(5):
 lib.bvhgpu_debug_mid_prof(out, 0)
 n = max(out[0], 1)
 print("levels(block0, 5 builds):", out[0])
-for i, name in ((1, "bucket+scan"), (2, "sort/move"), (3, "stats"), (4, "select"), (5, "reseg")):
+for i, name in ((1, "bucket+scan"), (2, "sort/move"), (3, "stats"), (6, "select (4a)"), (4, "nodes+children (4b)"), (7, "  of which queue atomics"), (5, "reseg")):
     print(f"  {name:12s} {out[i] / n:10.0f} cycles/level")

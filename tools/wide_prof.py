@@ -1,6 +1,7 @@
 """developer tool: per-wave phase times inside k_traverse_wide.  Build the instrumented library first:
    python bvh_amd/build_ext.py --variant tools/libbvh_wideprof.so BVH_WIDE_PROFILE
-   then on the GPU box: python tools/wide_prof.py [rays] [items_log4]"""
+   then on the GPU box: python tools/wide_prof.py [rays] [items_log4] [cubes | primary | incoherent]   (the last two: the stand-in scene,
+   10 M pinhole rays / a 12.5 M-ray shard of the incoherent stream — give rays = 0 for their own counts)"""
 import ctypes as C
 import os
 import sys
@@ -11,7 +12,8 @@ os.environ["BVH_AMD_SO"] = os.path.join(ROOT, "tools", "libbvh_wideprof.so")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from bvh_amd import Bvh, Context, RayBatch, _lib, testbase as tb  # noqa: E402
+from bvh_amd import Bvh, Context, RayBatch, _lib, scene, testbase as tb  # noqa: E402
+from bvh_amd.api import camera  # noqa: E402
 from bvh_amd._lib import RAY_F32, TUNE_WIDE_ITEMS_LOG4  # noqa: E402
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
@@ -20,14 +22,26 @@ lib = _lib.load()
 dev = torch.device("cuda", 0)
 ctx = Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
 ctx.set_tuning(TUNE_WIDE_ITEMS_LOG4, items)
-bounds = tb.default_bounds()
-_, aabbs = tb.create_n_cubes(10_000, bounds)
+what = sys.argv[3] if len(sys.argv) > 3 else "cubes"
+if what == "cubes":
+    bounds = tb.default_bounds()
+    _, aabbs = tb.create_n_cubes(10_000, bounds)
+else:
+    _, aabbs, bounds = scene.parse_obj(scene.make_atrium_obj(16))
 bvh = Bvh.from_aabbs(torch.from_numpy(aabbs).to(dev), ctx)
 bvh.flatten_in_place()
-buf = torch.empty(R * RAY_F32.itemsize, dtype=torch.uint8, device=dev)
-rays = RayBatch.generate(0, R, bounds, buf, np.float32, ctx)
+if what == "primary":
+    W, H = 4000, 2500
+    R = R or W * H
+    buf = torch.empty(W * H * RAY_F32.itemsize, dtype=torch.uint8, device=dev)
+    c = (bounds[:3] + bounds[3:]) * 0.5
+    rays = RayBatch.primary(camera(c, c + np.array([1.0, -0.15, 0.25]), fov_y_deg=70.0, aspect=W / H), W, H, 0, R, buf, np.float32, ctx)
+else:
+    R = R or 12_500_000
+    buf = torch.empty(R * RAY_F32.itemsize, dtype=torch.uint8, device=dev)
+    rays = RayBatch.generate(62_500_000 if what == "incoherent" else 0, R, bounds, buf, np.float32, ctx)
 for _ in range(3):
-    bvh.traverse_batch(rays, fetch=False)
+    bvh.traverse_batch(rays, fetch=False, coherent=(what == "primary"))
 n_waves = 8192
 out = (C.c_ulonglong * (4 * n_waves))()
 lib.bvhgpu_debug_wide_prof(out, 4 * n_waves)
