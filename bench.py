@@ -561,6 +561,9 @@ def main():
                     r2["note"] = ("one GPU's share of configs[3]: rays [62.5 M, 75 M) of the 100 M-ray stream (rank 5 of 8)" if scaling == "weak" else
                                   "configs[3] whole: all 100 M rays of the stream on one GPU in one batch — the N = 1 point of the strong-scaling "
                                   "curve whose N > 1 points the same entry carries when bench.py runs with --gpus N")
+                if dt == "f64":
+                    r2["note"] = ("tree, rays, builder and every test that decides a hit in f64; the walk's inner-node tests run on f32 boxes that contain "
+                                  "the f64 ones (BVHGPU_TUNE_WIDE_F64_GUIDE, DESIGN.md §4 \"f64 guide walk\"): same lists, checked against the f64 oracle below")
                 if rank == 0 and not args.no_parity:
                     from oracle import orc
                     r2["parity"] = check_parity(w2, env, orc, min(w2.R, args.parity_max_rays))

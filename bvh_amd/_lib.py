@@ -127,6 +127,7 @@ SYMBOLS = [
     ("bvhgpu_hits_fetch_triangles", _i, [_vp, _vp, _i]),
     ("bvhgpu_hits_fetch_closest", _i, [_vp, _vp, _vp, _i]),
     ("bvhgpu_hits_info", _i, [_vp, C.POINTER(_sz), C.POINTER(C.c_uint64), C.POINTER(TraverseStats)]),
+    ("bvhgpu_hits_walk_info", _i, [_vp, C.POINTER(C.c_uint)]),
     ("bvhgpu_hits_fetch", _i, [_vp, _vp, _vp, _vp, _i]),
     ("bvhgpu_hits_device", _i, [_vp, _pp, _pp, _pp]),
     ("bvhgpu_hits_destroy", None, [_vp]),
@@ -146,7 +147,9 @@ TUNE_WIDE_EARLY_ITEMS = 11       # wide walk on a tree being rebuilt, RAYS_READY
 TUNE_WIDE_STAGE_SHIFT = 12       # wide walk, whole rays, indices only: 2^v shapes per ray staged without pool records (-1 default = 3, 0 off)
 TUNE_WIDE_REC8 = 13              # wide walk, whole rays, indices only: 8-byte pool records (1, default) or the 12-byte HitRec (0)
 TUNE_BUILD_LEVEL_LAUNCHES = 10   # builder, level tier: 1 one launch per level, 2 k_bin + k_split per level, 0 (default) by scene size
-ABI_VERSION = 3
+TUNE_WIDE_F64_GUIDE = 14        # wide walk, f64 trees, indices only: walk the f32 guide boxes, test leaf candidates in f64 (1, default) or the f64 walk (0)
+WALK_WIDE, WALK_STAGED, WALK_REC8, WALK_F64_GUIDE = 1, 2, 4, 8   # bvhgpu_hits_walk_info
+ABI_VERSION = 4
 
 _lib = None
 

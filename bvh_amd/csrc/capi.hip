@@ -74,7 +74,7 @@ void free_tree_buffers(bvhgpu_tree* t) {
     t->big[0].release(); t->big[1].release(); t->mid2.release(); t->small.release();
     t->stats[0].release(); t->stats[1].release();
     t->tile_item[0].release(); t->tile_item[1].release(); t->tile_cnt.release(); t->ctr.release(); t->refit_seg.release();
-    t->wide.release(); t->wslot_node.release();
+    t->wide.release(); t->wslot_node.release(); t->wide_guide.release(); t->guide_info.release();
     t->bstat.release();
     if (t->ev_top) { (void)hipEventDestroy(t->ev_top); t->ev_top = nullptr; }
     if (t->pin) { (void)hipHostFree(t->pin); t->pin = nullptr; }
@@ -916,6 +916,14 @@ int bvhgpu_hits_info(const bvhgpu_hits* h, size_t* n_rays, uint64_t* total, bvhg
     return BVHGPU_OK;
 }
 
+int bvhgpu_hits_walk_info(const bvhgpu_hits* h, unsigned* flags) {
+    if (!h || !flags) return BVHGPU_INVALID_ARG;
+    if (h->pend_async) return fail(h->ctx, BVHGPU_INVALID_ARG, "the result object holds an asynchronous batch that has not been completed: call bvhgpu_hits_wait first");
+    *flags = (h->pend_wide ? BVHGPU_WALK_WIDE : 0u) | (h->pend_wide && h->pend_staged ? BVHGPU_WALK_STAGED : 0u) |
+             (h->pend_wide && h->pend_rec8 ? BVHGPU_WALK_REC8 : 0u) | (h->pend_wide && h->pend_guide ? BVHGPU_WALK_F64_GUIDE : 0u);
+    return BVHGPU_OK;
+}
+
 int bvhgpu_hits_fetch(bvhgpu_hits* h, uint32_t* offsets, uint32_t* indices, void* tslice, int mem) {
     if (!h || !h->ctx) return BVHGPU_INVALID_ARG;
     bvhgpu_ctx* ctx = h->ctx;
@@ -949,7 +957,7 @@ void bvhgpu_hits_destroy(bvhgpu_hits* h) {
     h->indices.release(); h->tslice.release(); h->blocksums.release(); h->scan_sums.release(); h->ctr.release();
     h->isect.release(); h->closest.release(); h->closest_prim.release();
     h->heap_dist.release(); h->heap_node.release();
-    h->wg_items.release(); h->raybuf.release();
+    h->wg_items.release(); h->raybuf.release(); h->guide_rays.release();
     if (h->ev_items) (void)hipEventDestroy(h->ev_items);
     h->wcounts.release(); h->ray_mask.release(); h->item_cnt.release(); h->wstack.release(); h->ray_items.release(); h->witems.release();
     if (h->pin) (void)hipHostFree(h->pin);
@@ -969,7 +977,8 @@ int bvhgpu_last_timings(bvhgpu_ctx* ctx, bvhgpu_timings* out) {
         if (ctx->ev_set & 1u) (void)hipEventElapsedTime(&ctx->last.build_ms, ctx->ev[0], ctx->ev[1]);
         if (ctx->ev_set & 2u) (void)hipEventElapsedTime(&ctx->last.flatten_ms, ctx->ev[2], ctx->ev[3]);
         if (ctx->ev_set & 4u) {
-            (void)hipEventElapsedTime(&ctx->last.traverse_kernel_ms, ctx->ev[4], ctx->ev[5]);
+            // (ev[7]: behind the f32 ray copy of an f64 guide walk — the copy counts towards the total, not towards the walk kernel)
+            (void)hipEventElapsedTime(&ctx->last.traverse_kernel_ms, (ctx->ev_set & 8u) ? ctx->ev[7] : ctx->ev[4], ctx->ev[5]);
             (void)hipEventElapsedTime(&ctx->last.traverse_total_ms, ctx->ev[4], ctx->ev[6]);
         }
         *out = ctx->last;

@@ -141,6 +141,24 @@ template <> struct __attribute__((aligned(256))) WideNode<double> {
 };
 static_assert(sizeof(WideNode<float>) == 128, "wide f32");
 static_assert(sizeof(WideNode<double>) == 256, "wide f64");
+// ---- guide boxes of f64 trees (engine.hpp bvhgpu_tree::wide_guide) -------------------------------------------------------------
+// A guide box is the f64 box grown by delta = GUIDE_GROW * S on every side (S = largest |coordinate| of the scene) and rounded outward
+// to f32.  For a ray with |o_k| <= GUIDE_ORIGIN_MAX * S and |inv_k| * S inside the f32 range, the f32 slab test on the guide box with
+// the round-to-nearest f32 ray passes whenever the f64 test on the f64 box does: every f32 rounding (origin, inverse direction,
+// difference, product) moves a plane's t by less than |inv_k| * 2^-21 * (S + |o_k|), the growth moves it by |inv_k| * 2^-18 * S the other way
+// (tests/test_guide_cpu.py replays the argument numerically on grazing rays).  Rays outside the range are never walked this way.
+constexpr double GUIDE_GROW = 1.0 / 262144.0;   // 2^-18
+constexpr double GUIDE_ORIGIN_MAX = 3.0;
+__host__ __device__ inline float f32_below(double x) {   // largest float <= x (NaN stays NaN)
+    float f = (float)x;
+    if ((double)f > x) {
+        uint32_t b; __builtin_memcpy(&b, &f, 4);
+        b = f > 0.0f ? b - 1u : (f < 0.0f ? b + 1u : 0x80000001u);
+        __builtin_memcpy(&f, &b, 4);
+    }
+    return f;
+}
+__host__ __device__ inline float f32_above(double x) { return -f32_below(-x); }
 constexpr uint32_t WIDE_INNER = 0x80000000u;
 constexpr uint32_t WIDE_RESIDENT = 0x40000000u;        // walk-private: WIDE_INNER | WIDE_RESIDENT | LDS slot (4-ary heap number)
 constexpr size_t WIDE_MAX_SHAPES = (size_t)1 << 28;    // node indices fit 30 bits, per-ray hit counts fit 28 bits

@@ -46,7 +46,7 @@ struct bvhgpu_ctx {
     bool own_stream = false;
     std::string err;
     int n_cu = 256;
-    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0, 0, -1, 1};  // bvhgpu_set_tuning defaults
+    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0, 0, -1, 1, 1};  // bvhgpu_set_tuning defaults
     // timing
     bool timing = false;
     hipEvent_t ev[8] = {};
@@ -104,6 +104,11 @@ struct bvhgpu_tree {
     bvhgpu::DevBuf wide;        // n_nodes * WideNode: the four grandchildren of every inner node (wide walk, traverse.hip)
     bvhgpu::DevBuf wslot_node;  // WideCfg::SLOTS * u32: tree node held in 4-ary heap slot s of the LDS-resident top (NONE = none)
     bool has_wide = false;
+    // f64 trees: the same wide nodes as f32 boxes that CONTAIN the f64 ones (rounded outward and grown by GUIDE_GROW x the scene's largest
+    // |coordinate|): index batches are walked over these with f32 rays and only leaf candidates are tested in f64 (traverse.hip "guide walk")
+    bvhgpu::DevBuf wide_guide;  // n_nodes * WideNode<float>
+    bvhgpu::DevBuf guide_info;  // float[4]: [0] = S, the largest |coordinate| of the root's child boxes
+    bool has_guide = false;
     bvhgpu::DevBuf tris;        // n * 9 T triangle vertices (optional: triangle stage)
     bool has_tris = false;
     bvhgpu::DevBuf slot_entry;  // TopCfg::SLOTS * u32: traversal entry held in LDS slot s (NONE = unused slot)
@@ -148,6 +153,8 @@ struct bvhgpu_hits {
     bvhgpu::DevBuf raybuf;   // staged output of the wide walk: 2^shift shape indices per ray (traverse.hip WalkOut::raybuf)
     bool pend_staged = false;
     bool pend_rec8 = false, no_rec8 = false;   // 8-byte pool records in the batch in flight / never again for this result object
+    bvhgpu::DevBuf guide_rays;                 // f64 batches walked over the tree's f32 guide boxes: the batch as f32 rays (traverse.hip "guide walk")
+    bool pend_guide = false, no_guide = false; // guide walk in the batch in flight / never again for this result object (a ray was out of its range)
     bool ctr_clean = false;  // the counters were zeroed behind the previous call's readback
     int ctr_set = 0;         // which of the two counter sets the next batch uses
     int bsum_set = 0;        // likewise for the wide walk's scan-block sums

@@ -33,13 +33,37 @@ template <> __device__ __forceinline__ void write_trav<double>(TravNode<double>*
     p[3] = make_double2(__longlong_as_double((long long)es), 0.0);
 }
 
+// f64 wide node → its f32 guide node (common.hpp "guide boxes"); absent slots keep their NaN boxes
+__device__ __forceinline__ WideNode<float> guide_node(const WideNode<double>& w, double delta) {
+    WideNode<float> g;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) { g.mn[k][c] = f32_below(w.mn[k][c] - delta); g.mx[k][c] = f32_above(w.mx[k][c] + delta); }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) g.ref[c] = w.ref[c];
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(g._pad) / 4); k++) g._pad[k] = 0;
+    return g;
+}
+__device__ __forceinline__ WideNode<float> guide_node(const WideNode<float>& w, double) { return w; }   // (never used: f32 trees have no guide)
+// S of a tree from the two child boxes of its root (their union is the scene)
+template <typename T> __device__ __forceinline__ double guide_scene_extent(const T* a, const T* b, const T* c, const T* d) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) s = fmax(fmax(s, fmax(fabs((double)a[k]), fabs((double)b[k]))), fmax(fabs((double)c[k]), fabs((double)d[k])));
+    return s;
+}
+
 // The wide node (common.hpp WideNode) of inner tree node i, straight from the BvhNode array: slots 0,1 = the left child's
 // children (or the left child itself when it is a leaf), slots 2,3 likewise on the right.  A child's box is its parent's
 // child_l_aabb / child_r_aabb; a leaf's is bit-identical to its shape's AABB (join(empty, aabb) == aabb).
 template <typename T>
 __device__ __forceinline__ void flatten_wide_node(const typename Traits<T>::Node* __restrict__ nodes, const typename Traits<T>::Node& nd,
                                                   uint32_t i, const uint16_t* __restrict__ node_slot, WideNode<T>* __restrict__ wide,
-                                                  uint32_t* __restrict__ wslot_node, uint32_t n_nodes, uint32_t n_shapes) {
+                                                  uint32_t* __restrict__ wslot_node, uint32_t n_nodes, uint32_t n_shapes,
+                                                  WideNode<float>* __restrict__ guide) {
     const T nan = __builtin_nan("");
     const typename Traits<T>::Node cl = nodes[nd.l], cr = nodes[nd.r];
     // references of the four grandchildren: a leaf by its shape, an inner node by its index
@@ -77,6 +101,10 @@ __device__ __forceinline__ void flatten_wide_node(const typename Traits<T>::Node
 #pragma unroll
     for (int k = 0; k < (int)(sizeof(w._pad) / 4); k++) w._pad[k] = 0;
     wide[i] = w;
+    if (sizeof(T) == 8 && guide) {
+        const typename Traits<T>::Node& r0 = nodes[0];
+        guide[i] = guide_node(w, GUIDE_GROW * guide_scene_extent<T>(r0.l_min, r0.l_max, r0.r_min, r0.r_max));
+    }
     // LDS slot table of the wide walk: tree levels 0, 2, .., 10 in 4-ary heap order (binary heap number h: root 1)
     const uint32_t h = node_slot[i];
     if (h >= 1u && h < 2048u) {
@@ -94,7 +122,8 @@ __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node*
                                                  WideNode<T>* __restrict__ wide, uint32_t* __restrict__ wslot_node,
                                                  uint32_t n_nodes, uint32_t n_shapes, uint32_t* __restrict__ pub_ctr,
                                                  uint32_t* __restrict__ pub_host, uint32_t pub_words, uint32_t* __restrict__ bstat,
-                                                 uint32_t flags_idx, uint32_t level_idx) {
+                                                 uint32_t flags_idx, uint32_t level_idx, WideNode<float>* __restrict__ guide,
+                                                 float* __restrict__ guide_info) {
     using Tr = Traits<T>;
     // build + flatten in one enqueue: this launch is the last of the chain, so its first workgroup also stores the builder's
     // counters in the tree's pinned host page and zeroes them for the next build (nothing in this kernel reads them) —
@@ -116,7 +145,8 @@ __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node*
     if (wide && nd.shape == NONE && nd.l < n_nodes && nd.r < n_nodes) {
         const uint32_t h = node_slot[i];
         const bool odd_level = h != SLOT_NONE && h >= 1u && (((31 - __clz((int)h)) & 1) != 0);
-        if (!odd_level) flatten_wide_node<T>(nodes, nd, i, node_slot, wide, wslot_node, n_nodes, n_shapes);
+        if (!odd_level) flatten_wide_node<T>(nodes, nd, i, node_slot, wide, wslot_node, n_nodes, n_shapes, guide);
+        if (guide_info && i == 0) guide_info[0] = (float)guide_scene_extent<T>(nd.l_min, nd.l_max, nd.r_min, nd.r_max);   // (read by the ray conversion of the guide walk)
     }
     if (n_nodes == 1) {
         // single-shape tree: the root is a leaf and emits one leaf entry (flat_bvh.rs:129-141); its
@@ -202,7 +232,8 @@ template <typename T> __device__ __forceinline__ void wide_slot_absent(WideSlot<
 template <typename T>
 __global__ __launch_bounds__(256) void k_wide(const TravNode<T>* __restrict__ trav, uint32_t n_nodes, uint32_t n_trav,
                                               const uint32_t* __restrict__ slot_entry, uint32_t n_bin_slots,
-                                              WideNode<T>* __restrict__ wide, uint32_t* __restrict__ wslot_node) {
+                                              WideNode<T>* __restrict__ wide, uint32_t* __restrict__ wslot_node,
+                                              WideNode<float>* __restrict__ guide, float* __restrict__ guide_info) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < WIDE_SLOTS) {   // slot table of the resident top
         int k = 0;
@@ -246,19 +277,30 @@ __global__ __launch_bounds__(256) void k_wide(const TravNode<T>* __restrict__ tr
     }
     for (int k = 0; k < (int)(sizeof(w._pad) / 4); k++) w._pad[k] = 0;
     wide[b] = w;
+    if (sizeof(T) == 8 && guide && n_trav >= 2u) {   // the root's children: entry 0 and the entry it exits to
+        const TravNode<T> c0 = trav[0];
+        const TravNode<T> c1 = trav[c0.exit < n_trav ? c0.exit : n_trav - 1u];
+        const double S = guide_scene_extent<T>(c0.mn, c0.mx, c1.mn, c1.mx);
+        guide[b] = guide_node(w, GUIDE_GROW * S);
+        if (b == 0 && guide_info) guide_info[0] = (float)S;
+    }
 }
 
 template <typename T> void wide_from_trav(bvhgpu_tree* t) {
-    t->has_wide = false;
+    t->has_wide = false; t->has_guide = false;
     if (t->n < 2 || t->n >= WIDE_MAX_SHAPES || t->unfolded || !t->slot_entry.p) return;
     const uint32_t nn = (uint32_t)(t->n_trav + 1);   // tree nodes = entries + the root
     t->wide.reserve((size_t)nn * sizeof(WideNode<T>));
     t->wslot_node.reserve(WIDE_SLOTS * 4);
+    const bool with_guide = sizeof(T) == 8;
+    if (with_guide) { t->wide_guide.reserve((size_t)nn * sizeof(WideNode<float>)); t->guide_info.reserve(16); }
     hipLaunchKernelGGL(k_wide<T>, dim3((std::max(nn, WIDE_SLOTS) + 255) / 256), dim3(256), 0, t->ctx->stream, t->trav.as<TravNode<T>>(),
                        nn, (uint32_t)t->n_trav, t->slot_entry.as<uint32_t>(), (uint32_t)TopCfg<T>::SLOTS, t->wide.as<WideNode<T>>(),
-                       t->wslot_node.as<uint32_t>());
+                       t->wslot_node.as<uint32_t>(), with_guide ? t->wide_guide.as<WideNode<float>>() : nullptr,
+                       with_guide ? t->guide_info.as<float>() : nullptr);
     BVH_HIP(hipGetLastError());
     t->has_wide = true;
+    t->has_guide = with_guide;
 }
 template void wide_from_trav<float>(bvhgpu_tree*);
 template void wide_from_trav<double>(bvhgpu_tree*);
@@ -274,14 +316,18 @@ template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr, uint3
     // the wide nodes come out of the same pass (their LDS slot table was cleared by the build's first kernel)
     const bool with_wide = t->n >= 2 && t->n < WIDE_MAX_SHAPES && t->wslot_node.p != nullptr;
     if (with_wide) t->wide.reserve((size_t)nn * sizeof(WideNode<T>));
+    const bool with_guide = with_wide && sizeof(T) == 8;
+    if (with_guide) { t->wide_guide.reserve((size_t)nn * sizeof(WideNode<float>)); t->guide_info.reserve(16); }
     hipLaunchKernelGGL(k_flatten<T>, dim3((nn + 255) / 256), dim3(256), 0, st,
                        t->nodes.as<typename Tr::Node>(), t->node_start.as<uint32_t>(), t->node_count.as<uint32_t>(),
                        t->aabbs.as<T>(), t->node_slot.as<uint16_t>(), t->slot_entry.as<uint32_t>(),
                        t->flat.as<typename Tr::Flat>(),
                        t->trav.as<TravNode<T>>(), with_wide ? t->wide.as<WideNode<T>>() : nullptr, t->wslot_node.as<uint32_t>(), nn,
-                       (uint32_t)t->n, pub_ctr, pub_host, pub_words, bstat, flags_idx, level_idx);
+                       (uint32_t)t->n, pub_ctr, pub_host, pub_words, bstat, flags_idx, level_idx,
+                       with_guide ? t->wide_guide.as<WideNode<float>>() : nullptr, with_guide ? t->guide_info.as<float>() : nullptr);
     BVH_HIP(hipGetLastError());
     t->has_wide = with_wide;
+    t->has_guide = with_guide;
     t->flattened = true;
 }
 

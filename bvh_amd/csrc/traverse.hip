@@ -975,6 +975,41 @@ __global__ __launch_bounds__(256) void k_wide_items(const typename Traits<T>::No
     if (tid == 0) { wg_items[2u * blockIdx.x] = s_nlist; wg_items[2u * blockIdx.x + 1u] = s_nback; }
 }
 
+// ---- guide walk: an f64 index batch walked over the tree's f32 guide boxes (common.hpp "guide boxes") -----------------------------------
+// The f64 wide walk costs 1.9 x the f32 one (half-rate VALU, 13 instead of 7 chunks per node).  Only leaf tests decide a ray's list
+// (monotonicity), so every inner test may be conservative: k_guide_rays writes the batch as f32 rays (round to nearest) and
+// flags rays the containment argument does not cover; the f32 wide walk then runs over `wide_guide` unchanged, except that a leaf
+// CANDIDATE is confirmed by the f64 slab test of the shape's own f64 box with the f64 ray before it is reported.  Same lists, same order.
+constexpr unsigned long long WALK_FLAG_GUIDE_RANGE = 16ull;   // ctr[7] bit: a ray was outside the guide walk's range — the host replays in f64
+struct GuideArgs { const bvhgpu_ray_f64* rays64; const double* aabbs64; };
+__global__ __launch_bounds__(256) void k_guide_rays(const bvhgpu_ray_f64* __restrict__ in, uint32_t n, const float* __restrict__ guide_info,
+                                                    bvhgpu_ray_f32* __restrict__ out, uint32_t* __restrict__ flags) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (r < n) {
+        const double S = (double)guide_info[0];
+        const bvhgpu_ray_f64 q = in[r];
+        bvhgpu_ray_f32 o;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double ao = fabs(q.o[k]), ai = fabs(q.inv[k]) * (4.0 * S);
+            // (NaN fails every comparison; S = 0 — a scene that is one point — leaves no room for the growth)
+            bad = bad || !(ao <= GUIDE_ORIGIN_MAX * S) || !(ai <= 0x1p100) || !(ai >= 0x1p-100);
+            o.o[k] = (float)q.o[k]; o.d[k] = (float)q.d[k]; o.inv[k] = (float)q.inv[k];
+        }
+        out[r] = o;
+    }
+    if (__any(bad) && (threadIdx.x & 63u) == 0u) atomicOr(flags, (uint32_t)WALK_FLAG_GUIDE_RANGE);
+}
+// the f64 test of a leaf candidate (finite ray: the NaN-free form is exact, common.hpp slab_hit_finite)
+__device__ __forceinline__ bool guide_leaf_hit(const GuideArgs& ga, uint32_t ray, uint32_t shape) {
+    const bvhgpu_ray_f64* rp = ga.rays64 + ray;
+    const double* b = ga.aabbs64 + 6 * (size_t)shape;
+    const double o[3] = {rp->o[0], rp->o[1], rp->o[2]}, inv[3] = {rp->inv[0], rp->inv[1], rp->inv[2]};
+    const double mn[3] = {b[0], b[1], b[2]}, mx[3] = {b[3], b[4], b[5]};
+    return slab_hit_finite<double>(o, inv, mn, mx);
+}
+
 #ifdef BVH_WIDE_PROFILE   // developer build: per-wave timestamps (100 MHz wall clock) of the wide walk's phases
 __device__ unsigned long long g_wide_prof[4 * 16384];
 // lane-utilisation counts per wave (16 per wave): [0] wave-steps, [1] lanes on an inner node, [2] steps with a resident fetch,
@@ -986,11 +1021,12 @@ __device__ unsigned long long g_wide_util[16 * 16384];
 // ITEMS_LOG4 = 0: one item per ray, drawn by ray number.  1 / 2: every workgroup first cuts ITS rays into live items (its
 // region of `list`, filled through an LDS counter — no global atomic: one address only takes ~88 atomics per µs on this
 // chip, which made a separate filter kernel with one atomic per wave cost more than the walk) and then walks them.
-template <typename T, int MODE, int ITEMS_LOG4, int MAX_THREADS, int MIN_WAVES>
+template <typename T, int MODE, int ITEMS_LOG4, int MAX_THREADS, int MIN_WAVES, int GUIDE = 0>
 __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     const WideNode<T>* __restrict__ wide, const uint32_t* __restrict__ wslot_node, uint32_t K, uint32_t stack_lds,
     const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_rays, uint32_t* __restrict__ list_all, const uint32_t* __restrict__ wg_items,
-    WalkOut<T> w, uint32_t* __restrict__ gstack, uint32_t gstack_cap, uint32_t* __restrict__ overflow) {
+    WalkOut<T> w, uint32_t* __restrict__ gstack, uint32_t gstack_cap, uint32_t* __restrict__ overflow, GuideArgs ga) {
+    static_assert(GUIDE == 0 || (MODE == MODE_INDICES && sizeof(T) == 4), "the guide walk is the f32 index walk");
     static_assert(ITEMS_LOG4 >= 0 && ITEMS_LOG4 <= 2, "1, 4 or 16 items per ray");
     static_assert(MODE != MODE_T_SLICE, "the t-slice output walks the binary array");
     static_assert(MODE != MODE_CLOSEST || ITEMS_LOG4 == 0, "closest hit: one lane owns the ray");
@@ -1194,6 +1230,11 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
             bool rec = cur < CUR_NONE;   // a leaf: report it, take the next pending grandchild
             const uint32_t shape = cur;
             if (rec) cur = pop_or_none();
+            if (GUIDE) {   // a leaf candidate of the guide walk: the shape's own f64 box and the f64 ray decide (wave-uniform skip: candidates are rare)
+                if (__any(rec)) {
+                    if (rec) rec = guide_leaf_hit(ga, ITEMS_LOG4 == 0 ? ray.r : (ray.r >> WIDE_ITEM_BITS), shape);
+                }
+            }
             if (MODE == MODE_INDICES && ITEMS_LOG4 == 0 && w.raybuf) {   // (wave-uniform) the ray's first hits need no record: see WalkOut::raybuf
                 if (rec && (ray.cnt >> w.stage_shift) == 0u) {
                     w.raybuf[((size_t)ray.r << w.stage_shift) | ray.cnt] = shape;
@@ -1574,9 +1615,10 @@ template <typename T> struct WideGeom {
 };
 constexpr uint32_t WIDE_GSTACK = 24;   // stack entries per lane beyond the LDS part, in HBM (a walk pushes at most 3 per wide level)
 
-template <typename T, int MODE, int ITEMS_LOG4>
+// GUIDE: T = float on an f64 tree — the nodes are the tree's guide boxes, rays_dev the batch's f32 copy, ga the f64 originals (see k_guide_rays)
+template <typename T, int MODE, int ITEMS_LOG4, int GUIDE = 0>
 static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, const WalkOut<T>& w, bvhgpu_hits* h,
-                        uint32_t* ovf_flag, bool early_items) {
+                        uint32_t* ovf_flag, bool early_items, GuideArgs ga = GuideArgs{nullptr, nullptr}) {
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
     const WideGeom<T> g(ctx, ITEMS_LOG4 == 0);
@@ -1609,15 +1651,16 @@ static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
     h->wstack.reserve(lanes * WIDE_GSTACK * 4);
     constexpr int MAXT = sizeof(T) == 8 ? 512 : 1024;
     constexpr int MINW = sizeof(T) == 8 ? BVH_WIDE_MIN_WAVES_F64 : BVH_WIDE_MIN_WAVES_F32;
-    auto kern = &k_traverse_wide<T, MODE, ITEMS_LOG4, MAXT, MINW>;
+    auto kern = &k_traverse_wide<T, MODE, ITEMS_LOG4, MAXT, MINW, GUIDE>;
     static thread_local size_t lds_attr[16] = {};   // per device: dynamic-LDS limit already set for this instantiation
     size_t& have = lds_attr[ctx->device & 15];
     if (have < g.lds_bytes) {
         BVH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds_bytes));
         have = g.lds_bytes;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(g.threads), g.lds_bytes, st, t->wide.as<WideNode<T>>(), t->wslot_node.as<uint32_t>(),
-                       g.K, g.stack_lds, rays_dev, (uint32_t)n_rays, list, wg_items, w, h->wstack.as<uint32_t>(), WIDE_GSTACK, ovf_flag);
+    hipLaunchKernelGGL(kern, grid, dim3(g.threads), g.lds_bytes, st, GUIDE ? t->wide_guide.as<WideNode<T>>() : t->wide.as<WideNode<T>>(),
+                       t->wslot_node.as<uint32_t>(), g.K, g.stack_lds, rays_dev, (uint32_t)n_rays, list, wg_items, w, h->wstack.as<uint32_t>(),
+                       WIDE_GSTACK, ovf_flag, ga);
 }
 
 // ---- one batch = enqueue (no host round trip) + check (after the stream has been synchronised) --------------------
@@ -1657,6 +1700,11 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     // the pass that splits level 3, and the caller says that the rays do not depend on anything enqueued since
     const bool early_items = use_wide && items_log4 == 2 && (flags & BVHGPU_TRAVERSE_RAYS_READY) != 0 && t->pending_build && t->ev_top != nullptr &&
                              t->ev_top_gen == t->gen && ctx->tune[BVHGPU_TUNE_WIDE_EARLY_ITEMS] != 0;
+    // f64 index batches: the f32 walk over the tree's guide boxes, leaf candidates confirmed in f64 (k_guide_rays; a result object that met
+    // a ray outside the guide walk's range stays with the f64 walk)
+    const bool use_guide = sizeof(T) == 8 && use_wide && mode == MODE_INDICES && t->has_guide && !h->no_guide && !early_items &&
+                           ctx->tune[BVHGPU_TUNE_WIDE_F64_GUIDE] != 0;
+    h->pend_guide = use_guide;
     const size_t n_items = split_at ? 2 * n_rays : n_rays;
     h->ctx = ctx; h->dtype = Traits<T>::dtype; h->n_rays = n_rays; h->flags = flags; h->total = 0;
     h->stats = bvhgpu_traverse_stats{0, 0, 0, 0, 0};
@@ -1699,6 +1747,24 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     };
     auto dispatch_wide = [&](auto mode_tag) {
         constexpr int M = decltype(mode_tag)::value;
+        if constexpr (sizeof(T) == 8 && M == MODE_INDICES) {
+            if (use_guide) {
+                h->guide_rays.reserve(std::max<size_t>(n_rays, 1) * sizeof(bvhgpu_ray_f32));
+                bvhgpu_ray_f32* r32 = h->guide_rays.as<bvhgpu_ray_f32>();
+                hipLaunchKernelGGL(k_guide_rays, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const bvhgpu_ray_f64*>(rays_dev),
+                                   (uint32_t)n_rays, t->guide_info.as<float>(), r32, ovf_flag);
+                if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[7], st)); ctx->ev_set |= 8u; }   // traverse_kernel_ms = the walk kernel alone
+                WalkOut<float> wg;   // the same outputs: an index batch touches none of the T-typed ones
+                wg.counts = w.counts; wg.pool = w.pool; wg.pool_v = nullptr; wg.pool_cap = w.pool_cap; wg.ctr = w.ctr; wg.tris = nullptr;
+                wg.closest = nullptr; wg.closest_prim = nullptr; wg.item_cnt = w.item_cnt; wg.ray_items = w.ray_items; wg.scan_sums = w.scan_sums;
+                wg.pool8 = w.pool8; wg.raybuf = w.raybuf; wg.stage_shift = w.stage_shift;
+                const GuideArgs ga{reinterpret_cast<const bvhgpu_ray_f64*>(rays_dev), t->aabbs.as<double>()};
+                if (items_log4 == 2) launch_wide<float, MODE_INDICES, 2, 1>(t, r32, n_rays, wg, h, ovf_flag, false, ga);
+                else if (items_log4 == 1) launch_wide<float, MODE_INDICES, 1, 1>(t, r32, n_rays, wg, h, ovf_flag, false, ga);
+                else launch_wide<float, MODE_INDICES, 0, 1>(t, r32, n_rays, wg, h, ovf_flag, false, ga);
+                return;
+            }
+        }
         if (M != MODE_CLOSEST && items_log4 == 2) launch_wide<T, M, (M == MODE_CLOSEST ? 0 : 2)>(t, rays_dev, n_rays, w, h, ovf_flag, early_items);
         else if (M != MODE_CLOSEST && items_log4 == 1) launch_wide<T, M, (M == MODE_CLOSEST ? 0 : 1)>(t, rays_dev, n_rays, w, h, ovf_flag, false);
         else launch_wide<T, M, 0>(t, rays_dev, n_rays, w, h, ovf_flag, false);
@@ -1740,7 +1806,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         h->closest_prim.reserve(std::max<size_t>(n_rays, 1) * 4);
         if (n_rays == 0) { h->pend_tree = nullptr; return; }
         w.closest = h->closest.as<T>(); w.closest_prim = h->closest_prim.as<uint32_t>();
-        if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
+        if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); ctx->ev_set &= ~8u; }
         DISPATCH_WALK();
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
         hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);   // readback + reset for the next call
@@ -1795,9 +1861,11 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         counts = h->wcounts.as<uint32_t>();
         // the walk's workgroups leave the hits per 64-ray block (their own blocks: LDS sums): no reduce pass for the scan
         {
-            const WideGeom<T> g(ctx, items_log4 == 0);
-            const size_t full = (n_rays + g.threads - 1) / g.threads;
-            const size_t grid = std::min<size_t>(std::max<size_t>(full, 1), (size_t)ctx->n_cu * g.wg_per_cu);   // launch_wide: the same
+            const WideGeom<T> gt(ctx, items_log4 == 0);
+            const WideGeom<float> gf(ctx, items_log4 == 0);   // (the guide walk of an f64 batch launches the f32 geometry)
+            const uint32_t g_threads = use_guide ? gf.threads : gt.threads, g_wg_per_cu = use_guide ? gf.wg_per_cu : gt.wg_per_cu;
+            const size_t full = (n_rays + g_threads - 1) / g_threads;
+            const size_t grid = std::min<size_t>(std::max<size_t>(full, 1), (size_t)ctx->n_cu * g_wg_per_cu);   // launch_wide: the same
             const size_t n_blocks = (n_rays + 63) / 64;
             if (nb <= SCAN_FUSED_MAX_BLOCKS && (n_blocks + grid - 1) / grid <= WIDE_BSUM_MAX) {
                 // two sets of SCAN_FUSED_MAX_BLOCKS sums, used alternately like the counter sets (k_scan_final zeroes the other one)
@@ -1813,7 +1881,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     }
     w.counts = counts; w.pool = h->pool.as<HitRec>(); w.pool_v = h->pool_t.as<T>(); w.pool_cap = cap;
     w.pool8 = rec8 ? h->pool.as<uint2>() : nullptr;
-    if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
+    if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); ctx->ev_set &= ~8u; }
     DISPATCH_WALK();
     if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); }
     unsigned long long* bs = h->blocksums.as<unsigned long long>();
@@ -1893,6 +1961,9 @@ bool traverse_check(bvhgpu_hits* h) {
         h->heap_cap *= 2; return false;
     }
     if (ordered && (pin[7] & 1ull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
+    if (h->pend_guide && (pin[7] & WALK_FLAG_GUIDE_RANGE)) {   // a ray outside the guide walk's range: this result object goes back to the f64 walk
+        h->no_guide = true; h->wcounts_clean = false; return false;
+    }
     if (h->pend_rec8 && (pin[7] & 8ull)) {   // a ray with 128+ hits (or a shape index beyond 2^25): this result object goes back to 12-byte records
         h->no_rec8 = true; h->wcounts_clean = false; return false;
     }

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BVHGPU_ABI_VERSION 3 /* 3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 14 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT, 13 = WIDE_REC8), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
+#define BVHGPU_ABI_VERSION 4 /* 4: BVHGPU_TUNE_COUNT 15 (slot 14 = WIDE_F64_GUIDE), bvhgpu_hits_walk_info.  3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 14 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT, 13 = WIDE_REC8), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
 #define BVHGPU_NONE 0xFFFFFFFFu /* u32::MAX marker (flat_bvh.rs:51-53, :124, :137) */
 
 typedef enum {
@@ -303,6 +303,12 @@ int bvhgpu_hits_wait(bvhgpu_hits *hits);
 int bvhgpu_tree_set_triangles_f32(bvhgpu_tree *tree, const float *verts, size_t n, int mem);
 int bvhgpu_tree_set_triangles_f64(bvhgpu_tree *tree, const double *verts, size_t n, int mem);
 int bvhgpu_hits_info(const bvhgpu_hits *hits, size_t *n_rays, uint64_t *total, bvhgpu_traverse_stats *stats);
+/* Which form of the walk produced the batch the result object holds (diagnostic; the lists never depend on it): */
+#define BVHGPU_WALK_WIDE 1u       /* the 4-wide walk (batches of BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS rays and more) */
+#define BVHGPU_WALK_STAGED 2u     /* ... with a ray's first hits handed over through its own slot (BVHGPU_TUNE_WIDE_STAGE_SHIFT) */
+#define BVHGPU_WALK_REC8 4u       /* ... with 8-byte pool records (BVHGPU_TUNE_WIDE_REC8) */
+#define BVHGPU_WALK_F64_GUIDE 8u  /* ... over the f32 guide boxes of an f64 tree, leaf candidates confirmed in f64 (BVHGPU_TUNE_WIDE_F64_GUIDE) */
+int bvhgpu_hits_walk_info(const bvhgpu_hits *hits, unsigned *flags);
 /* copy out; indices / tslice may be NULL.  tslice: 2 scalars of the tree's dtype per hit (flag T_SLICE). */
 int bvhgpu_hits_fetch(bvhgpu_hits *hits, uint32_t *offsets, uint32_t *indices, void *tslice, int mem);
 /* TRIANGLES: 3 scalars {distance,u,v} per hit, CSR order (distance = +inf: no intersection, ray_impl.rs:150-151). */
@@ -357,7 +363,12 @@ typedef enum {
                                               through the pool); 2 .. 5 = on for every such batch */
     BVHGPU_TUNE_WIDE_REC8 = 13,            /* variant 3, whole rays, indices only: pool records of 8 bytes {ray, k << 25 | shape} instead of 12 (a ray with 128+
                                               hits or a scene beyond 2^25 shapes falls back by itself); 1 (default) on, 0 off */
-    BVHGPU_TUNE_COUNT = 14
+    BVHGPU_TUNE_WIDE_F64_GUIDE = 14,       /* variant 3, f64 trees, indices only: 1 (default) = walk the tree's f32 guide boxes (the f64 boxes grown by 2^-18 of the
+                                              scene's largest |coordinate| and rounded outward) with f32 copies of the rays and test only the leaf
+                                              candidates in f64 — the hit lists are the same, the walk runs at the f32 rate; a batch with a ray outside
+                                              the range the argument covers (|origin| > 3 x scene, |1/d| x scene outside 2^+-100, non-finite) is replayed
+                                              with the f64 walk and the result object stays with it; 0 = always the f64 walk */
+    BVHGPU_TUNE_COUNT = 15
 } bvhgpu_tune;
 int bvhgpu_set_tuning(bvhgpu_ctx *ctx, int knob, int value);
 int bvhgpu_get_tuning(const bvhgpu_ctx *ctx, int knob, int *value);

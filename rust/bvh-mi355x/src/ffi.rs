@@ -3,7 +3,7 @@
 #![allow(non_camel_case_types, dead_code)]
 use core::ffi::{c_char, c_int, c_uint, c_void};
 
-pub const BVHGPU_ABI_VERSION: c_int = 3;
+pub const BVHGPU_ABI_VERSION: c_int = 4;
 pub const BVHGPU_NONE: u32 = u32::MAX; // flat_bvh.rs:51-53
 
 // bvhgpu_status
@@ -142,6 +142,7 @@ extern "C" {
     pub fn bvhgpu_tree_set_triangles_f32(t: *mut bvhgpu_tree, verts: *const f32, n: usize, mem: c_int) -> c_int;
     pub fn bvhgpu_tree_set_triangles_f64(t: *mut bvhgpu_tree, verts: *const f64, n: usize, mem: c_int) -> c_int;
     pub fn bvhgpu_hits_info(h: *const bvhgpu_hits, n_rays: *mut usize, total: *mut u64, stats: *mut bvhgpu_traverse_stats) -> c_int;
+    pub fn bvhgpu_hits_walk_info(h: *const bvhgpu_hits, flags: *mut c_uint) -> c_int;
     pub fn bvhgpu_hits_fetch(h: *mut bvhgpu_hits, offsets: *mut u32, indices: *mut u32, tslice: *mut c_void, mem: c_int) -> c_int;
     pub fn bvhgpu_hits_fetch_triangles(h: *mut bvhgpu_hits, isect: *mut c_void, mem: c_int) -> c_int;
     pub fn bvhgpu_hits_fetch_closest(h: *mut bvhgpu_hits, isect: *mut c_void, shape: *mut u32, mem: c_int) -> c_int;

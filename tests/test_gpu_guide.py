@@ -1,0 +1,142 @@
+"""f64 index batches walked over the tree's f32 guide boxes (traverse.hip "guide walk", BVHGPU_TUNE_WIDE_F64_GUIDE): the lists are the
+oracle's — on random rays, on rays that graze faces / edges / corners of the shapes' boxes (where a conservative inner test and the
+f64 leaf test must agree exactly), with whole rays and with rays cut into items, after a refit, on an imported scene — and a batch with
+a ray outside the guide walk's range is replayed with the f64 walk without the caller noticing."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import bvh_amd
+    if bvh_amd.device_count() <= 0:
+        pytest.fail("GPU test selected but no HIP device is visible (no CPU fallback exists)")
+    return bvh_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import orc as o
+    return o
+
+
+def _csr(eng, flat, rays, **kw):
+    off, idx, _, st = flat.traverse_batch(eng.RayBatch(len(rays), np.float64, host=np.ascontiguousarray(rays)), **kw)
+    return off, idx, st
+
+
+def _oracle(orc, aabbs, rays):
+    oflat = orc.flatten(orc.build(aabbs).nodes)
+    ooff, oidx, _, _ = orc.traverse_flat(oflat, aabbs, rays, threads=orc.max_threads())
+    return ooff, oidx
+
+
+def _cubes64(n):
+    from bvh_amd import testbase as tb
+    _, aabbs = tb.create_n_cubes(n)
+    return aabbs.astype(np.float64)
+
+
+def _grazing_rays(orc, aabbs, n, seed):
+    """rays from inside the scene's bounds aimed at points ON the surface of random shapes' boxes (corners, edges, faces)"""
+    rng = np.random.default_rng(seed)
+    lo, hi = aabbs[:, :3].min(axis=0), aabbs[:, 3:].max(axis=0)
+    b = aabbs[rng.integers(0, len(aabbs), n)]
+    pick = rng.integers(0, 3, (n, 3))                                   # per axis: min plane, max plane, somewhere between
+    u = rng.uniform(0, 1, (n, 3))
+    tgt = np.where(pick == 0, b[:, :3], np.where(pick == 1, b[:, 3:], b[:, :3] + u * (b[:, 3:] - b[:, :3])))
+    o = rng.uniform(lo, hi, (n, 3))
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return orc.make_rays(o, d, np.float64)
+
+
+@pytest.mark.parametrize("items", [-1, 0, 2])
+def test_guide_walk_lists_are_the_oracles(eng, orc, items):
+    from bvh_amd._lib import TUNE_WIDE_F64_GUIDE, TUNE_WIDE_ITEMS_LOG4, WALK_F64_GUIDE, WALK_WIDE
+    aabbs = _cubes64(3000)
+    ctx = eng.Context(0)
+    ctx.set_tuning(TUNE_WIDE_ITEMS_LOG4, items)
+    flat = eng.Bvh.from_aabbs(aabbs, ctx).flatten()
+    rays = np.concatenate([orc.create_rays(0, 60_000, dtype=np.float64), _grazing_rays(orc, aabbs, 60_000, 3)])
+    ooff, oidx = _oracle(orc, aabbs, rays)
+    off, idx, st = _csr(eng, flat, rays)
+    assert st["walk"] & WALK_WIDE and st["walk"] & WALK_F64_GUIDE          # the guide walk ran (no ray was out of range)
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+    ctx.set_tuning(TUNE_WIDE_F64_GUIDE, 0)
+    off2, idx2, st2 = _csr(eng, flat, rays)
+    assert st2["walk"] & WALK_WIDE and not st2["walk"] & WALK_F64_GUIDE    # the f64 walk
+    assert np.array_equal(off2, ooff) and np.array_equal(idx2, oidx)
+
+
+def test_guide_walk_hit_heavy_scene_whole_rays_and_staged(eng, orc):
+    from bvh_amd import scene
+    from bvh_amd._lib import WALK_F64_GUIDE
+    _, a32, bounds = scene.parse_obj(scene.make_atrium_obj(4))
+    aabbs = a32.astype(np.float64)
+    flat = eng.Bvh.from_aabbs(aabbs).flatten()
+    r32 = orc.create_rays(5_000_000, 120_000, bounds=bounds)
+    rays = np.concatenate([orc.make_rays(r32["o"].astype(np.float64), r32["d"].astype(np.float64), np.float64), _grazing_rays(orc, aabbs, 40_000, 9)])
+    ooff, oidx = _oracle(orc, aabbs, rays)
+    assert len(oidx) > 4 * len(rays)                                        # hit-heavy: most steps report a leaf candidate
+    for coherent in (False, True):
+        off, idx, st = _csr(eng, flat, rays, coherent=coherent)
+        assert st["walk"] & WALK_F64_GUIDE
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+
+
+def test_ray_outside_the_guide_range_replays_in_f64(eng, orc):
+    from bvh_amd._lib import WALK_F64_GUIDE, WALK_WIDE
+    aabbs = _cubes64(2000)
+    flat = eng.Bvh.from_aabbs(aabbs).flatten()
+    good = orc.create_rays(77, 40_000, dtype=np.float64)
+    S = np.abs(aabbs).max()
+    far = orc.make_rays(np.array([[20 * S, 0.3, 0.1]]), np.array([[-1.0, 0.001, 0.002]]), np.float64)        # origin beyond 3 x the scene
+    axis = orc.make_rays(np.array([[-S, 1.0, 2.0]]), np.array([[1.0, 0.0, 0.0]]), np.float64)               # 1/d = inf on two axes
+    for odd in (far, axis):
+        rays = np.concatenate([good[:20_000], odd, good[20_000:]])
+        ooff, oidx = _oracle(orc, aabbs, rays)
+        off, idx, st = _csr(eng, flat, rays)
+        assert st["walk"] & WALK_WIDE and not st["walk"] & WALK_F64_GUIDE   # replayed with the f64 walk
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+    # the tree's result object stays with the f64 walk; a fresh tree object walks its guide again
+    flat2 = eng.Bvh.from_aabbs(aabbs).flatten()
+    ooff, oidx = _oracle(orc, aabbs, good)
+    off, idx, st = _csr(eng, flat2, good)
+    assert st["walk"] & WALK_F64_GUIDE and np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+
+
+def test_guide_boxes_follow_refit_and_scene_import(eng, orc):
+    from bvh_amd import FlatBvh
+    from bvh_amd._lib import WALK_F64_GUIDE
+    aabbs = _cubes64(1500)
+    bvh = eng.Bvh.from_aabbs(aabbs)
+    flat = bvh.flatten()
+    rays = np.concatenate([orc.create_rays(5, 30_000, dtype=np.float64), _grazing_rays(orc, aabbs, 30_000, 21)])
+    ooff, oidx = _oracle(orc, aabbs, rays)
+    off, idx, st = _csr(eng, flat, rays)
+    assert st["walk"] & WALK_F64_GUIDE and np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+    # an imported scene makes its wide nodes (and with them the guide boxes) from the traversal array alone (flatten.hip k_wide)
+    blob = np.zeros(flat.scene_nbytes(), np.uint8)
+    flat.scene_export(blob)
+    imp = FlatBvh.scene_import(blob, len(blob))
+    off, idx, st = _csr(eng, imp, rays)
+    assert st["walk"] & WALK_F64_GUIDE and np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+    # the shapes move (same topology): the refit re-flattens, the guide boxes follow; the oracle refits the same tree
+    rng = np.random.default_rng(2)
+    moved = aabbs + np.tile(rng.uniform(-0.4, 0.4, (len(aabbs), 3)), 2)
+    bvh.refit(moved)                                                          # (flat is the same tree: it is re-flattened)
+    rays2 = np.concatenate([rays[:30_000], _grazing_rays(orc, moved, 30_000, 22)])
+    ot = orc.build(aabbs)
+    oflat = orc.flatten(orc.refit(ot.nodes, moved))
+    off, idx, st = _csr(eng, flat, rays2)
+    assert st["walk"] & WALK_F64_GUIDE
+    from bvh_amd._lib import TUNE_WIDE_F64_GUIDE
+    flat.ctx.set_tuning(TUNE_WIDE_F64_GUIDE, 0)                              # the f64 walk over the same refitted tree is the reference here
+    off2, idx2, st2 = _csr(eng, flat, rays2)
+    flat.ctx.set_tuning(TUNE_WIDE_F64_GUIDE, 1)
+    assert not st2["walk"] & WALK_F64_GUIDE and np.array_equal(off, off2) and np.array_equal(idx, idx2)
+    ooff2, oidx2, _, _ = orc.traverse_flat(oflat, moved, rays2, threads=orc.max_threads())
+    assert np.array_equal(off, ooff2) and np.array_equal(idx, oidx2)
