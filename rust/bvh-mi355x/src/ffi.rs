@@ -1,4 +1,4 @@
-//! Declarations of include/bvh_mi355x.h (ABI version 3), one for one.  Every function returns a `bvhgpu_status`
+//! Declarations of include/bvh_mi355x.h (ABI version 4), one for one.  Every function returns a `bvhgpu_status`
 //! (0 = OK) and never unwinds; `bvhgpu_last_error` gives the text of the last failure on a ctx.
 #![allow(non_camel_case_types, dead_code)]
 use core::ffi::{c_char, c_int, c_uint, c_void};
@@ -32,6 +32,11 @@ pub const BVHGPU_TRAVERSE_NEAREST_FIRST: c_uint = 32;
 pub const BVHGPU_TRAVERSE_FARTHEST_FIRST: c_uint = 64;
 pub const BVHGPU_TRAVERSE_BEST_FIRST: c_uint = 128;
 pub const BVHGPU_TRAVERSE_RAYS_READY: c_uint = 256;
+// bvhgpu_hits_walk_info
+pub const BVHGPU_WALK_WIDE: c_uint = 1;
+pub const BVHGPU_WALK_STAGED: c_uint = 2;
+pub const BVHGPU_WALK_REC8: c_uint = 4;
+pub const BVHGPU_WALK_F64_GUIDE: c_uint = 8;
 pub const BVHGPU_COMM_ID_BYTES: usize = 128;
 pub const BVHGPU_BCAST_TRIANGLES: c_uint = 1;
 
