@@ -314,6 +314,12 @@ def run_workload(wl, args, env, steps, warmup, detailed):
     else:
         kern_name = f"bvhgpu::k_traverse<{ctype}, 0"
     pmc, src = newest_bound(kern_name, wl.name, wl.dtype_name, R)
+    if wl.dtype_name == "f64" and R >= 16384:   # an f64 index batch is walked by the f32 kernel over the tree's guide boxes (template flag GUIDE = 1)
+        items = 2 if R < N_CU * 2048 * 4 else 0
+        g_name = f"bvhgpu::k_traverse_wide<float, 0, {items}, 1024, 8, 1>"
+        g_pmc, g_src = newest_bound(g_name, wl.name, wl.dtype_name, R)
+        if g_pmc is not None and (src is None or g_src >= src):   # (the newer profile round says which walk the library runs)
+            kern_name, pmc, src = g_name, g_pmc, g_src
     roof = {
         "kernel": kern_name.rstrip("<,"), "kernel_ms": round(phases["traverse_kernel_ms"], 4),
         "algorithmic_bytes_per_launch": int(algo_bytes),
