@@ -728,9 +728,13 @@ constexpr uint32_t CUR_NONE = 0x7FFFFFFFu;   // neither a shape index (< 2^28) n
 #ifndef BVH_WIDE_INNER_STEPS_WHOLE
 #define BVH_WIDE_INNER_STEPS_WHOLE 8
 #endif
+#ifndef BVH_WIDE_INNER_STEPS_COHERENT
+#define BVH_WIDE_INNER_STEPS_COHERENT 12
+#endif
 // walk steps between two refill phases: items of a ray cut into 16 are short (2 / 3 / 4 / 6 steps: 0.1225 / 0.1220 / 0.1219 / 0.1252 ms on
-// configs[1]), whole rays walk for hundreds of steps (4 / 6 / 8: 1.50 / 1.45 / 1.42 ms for 10 M primary rays on the stand-in scene)
-template <int ITEMS_LOG4> struct WideSteps { static constexpr int N = ITEMS_LOG4 == 0 ? BVH_WIDE_INNER_STEPS_WHOLE : BVH_WIDE_INNER_STEPS; };
+// configs[1]: a compile-time 4), whole rays walk for hundreds of steps (a kernel argument: 4 / 6 / 8 / 12 / 16 → 1.50 / 1.45 / 1.42 / 1.38 / 1.41 ms for
+// 10 M primary rays on the stand-in scene, 2.28 / 2.28 / 2.26 / 2.27 / 2.30 for a 12.5 M-ray incoherent shard: 12 for batches the caller
+// calls COHERENT, 8 otherwise)
 #ifndef BVH_WIDE_MIN_WAVES_F32
 #define BVH_WIDE_MIN_WAVES_F32 8   // __launch_bounds__: waves per SIMD the f32 kernel must allow (8 = two 1024-thread workgroups per CU)
 #endif
@@ -1025,7 +1029,7 @@ template <typename T, int MODE, int ITEMS_LOG4, int MAX_THREADS, int MIN_WAVES, 
 __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     const WideNode<T>* __restrict__ wide, const uint32_t* __restrict__ wslot_node, uint32_t K, uint32_t stack_lds,
     const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_rays, uint32_t* __restrict__ list_all, const uint32_t* __restrict__ wg_items,
-    WalkOut<T> w, uint32_t* __restrict__ gstack, uint32_t gstack_cap, uint32_t* __restrict__ overflow, GuideArgs ga) {
+    WalkOut<T> w, uint32_t* __restrict__ gstack, uint32_t gstack_cap, uint32_t* __restrict__ overflow, GuideArgs ga, uint32_t whole_steps) {
     static_assert(GUIDE == 0 || (MODE == MODE_INDICES && sizeof(T) == 4), "the guide walk is the f32 index walk");
     static_assert(ITEMS_LOG4 >= 0 && ITEMS_LOG4 <= 2, "1, 4 or 16 items per ray");
     static_assert(MODE != MODE_T_SLICE, "the t-slice output walks the binary array");
@@ -1041,7 +1045,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     uint4* nodes = wsmem + 5;
     uint32_t* s_stack = reinterpret_cast<uint32_t*>(nodes + (size_t)CH * K);
     const uint32_t bd = blockDim.x, tid = threadIdx.x;
-    constexpr int WIDE_INNER_STEPS = WideSteps<ITEMS_LOG4>::N;
+    const int WIDE_INNER_STEPS = ITEMS_LOG4 == 0 ? (int)whole_steps : BVH_WIDE_INNER_STEPS;
     constexpr uint32_t SB = MAX_THREADS;   // stride of the LDS stack's entry planes: a constant, so that the three stores of a push share one address register
     const size_t G = (size_t)gridDim.x * bd, gid = (size_t)blockIdx.x * bd + tid;
     const int lane = lane_id();
@@ -1660,7 +1664,8 @@ static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
     }
     hipLaunchKernelGGL(kern, grid, dim3(g.threads), g.lds_bytes, st, GUIDE ? t->wide_guide.as<WideNode<T>>() : t->wide.as<WideNode<T>>(),
                        t->wslot_node.as<uint32_t>(), g.K, g.stack_lds, rays_dev, (uint32_t)n_rays, list, wg_items, w, h->wstack.as<uint32_t>(),
-                       WIDE_GSTACK, ovf_flag, ga);
+                       WIDE_GSTACK, ovf_flag, ga,
+                       (uint32_t)((h->flags & BVHGPU_TRAVERSE_COHERENT) ? BVH_WIDE_INNER_STEPS_COHERENT : BVH_WIDE_INNER_STEPS_WHOLE));
 }
 
 // ---- one batch = enqueue (no host round trip) + check (after the stream has been synchronised) --------------------
