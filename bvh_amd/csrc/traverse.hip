@@ -1596,7 +1596,7 @@ static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
 template <typename T> struct WideGeom {
     uint32_t threads, wg_per_cu, stack_lds, K;
     size_t lds_bytes;
-    WideGeom(const bvhgpu_ctx* ctx, bool whole_rays) {
+    WideGeom(const bvhgpu_ctx* ctx, bool whole_rays, bool coherent = false) {
         const bool f64 = sizeof(T) == 8;
         const int want_threads = ctx->tune[BVHGPU_TUNE_WIDE_THREADS] > 0 ? ctx->tune[BVHGPU_TUNE_WIDE_THREADS] : (f64 ? 512 : 1024);
         threads = (uint32_t)std::min(f64 ? 512 : 1024, std::max(64, want_threads & ~63));
@@ -1604,8 +1604,9 @@ template <typename T> struct WideGeom {
                                                    (int)(2048 / threads)));
         // 16 items per ray (short walks below tree level 4): 4 / 6 / 8 / 10 / 12 entries measured, 6; whole rays on the stand-in scene (a lane on the
         // slow push path in 68-93 % of the steps with 6): 4 / 6 / 8 / 10 / 12 / 16 → 1.71 / 1.58 / 1.50 / 1.48 / 1.47 / 1.50 ms for 10 M primary rays,
-        // 2.79 / 2.46 / 2.28 / 2.31 / 2.39 / 2.60 ms for a 12.5 M-ray incoherent shard: 8
-        stack_lds = (uint32_t)std::max(0, std::min(ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] >= 0 ? ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] : (whole_rays ? 8 : 6), 32));
+        // 2.79 / 2.46 / 2.28 / 2.31 / 2.39 / 2.60 ms for a 12.5 M-ray incoherent shard: 8, and 10 for batches the caller calls COHERENT (with 12 steps
+        // between refills: 8 / 10 / 12 entries → 1.39 / 1.36 / 1.37 ms)
+        stack_lds = (uint32_t)std::max(0, std::min(ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] >= 0 ? ctx->tune[BVHGPU_TUNE_WIDE_STACK_LDS] : (whole_rays ? (coherent ? 10 : 8) : 6), 32));
         // static LDS of the kernel: item table (448 / 832 bytes) + block sums (512 bytes)
         const size_t budget = (size_t)(160 * 1024) / wg_per_cu - (f64 ? 1536 : 1024);
         const size_t stack_stride = f64 ? 512 : 1024;   // (the kernel's MAX_THREADS: its stack planes have a fixed stride)
@@ -1625,7 +1626,7 @@ static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
                         uint32_t* ovf_flag, bool early_items, GuideArgs ga = GuideArgs{nullptr, nullptr}) {
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
-    const WideGeom<T> g(ctx, ITEMS_LOG4 == 0);
+    const WideGeom<T> g(ctx, ITEMS_LOG4 == 0, (h->flags & BVHGPU_TRAVERSE_COHERENT) != 0);
     const size_t full = (n_rays + g.threads - 1) / g.threads;
     const dim3 grid((unsigned)std::min<size_t>(std::max<size_t>(full, 1), (size_t)ctx->n_cu * g.wg_per_cu));
     uint32_t* list = nullptr;
@@ -1866,8 +1867,8 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         counts = h->wcounts.as<uint32_t>();
         // the walk's workgroups leave the hits per 64-ray block (their own blocks: LDS sums): no reduce pass for the scan
         {
-            const WideGeom<T> gt(ctx, items_log4 == 0);
-            const WideGeom<float> gf(ctx, items_log4 == 0);   // (the guide walk of an f64 batch launches the f32 geometry)
+            const WideGeom<T> gt(ctx, items_log4 == 0, coherent);
+            const WideGeom<float> gf(ctx, items_log4 == 0, coherent);   // (the guide walk of an f64 batch launches the f32 geometry)
             const uint32_t g_threads = use_guide ? gf.threads : gt.threads, g_wg_per_cu = use_guide ? gf.wg_per_cu : gt.wg_per_cu;
             const size_t full = (n_rays + g_threads - 1) / g_threads;
             const size_t grid = std::min<size_t>(std::max<size_t>(full, 1), (size_t)ctx->n_cu * g_wg_per_cu);   // launch_wide: the same

@@ -341,7 +341,7 @@ typedef enum {
                                               array with ray refill and the top of the tree resident in LDS; 3 (default) wide
                                               walk (four grandchild boxes per step) where its preconditions hold, else 2 */
     BVHGPU_TUNE_WIDE_ITEMS_LOG4 = 1,       /* variant 3, CSR outputs: cut every ray into up to 4^v items (v = 0, 1, 2); default -1 = by batch size */
-    BVHGPU_TUNE_WIDE_STACK_LDS = 2,        /* variant 3: stack entries per lane kept in LDS (default -1 = 6 for rays cut into items, 8 for whole rays; deeper entries live in HBM) */
+    BVHGPU_TUNE_WIDE_STACK_LDS = 2,        /* variant 3: stack entries per lane kept in LDS (default -1 = 6 for rays cut into items, 8 for whole rays, 10 for whole rays of a COHERENT batch; deeper entries live in HBM) */
     BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS = 3, /* variant 2 is used for batches of at least this many rays (default 16384) */
     BVHGPU_TUNE_TRAVERSE_LDS_SLOTS = 4,    /* variant 2: top-of-tree entries kept in LDS per workgroup (default 0 = as many as let two workgroups share a CU: f32 2559, f64 1462) */
     BVHGPU_TUNE_TRAVERSE_LDS_THREADS = 5,  /* variant 2: workgroup size (default 0 = per type: f32 1024, f64 512) */
