@@ -4,8 +4,13 @@
 One STEP = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
 Bvh::build_par (SAH) → Bvh::flatten → FlatBvh::traverse of R rays, results left in HBM as CSR.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: bench.py starts the N ranks itself, below)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A run is never downgraded: `--gpus N` with no WORLD_SIZE in the environment re-executes itself under torch.distributed.run with N
+ranks on 127.0.0.1 (resolve_launch / self_launch); with a WORLD_SIZE that is not N it stops with an error.  The JSON line says how
+many ranks there really were: "launch" (ranks counted through the process group, the devices they sat on) and "rccl" (the size the
+C ABI's RCCL communicator reports for itself, RCCL's version and library file).
 
 Headline workload (`value`): BASELINE.json configs[1] — create_n_cubes(10 000) = 120 000 triangles f32/3D and
 R = 1 000 000 create_ray rays PER GPU (weak scaling: rank r traverses rays [r*R, (r+1)*R) of the seed-0 stream).
@@ -79,6 +84,60 @@ def parse():
     ap.add_argument("--cpu-sample-rays", type=int, default=1_000_000)
     ap.add_argument("--standin-detail", type=int, default=16)
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def resolve_launch(gpus, environ):
+    """How this invocation becomes `gpus` ranks.  Returns ("run", world) when this process IS one rank of a launched job (or
+    the single rank of an N = 1 run) and ("spawn", gpus) when it has to launch the ranks itself.  A run can never silently
+    shrink: --gpus N with a WORLD_SIZE that is set and is not N is an error, and --gpus N > 1 without WORLD_SIZE launches
+    N ranks — it never falls through to one rank reporting n_gpus = 1 (the old code did exactly that)."""
+    if gpus < 1:
+        raise SystemExit(f"--gpus {gpus}: need at least one GPU")
+    ws = environ.get("WORLD_SIZE")
+    if ws is None or ws == "":
+        return ("run", 1) if gpus == 1 else ("spawn", gpus)
+    try:
+        world = int(ws)
+    except ValueError:
+        raise SystemExit(f"WORLD_SIZE={ws!r} is not a number")
+    if world != gpus:
+        raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}: the launcher and the flag must agree (a run is never downgraded)")
+    for k in ("RANK", "LOCAL_RANK"):
+        if world > 1 and environ.get(k) in (None, ""):
+            raise SystemExit(f"WORLD_SIZE={world} but {k} is not set: launch with torch.distributed.run (or plain `python bench.py --gpus {gpus}`)")
+    return ("run", world)
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_command(gpus, argv, port):
+    """the command `python bench.py --gpus N` turns itself into: the driver's own launch line (one rank per GPU, rendezvous on 127.0.0.1)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(gpus, argv):
+    """`python bench.py --gpus N` without a launcher: run N ranks under torch.distributed.run and pass rank 0's JSON line through."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["BVH_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = launch_command(gpus, argv, free_port())
+    sys.stderr.write("bench.py: --gpus %d without a launcher: running %s\n" % (gpus, " ".join(cmd)))
+    sys.stderr.flush()
+    if os.environ.get("BVH_BENCH_LAUNCH_DRY_RUN"):      # tests: show what would run, run nothing
+        print(json.dumps({"launch": cmd}))
+        return 0
+    return subprocess.call(cmd, env=env)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -418,6 +477,9 @@ def check_parity(wl, env, orc, n_check, chunk=1_000_000):
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
+    how, world = resolve_launch(args.gpus, os.environ)
+    if how == "spawn":
+        raise SystemExit(self_launch(world, sys.argv[1:]))
     # Exactly ONE line goes to stdout: the JSON.  RCCL prints a version banner to stdout when a communicator is created (torch's
     # and the engine's), so everything else that writes to fd 1 during the run is sent to stderr.
     sys.stdout.flush()
@@ -428,12 +490,12 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world != 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     n_gpus = world
+    assert n_gpus == args.gpus     # resolve_launch: the run has exactly the ranks the flag asked for
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if not args.one_device and torch.cuda.device_count() < (local_rank + 1):
+        raise SystemExit(f"rank {rank} (local rank {local_rank}) has no GPU: {torch.cuda.device_count()} visible, --gpus {args.gpus}")
     if args.one_device:
         if args.backend != "gloo":
             raise SystemExit("--one-device needs --backend gloo")
@@ -469,6 +531,24 @@ def main():
         if int(ok.item()) == 0:
             comm = None
     env = dict(rank=rank, n_gpus=n_gpus, dev=dev, ctx=ctx, comm=comm)
+    # how many ranks this job REALLY has, counted three ways: the launcher's WORLD_SIZE (= --gpus, resolve_launch), a sum over the
+    # torch.distributed group, and the size the C ABI's RCCL communicator reports for itself (bvhgpu_comm_info)
+    ranks_seen, devices_seen = 1, [torch.cuda.current_device()]
+    if n_gpus > 1:
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(one.item())
+        dl = [None] * n_gpus
+        dist.all_gather_object(dl, f"{os.uname().nodename}:{torch.cuda.current_device()}")
+        devices_seen = dl
+    rccl_obj = None
+    if comm is not None:
+        rccl_obj = comm.info()
+    launch_obj = {"world_size": n_gpus, "ranks_seen": ranks_seen, "self_launched": bool(os.environ.get("BVH_BENCH_SELF_LAUNCHED")),
+                  "backend": args.backend if n_gpus > 1 else None, "devices": devices_seen,
+                  "distinct_devices": len(set(devices_seen))}
+    if ranks_seen != n_gpus:
+        raise SystemExit(f"--gpus {args.gpus}: the process group holds {ranks_seen} ranks")
 
     wl = Workload(args.workload, args, args.dtype, rank, n_gpus, dev, ctx, scaling=args.scaling, rays=args.rays)
     torch.cuda.synchronize(dev)
@@ -492,6 +572,8 @@ def main():
         "scene_dist_probe_ms_per_step": res["scene_dist_probe_ms_per_step"],
         "roofline": res["roofline"], "roofline_build": res.get("roofline_build"),
     }
+    out["launch"] = launch_obj
+    out["rccl"] = rccl_obj     # None: no RCCL communicator in this run (N = 1, --backend gloo, --scene-dist replicate, or rccl_comm_error)
     if comm_err:
         out["rccl_comm_error"] = comm_err
 
@@ -567,6 +649,11 @@ def main():
                     r2["note"] = ("one GPU's share of configs[3]: rays [62.5 M, 75 M) of the 100 M-ray stream (rank 5 of 8)" if scaling == "weak" else
                                   "configs[3] whole: all 100 M rays of the stream on one GPU in one batch — the N = 1 point of the strong-scaling "
                                   "curve whose N > 1 points the same entry carries when bench.py runs with --gpus N")
+                if name == "standin-incoherent" and scaling == "strong" and nrays == 100_000_000 and args.standin_detail == 16:
+                    # the whole stream's hit count as one GPU produced it with oracle parity on all 100 M rays (BENCH_r03 extra_configs):
+                    # the shards of an N > 1 run must add up to exactly this
+                    r2["hits_n1_reference"] = 457_389_170
+                    r2["hits_match_n1_reference"] = bool(r2["hits_all_ranks"] == 457_389_170)
                 if dt == "f64":
                     r2["note"] = ("tree, rays, builder and every test that decides a hit in f64; the walk's inner-node tests run on f32 boxes that contain "
                                   "the f64 ones (BVHGPU_TUNE_WIDE_F64_GUIDE, DESIGN.md §4 \"f64 guide walk\"): same lists, checked against the f64 oracle below")

@@ -108,6 +108,7 @@ SYMBOLS = [
     ("bvhgpu_comm_init_all", _i, [_pp, _i, _pp]),
     ("bvhgpu_comm_info", _i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     ("bvhgpu_comm_destroy", None, [_vp]),
+    ("bvhgpu_rccl_info", _i, [C.POINTER(_i), C.POINTER(_i), C.c_char_p, _sz]),
     ("bvhgpu_bcast", _i, [_vp, _pp, _i]),
     ("bvhgpu_bcast_known", _i, [_vp, _pp, _i, _i, _sz, _u]),
     ("bvhgpu_rays_new_f32", _i, [_vp, _vp, _vp, _sz, _i, _vp, _i]),
@@ -149,7 +150,7 @@ TUNE_WIDE_REC8 = 13              # wide walk, whole rays, indices only: 8-byte p
 TUNE_BUILD_LEVEL_LAUNCHES = 10   # builder, level tier: 1 one launch per level, 2 k_bin + k_split per level, 0 (default) by scene size
 TUNE_WIDE_F64_GUIDE = 14        # wide walk, f64 trees, indices only: walk the f32 guide boxes, test leaf candidates in f64 (1, default) or the f64 walk (0)
 WALK_WIDE, WALK_STAGED, WALK_REC8, WALK_F64_GUIDE = 1, 2, 4, 8   # bvhgpu_hits_walk_info
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 

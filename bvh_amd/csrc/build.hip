@@ -2133,7 +2133,11 @@ template <typename T> void build_finalize(bvhgpu_tree* t) {
     const size_t n = t->n;
     const size_t MID_MAX = n <= MID_SCENE_SPLIT ? (size_t)MidSmallScene<T>::MAXN : (size_t)MidLargeScene<T>::MAXN;
     uint32_t* pin = reinterpret_cast<uint32_t*>(t->pin);
-    if (pin[CTR_FLAGS] & BUILD_FLAG_NONFINITE) { t->flattened = false; throw HipFail{hipErrorInvalidValue, "NONFINITE", __LINE__}; }
+    if (pin[CTR_FLAGS] & BUILD_FLAG_NONFINITE) {
+        t->flattened = false;
+        t->failed_gen = t->gen; t->failed_what = "NONFINITE";   // (batches already enqueued on this generation walked nothing: their waits say so)
+        throw HipFail{hipErrorInvalidValue, "NONFINITE", __LINE__};
+    }
     int level = t->pend_level;
     if (n > (size_t)MID_MAX && pin[CTR_LEVEL0 + 2 * lvl_slot(level)] != 0) {
         // slow path: the level queue is not empty yet (unbalanced tree) — one more level per host round trip.  The counters

@@ -119,6 +119,10 @@ void finish_hits(bvhgpu_hits* h) {
     bool rebroadcast = false;
     try { ensure_built(t); }
     catch (const HipFail& e) { if (e.what && std::strcmp(e.what, "REBROADCAST") == 0) rebroadcast = true; else throw; }
+    // the generation this batch walked turned out to hold nothing (NaN / inf input, a broadcast whose root had no valid tree) and the
+    // error may have been consumed elsewhere — bvhgpu_tree_wait, a rebuild that replaces the tree, another result object's wait: the
+    // wait of THIS batch still returns what the synchronous call would have returned, never lists from an unbuilt tree
+    if (t->failed_gen != 0 && t->failed_gen == h->pend_gen) throw HipFail{hipErrorInvalidValue, t->failed_what ? t->failed_what : "NONFINITE", __LINE__};
     bool replay = h->pend_on_pending && h->pend_gen == t->gen && (t->redone_gen == h->pend_gen || (h->pend_wide && t->exact_only));
     if (h->pend_gen != t->gen) throw HipFail{hipErrorInvalidValue, "STALE_TREE", __LINE__};   // (rebuild / import settle the waiters first: unreachable)
     const void* rays = h->pend_rays;

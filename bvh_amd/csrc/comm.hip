@@ -58,6 +58,9 @@ struct RcclApi {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;   // optional: reported by bvhgpu_rccl_info
+    std::string path;      // the file the entry points came from (dladdr), for bvhgpu_rccl_info
+    bool shared = false;   // true: a copy the process already held (RTLD_NOLOAD), no second RCCL was loaded
     bool ok() const { return lib != nullptr; }
 };
 
@@ -71,7 +74,11 @@ RcclApi& rccl() {
         std::vector<std::string> names;
         if (const char* e = std::getenv("BVHGPU_RCCL_LIB")) names.push_back(e);
         void* h = nullptr;
-        if (names.empty()) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (names.empty())   // (RTLD_NOLOAD matches by SONAME or by the name the copy was loaded under: try both spellings)
+            for (const char* n : {"librccl.so.1", "librccl.so"}) {
+                h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+                if (h) { api.shared = true; break; }
+            }
         if (!h) {
             if (names.empty()) {
                 names = {"librccl.so.1", "librccl.so"};
@@ -95,7 +102,14 @@ RcclApi& rccl() {
         api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
         api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
-        if (all) api.lib = h;
+        api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(h, "ncclGetVersion"));
+        if (all) {
+            api.lib = h;
+            Dl_info di;
+            if (dladdr(reinterpret_cast<void*>(api.Broadcast), &di) && di.dli_fname) api.path = di.dli_fname;
+            if (std::getenv("BVHGPU_RCCL_DEBUG"))
+                fprintf(stderr, "bvhgpu: RCCL entry points from %s (%s)\n", api.path.c_str(), api.shared ? "already loaded in this process" : "loaded by libbvh_mi355x");
+        }
     });
     return api;
 }
@@ -156,7 +170,7 @@ constexpr uint32_t BCAST_MAGIC = 0x42564843u;   // "BVHC" (round 2: BVHB, withou
 // bstat != NULL: the build's outcome is not known to the host yet — it is taken from the word k_flatten's publishing block left.
 __global__ void k_bcast_header(BcastHeader* dst, BcastHeader h, const uint32_t* __restrict__ bstat) {
     if (threadIdx.x != 0) return;
-    if (bstat) {
+    if (bstat && h.status == BH_GOOD) {   // (what the host already found wrong with the root's tree stays: the root does not join a rebroadcast)
         const uint32_t s = bstat[0];
         if (s & BSTAT_NONFINITE) h.status = BH_INVALID;
         else if (s & BSTAT_UNFINISHED) h.status = BH_UNFINISHED;
@@ -331,9 +345,11 @@ void recv_finalize(bvhgpu_tree* t) {
     BVH_HIP(hipStreamSynchronize(t->ctx->stream));
     t->pending_recv = false;
     const BcastHeader h = *reinterpret_cast<const BcastHeader*>(t->pin_recv);
-    if (h.magic != BCAST_MAGIC || h.status > BH_UNFINISHED) { t->flattened = false; throw HipFail{hipErrorUnknown, "RECV_GARBLED", __LINE__}; }
-    if (h.status == BH_INVALID) { t->flattened = false; throw HipFail{hipErrorInvalidValue, "RECV_INVALID", __LINE__}; }
-    if (h.status == BH_UNFINISHED) { t->flattened = false; throw HipFail{hipErrorNotReady, "RECV_REBROADCAST", __LINE__}; }
+    // (nothing usable arrived: batches that were enqueued on this generation meanwhile return the same status from their own wait)
+    auto nothing = [&](hipError_t e, const char* what, int line) { t->flattened = false; t->failed_gen = t->gen; t->failed_what = what; throw HipFail{e, what, line}; };
+    if (h.magic != BCAST_MAGIC || h.status > BH_UNFINISHED) nothing(hipErrorUnknown, "RECV_GARBLED", __LINE__);
+    if (h.status == BH_INVALID) nothing(hipErrorInvalidValue, "RECV_INVALID", __LINE__);
+    if (h.status == BH_UNFINISHED) nothing(hipErrorNotReady, "RECV_REBROADCAST", __LINE__);
     t->exact_only = (h.flags & 1u) != 0;   // batches that were enqueued meanwhile and walked wide are replayed by their wait
     if (t->exact_only) t->has_wide = false;
 }
@@ -428,6 +444,16 @@ int bvhgpu_comm_info(const bvhgpu_comm* c, int* nranks, int* first_rank, int* n_
     return BVHGPU_OK;
 }
 
+// Which RCCL the broadcasts go through: version code (ncclGetVersion: major * 10000 + minor * 100 + patch), the file the entry
+// points were resolved from and whether that copy was already loaded in the process.  Loads RCCL if nothing has yet.
+int bvhgpu_rccl_info(int* version, int* shared_with_process, char* library_path, size_t cap) {
+    if (!rccl().ok()) return BVHGPU_RCCL_ERROR;
+    if (version) { int v = 0; if (!rccl().GetVersion || rccl().GetVersion(&v) != ncclSuccess) v = 0; *version = v; }
+    if (shared_with_process) *shared_with_process = rccl().shared ? 1 : 0;
+    if (library_path && cap) { std::snprintf(library_path, cap, "%s", rccl().path.c_str()); }
+    return BVHGPU_OK;
+}
+
 // Every rank knows the scene's type and size (a frame loop over a scene of constant shape count): ONE group of broadcasts,
 // enqueued on the streams, no host round trip on any rank — also when the root's build is still in flight.
 int bvhgpu_bcast_known(bvhgpu_comm* c, bvhgpu_tree** trees, int root, int dtype, size_t n_shapes, unsigned what) {
@@ -457,8 +483,8 @@ int bvhgpu_bcast_known(bvhgpu_comm* c, bvhgpu_tree** trees, int root, int dtype,
             bvhgpu_ctx* rctx = c->ctxs[local_root];
             BVH_HIP(hipSetDevice(rctx->device));
             hipLaunchKernelGGL(k_bcast_header, dim3(1), dim3(64), 0, rctx->stream, reinterpret_cast<BcastHeader*>(c->hdr_dev[local_root]), h,
-                               optimistic ? r->bstat.as<uint32_t>() : (const uint32_t*)nullptr);
-            if (optimistic) r->bcast_gen = r->gen;
+                               (optimistic && root_rc == BVHGPU_OK) ? r->bstat.as<uint32_t>() : (const uint32_t*)nullptr);
+            if (optimistic && root_rc == BVHGPU_OK) r->bcast_gen = r->gen;   // (a broadcast that carried nothing valid is not "this generation was sent")
         }
         bcast_arrays(c, trees, root, dtype, n_shapes, n_trav, false, (what & BVHGPU_BCAST_TRIANGLES) != 0, true, root_rc == BVHGPU_OK, true, false);
         return (int)BVHGPU_OK;

@@ -78,6 +78,9 @@ struct bvhgpu_tree {
                                  // were enqueued on that generation before the finalize walked an unfinished tree and are replayed by
                                  // bvhgpu_hits_wait — by EVERY result object that recorded it, whoever finalized the build first
     uint64_t bcast_gen = 0;      // the generation that bvhgpu_bcast_known sent before its build was finalized (comm.hip)
+    uint64_t failed_gen = 0;     // the generation whose build_finalize / recv_finalize found nothing usable (NaN / inf input, a root without a
+    const char* failed_what = nullptr;   // valid tree): WHOEVER consumed that error first (bvhgpu_tree_wait, a rebuild, another result object's
+                                 // wait), every asynchronous batch that was enqueued on that generation returns it from its own wait
     bool pending_recv = false;   // a broadcast was received on the stream; its status header (t->pin_recv) has not been looked at yet
     void* pin_recv = nullptr;    // 64 B of pinned host memory: the received broadcast header
     bvhgpu_comm* recv_comm = nullptr;

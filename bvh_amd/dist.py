@@ -90,6 +90,10 @@ class Communicator:
         check(lib.bvhgpu_tree_info(h, C.byref(dt), None, None, None), self.ctx._h)
         return FlatBvh(self.ctx, h, "f32" if dt.value == _lib.F32 else "f64")
 
+    def info(self) -> dict:
+        """what the communicator itself says (bvhgpu_comm_info) + which RCCL it runs over (bvhgpu_rccl_info)"""
+        return comm_info(self._h)
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.load().bvhgpu_comm_destroy(self._h)
@@ -100,6 +104,29 @@ class Communicator:
             self.close()
         except Exception:
             pass
+
+
+def rccl_info() -> dict:
+    """bvhgpu_rccl_info: version code and file of the RCCL the C ABI's broadcasts go through (loads it on first use)"""
+    lib = _lib.load()
+    ver, shared = C.c_int(0), C.c_int(0)
+    path = C.create_string_buffer(512)
+    check(lib.bvhgpu_rccl_info(C.byref(ver), C.byref(shared), path, 512))
+    v = int(ver.value)
+    return {"version_code": v, "version": f"{v // 10000}.{v // 100 % 100}.{v % 100}" if v else None,
+            "library": path.value.decode(errors="replace"), "shared_with_process": bool(shared.value)}
+
+
+def comm_info(handle) -> dict:
+    lib = _lib.load()
+    nr, fr, nl = C.c_int(0), C.c_int(0), C.c_int(0)
+    check(lib.bvhgpu_comm_info(handle, C.byref(nr), C.byref(fr), C.byref(nl)))
+    out = {"nranks": int(nr.value), "first_rank": int(fr.value), "n_local": int(nl.value)}
+    try:
+        out.update(rccl_info())
+    except _lib.BvhGpuError as e:   # (cannot happen on a live communicator; never let a report take a run down)
+        out["rccl_info_error"] = str(e)
+    return out
 
 
 def broadcast_step(comm: "Communicator", rank: int, tree, aabbs, rays, dtype: str, n_shapes: int, hits=None, flags: int = 0, root: int = 0):
@@ -176,6 +203,9 @@ class LocalCommunicator:
         if rc != _lib.OK and raise_on_error:
             check(rc, self.ctxs[min(max(root, 0), self.nranks - 1)]._h)
         return out
+
+    def info(self) -> dict:
+        return comm_info(self._h)
 
     def close(self):
         if getattr(self, "_h", None):

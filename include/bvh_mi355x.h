@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BVHGPU_ABI_VERSION 4 /* 4: BVHGPU_TUNE_COUNT 15 (slot 14 = WIDE_F64_GUIDE), bvhgpu_hits_walk_info.  3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 14 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT, 13 = WIDE_REC8), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
+#define BVHGPU_ABI_VERSION 5 /* 5: bvhgpu_rccl_info.  4: BVHGPU_TUNE_COUNT 15 (slot 14 = WIDE_F64_GUIDE), bvhgpu_hits_walk_info.  3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 14 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT, 13 = WIDE_REC8), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
 #define BVHGPU_NONE 0xFFFFFFFFu /* u32::MAX marker (flat_bvh.rs:51-53, :124, :137) */
 
 typedef enum {
@@ -234,6 +234,12 @@ int bvhgpu_comm_init_rank(bvhgpu_ctx *ctx, int nranks, int rank, const void *id,
 int bvhgpu_comm_init_all(bvhgpu_ctx *const *ctxs, int ndev, bvhgpu_comm **out);
 int bvhgpu_comm_info(const bvhgpu_comm *comm, int *nranks, int *first_rank, int *n_local);
 void bvhgpu_comm_destroy(bvhgpu_comm *comm);
+/* Which RCCL the broadcasts go through: `version` = ncclGetVersion's code (major*10000 + minor*100 + patch; 0 if the library
+ * has no such entry point), `shared_with_process` = 1 when the copy was already loaded in the process (PyTorch bundles one) and
+ * no second RCCL was opened, `library_path` = the file the entry points were resolved from (truncated to cap).  Loads RCCL on
+ * first use like every bvhgpu_comm_* call; BVHGPU_RCCL_ERROR when there is none.  Launchers print it so that a scaling record
+ * shows how many ranks over which library it ran (bench.py's "rccl" object). */
+int bvhgpu_rccl_info(int *version, int *shared_with_process, char *library_path, size_t cap);
 /* peers learn type and size from a 64-byte header that travels first (one host round trip per rank).  If the root has no valid
  * tree (NULL, not flattened, invalid input) it still sends the header: its own call returns the reason, the peers' calls return
  * BVHGPU_INVALID_ARG — nobody is left waiting inside a collective. */

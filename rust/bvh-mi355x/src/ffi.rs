@@ -1,9 +1,9 @@
-//! Declarations of include/bvh_mi355x.h (ABI version 4), one for one.  Every function returns a `bvhgpu_status`
+//! Declarations of include/bvh_mi355x.h (ABI version 5), one for one.  Every function returns a `bvhgpu_status`
 //! (0 = OK) and never unwinds; `bvhgpu_last_error` gives the text of the last failure on a ctx.
 #![allow(non_camel_case_types, dead_code)]
 use core::ffi::{c_char, c_int, c_uint, c_void};
 
-pub const BVHGPU_ABI_VERSION: c_int = 4;
+pub const BVHGPU_ABI_VERSION: c_int = 5;
 pub const BVHGPU_NONE: u32 = u32::MAX; // flat_bvh.rs:51-53
 
 // bvhgpu_status
@@ -124,6 +124,7 @@ extern "C" {
     pub fn bvhgpu_comm_init_all(ctxs: *const *mut bvhgpu_ctx, ndev: c_int, out: *mut *mut bvhgpu_comm) -> c_int;
     pub fn bvhgpu_comm_info(comm: *const bvhgpu_comm, nranks: *mut c_int, first_rank: *mut c_int, n_local: *mut c_int) -> c_int;
     pub fn bvhgpu_comm_destroy(comm: *mut bvhgpu_comm);
+    pub fn bvhgpu_rccl_info(version: *mut c_int, shared_with_process: *mut c_int, library_path: *mut c_char, cap: usize) -> c_int;
     pub fn bvhgpu_bcast(comm: *mut bvhgpu_comm, trees: *mut *mut bvhgpu_tree, root: c_int) -> c_int;
     pub fn bvhgpu_bcast_known(comm: *mut bvhgpu_comm, trees: *mut *mut bvhgpu_tree, root: c_int, dtype: c_int, n_shapes: usize, what: c_uint) -> c_int;
     // rays: Ray::new (ray_impl.rs:70-80), the bench stream (testbase.rs:687-691), primary rays

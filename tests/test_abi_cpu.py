@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(built):
     nm = subprocess.run(["nm", "-D", "--defined-only", built.SO_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (bvhgpu_[a-z0-9_]+)", nm))
     assert set(declared) <= exported
-    assert lib.bvhgpu_abi_version() == built.ABI_VERSION == 4
+    assert lib.bvhgpu_abi_version() == built.ABI_VERSION == 5
 
 
 def test_library_contains_gfx950_code_object(built):
@@ -217,3 +217,68 @@ def test_two_rank_gloo_sharding_matches_single_process(tmp_path):
     cat_idx = np.concatenate([parts[0][2], parts[1][2]])
     cat_off = np.concatenate([parts[0][1][:-1], parts[1][1] + parts[0][1][-1]])
     assert np.array_equal(cat_idx, idx) and np.array_equal(cat_off, off)
+
+
+def test_bench_gpus_flag_can_never_be_downgraded():
+    """`python bench.py --gpus 8` without torchrun used to fall through to ONE rank and print n_gpus = 1.  Now the flag
+    and the launcher must agree, and without a launcher bench.py starts the ranks itself."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.resolve_launch(1, {}) == ("run", 1)
+    assert bench.resolve_launch(1, {"WORLD_SIZE": "1"}) == ("run", 1)
+    for n in (2, 4, 8):
+        assert bench.resolve_launch(n, {}) == ("spawn", n)                       # no launcher: N ranks are started, never 1
+        assert bench.resolve_launch(n, {"WORLD_SIZE": ""}) == ("spawn", n)
+        assert bench.resolve_launch(n, {"WORLD_SIZE": str(n), "RANK": "0", "LOCAL_RANK": "0"}) == ("run", n)
+        for ws in ("1", str(n + 1), "x"):                                        # the launcher disagrees with the flag: hard error
+            with pytest.raises(SystemExit):
+                bench.resolve_launch(n, {"WORLD_SIZE": ws, "RANK": "0", "LOCAL_RANK": "0"})
+        with pytest.raises(SystemExit):
+            bench.resolve_launch(n, {"WORLD_SIZE": str(n)})                      # WORLD_SIZE without RANK: not a launched rank
+    with pytest.raises(SystemExit):
+        bench.resolve_launch(1, {"WORLD_SIZE": "8", "RANK": "3", "LOCAL_RANK": "3"})   # torchrun with 8 ranks but --gpus 1
+    with pytest.raises(SystemExit):
+        bench.resolve_launch(0, {})
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "5"], 29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "5"]
+
+
+def test_bench_self_launch_starts_n_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment: the dry run shows the torch.distributed.run command it
+    becomes; the real thing starts two ranks — on this GPU-less box both stop at "needs an MI355X", and no JSON line claiming
+    n_gpus = 1 is ever printed."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=dict(env, BVH_BENCH_LAUNCH_DRY_RUN="1"), capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    cmd = json.loads(p.stdout.strip().splitlines()[-1])["launch"]
+    assert "--nproc-per-node=2" in cmd and cmd[-6:] == ["--gpus", "2", "--steps", "1", "--warmup", "0"]
+    import torch
+    if torch.cuda.is_available():
+        return                                   # (on a GPU box tests/test_gpu_dist.py runs the real thing to the end)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--backend", "gloo", "--one-device"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.stderr.count("bench.py needs an MI355X") >= 2, p.stderr[-3000:]      # BOTH ranks got as far as looking for their GPU
+
+
+def test_rccl_is_shared_with_the_process_not_loaded_twice():
+    """comm.hip dlopen()s RCCL; when the process already holds a copy (PyTorch bundles librccl.so) that copy must be the
+    one used — a second RCCL in the process would open the devices again.  bvhgpu_rccl_info names what was resolved (no GPU needed)."""
+    code = ("import os, json, torch\n"
+            "from bvh_amd import dist\n"
+            "i = dist.rccl_info()\n"
+            "m = sorted({os.path.realpath(l.split()[-1]) for l in open('/proc/self/maps') if 'librccl' in l})\n"
+            "print(json.dumps({'info': i, 'mapped': m}))\n")
+    import json
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert len(r["mapped"]) == 1, r
+    assert os.path.realpath(r["info"]["library"]) == r["mapped"][0] and r["info"]["shared_with_process"] is True, r
+    assert r["info"]["version_code"] >= 20000

@@ -100,6 +100,43 @@ def test_rebuild_and_destroy_complete_batches_in_flight(eng, orc):
     assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
 
 
+@pytest.mark.parametrize("consumer", ["tree_wait", "rebuild_good", "other_result"])
+def test_failed_build_reaches_every_batch_enqueued_on_it(eng, orc, consumer):
+    """a NaN build's INVALID_ARG can be consumed by bvhgpu_tree_wait, by the rebuild that replaces the tree or by
+    another result object's wait before THIS batch is waited for; its own wait must still return INVALID_ARG — what the synchronous
+    call would have returned — never OK with lists from an unbuilt tree."""
+    import torch
+    from bvh_amd._lib import INVALID_ARG, BvhGpuError
+    from bvh_amd.api import _Hits
+    ctx, tree, dev, rays, keep, ooff, oidx = _setup(eng, orc, n=3000, m=5000)
+    tree.rebuild_async(dev).wait()
+    bad = _chain(3000); bad[1234, 4] = np.nan
+    bad_dev = torch.from_numpy(bad).cuda()
+    h1, h2 = _Hits(ctx), _Hits(ctx)
+    tree.rebuild_async(bad_dev)
+    tree.traverse_async(rays, h1)
+    if consumer == "tree_wait":
+        with pytest.raises(BvhGpuError) as e:
+            tree.wait()
+        assert e.value.status == INVALID_ARG
+    elif consumer == "rebuild_good":
+        tree.rebuild_async(dev)                   # swallows the bad generation's outcome: everything is rebuilt
+    else:
+        tree.traverse_async(rays, h2)
+        with pytest.raises(BvhGpuError) as e:
+            h2.wait()
+        assert e.value.status == INVALID_ARG
+    with pytest.raises(BvhGpuError) as e:
+        h1.wait()
+    assert e.value.status == INVALID_ARG and "bvh_node.rs:214-217" in str(e.value)
+    # and everything is still usable
+    tree.rebuild_async(dev)
+    tree.traverse_async(rays, h1)
+    assert h1.wait()["hits"] == len(oidx)
+    off, idx = h1.fetch(rays.n)
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+
+
 def test_fetch_before_wait_is_refused(eng, orc):
     from bvh_amd._lib import INVALID_ARG, BvhGpuError
     from bvh_amd.api import _Hits

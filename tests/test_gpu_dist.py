@@ -88,3 +88,48 @@ def test_bench_two_ranks_one_gpu(scene_dist):
     flat = orc.flatten(orc.build(aabbs).nodes)
     off, idx, _, _ = orc.traverse_flat(flat, aabbs, orc.create_rays(0, R if strong else 2 * R))
     assert out["hits_all_ranks"] == len(idx)
+
+
+def test_bench_launches_its_own_ranks():
+    """plain `python bench.py --gpus 2 …` with NO launcher in the environment starts two ranks itself (it used to run
+    one and print n_gpus = 1).  Two ranks share cuda:0 over gloo here; on a node the same command runs one rank per GPU over RCCL."""
+    import bvh_amd
+    if bvh_amd.device_count() <= 0:
+        pytest.fail("GPU test selected but no HIP device is visible (no CPU fallback exists)")
+    cubes, R = 2000, 60_000
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--cubes", str(cubes),
+           "--rays", str(R), "--backend", "gloo", "--one-device", "--no-extra"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["launch"]["ranks_seen"] == 2 and out["launch"]["self_launched"] is True
+    assert out["launch"]["world_size"] == 2 and len(out["launch"]["devices"]) == 2
+    assert out["rccl"] is None                    # gloo: no RCCL communicator (RCCL refuses two ranks on one GPU) — and the line says so
+    assert out["config"]["rays_total"] == 2 * R and out["parity"]["equal"] is True
+    # --gpus 2 under a launcher that made 1 or 3 ranks: refused, nothing printed
+    for ws in ("1", "3"):
+        bad = subprocess.run(cmd, env=dict(env, WORLD_SIZE=ws, RANK="0", LOCAL_RANK="0"), cwd=ROOT, capture_output=True, text=True, timeout=120)
+        assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_rccl_info_names_the_one_rccl_of_the_process():
+    """bvhgpu_rccl_info names the RCCL the C ABI resolved (the copy torch already holds must be shared, not a second one),
+    and a communicator reports its own size."""
+    import bvh_amd
+    from bvh_amd import Context, dist as bdist
+    if bvh_amd.device_count() <= 0:
+        pytest.fail("GPU test selected but no HIP device is visible (no CPU fallback exists)")
+    import torch  # noqa: F401  (bvh_amd loads torch first when it is installed: its bundled librccl is the one to share)
+    info = bdist.rccl_info()
+    assert info["library"] and "rccl" in info["library"].lower(), info
+    assert info["version_code"] >= 20000, info
+    mapped = {os.path.realpath(ln.split()[-1]) for ln in open("/proc/self/maps") if "librccl" in ln}
+    assert len(mapped) == 1 and os.path.realpath(info["library"]) in mapped, (mapped, info)     # ONE RCCL in the process
+    ctx = Context(0)
+    comm = bdist.Communicator(ctx, 1, 0, bdist.Communicator.unique_id())
+    ci = comm.info()
+    assert (ci["nranks"], ci["first_rank"], ci["n_local"]) == (1, 0, 1) and ci["version"] == info["version"]
+    comm.close()
