@@ -329,12 +329,13 @@ def run_workload(wl, args, env, steps, warmup, detailed):
     ctx.enable_timing(True)
     builder = plan not in ("bcast", "bcast-torch") or rank == 0
     tree = bvh if builder else state["peer"]
-    ph = dict(build_ms=[], flatten_ms=[], traverse_kernel_ms=[], traverse_total_ms=[])
+    ph = dict(build_ms=[], flatten_ms=[], traverse_kernel_ms=[], traverse_total_ms=[], ray_convert_ms=[])
+    stats_walk = 0
     for _ in range(max(5, min(steps, 20))):
         if builder:
             bvh.rebuild(aabbs)
             bvh.flatten_in_place()
-        tree.traverse_batch(rays, fetch=False, coherent=wl.coherent)
+        stats_walk = tree.traverse_batch(rays, fetch=False, coherent=wl.coherent)[3].get("walk", 0)
         t = ctx.last_timings()
         for k in ph:
             ph[k].append(t[k])
@@ -372,13 +373,12 @@ def run_workload(wl, args, env, steps, warmup, detailed):
         kern_name = f"bvhgpu::k_traverse_wide<{ctype}, 0, {2 if R < N_CU * 2048 * 4 else 0},"
     else:
         kern_name = f"bvhgpu::k_traverse<{ctype}, 0"
-    pmc, src = newest_bound(kern_name, wl.name, wl.dtype_name, R)
-    if wl.dtype_name == "f64" and R >= 16384:   # an f64 index batch is walked by the f32 kernel over the tree's guide boxes (template flag GUIDE = 1)
+    from bvh_amd._lib import WALK_F64_GUIDE
+    guide_ran = bool(stats_walk & WALK_F64_GUIDE)   # bvhgpu_hits_walk_info of the timed batch shape: which kernel walked it
+    if guide_ran:   # an f64 index batch walked by the f32 kernel over the tree's guide boxes (template flag GUIDE = 1)
         items = 2 if R < N_CU * 2048 * 4 else 0
-        g_name = f"bvhgpu::k_traverse_wide<float, 0, {items}, 1024, 8, 1>"
-        g_pmc, g_src = newest_bound(g_name, wl.name, wl.dtype_name, R)
-        if g_pmc is not None and (src is None or g_src >= src):   # (the newer profile round says which walk the library runs)
-            kern_name, pmc, src = g_name, g_pmc, g_src
+        kern_name = f"bvhgpu::k_traverse_wide<float, 0, {items}, 1024, 8, 1>"
+    pmc, src = newest_bound(kern_name, wl.name, wl.dtype_name, R)
     roof = {
         "kernel": kern_name.rstrip("<,"), "kernel_ms": round(phases["traverse_kernel_ms"], 4),
         "algorithmic_bytes_per_launch": int(algo_bytes),
@@ -387,6 +387,10 @@ def run_workload(wl, args, env, steps, warmup, detailed):
                             "exceeds what HBM delivers and is NOT the roofline fraction — `frac` is",
         "slab_tests_per_s": round(V / kern_s, 1), "visited": int(V), "leaf_visits": int(VL), "hits": int(H),
     }
+    if wl.dtype_name == "f64":
+        roof["f64_walk"] = ("guide: inner-node tests in f32 on boxes that contain the f64 ones, every leaf candidate decided by the f64 slab test "
+                            "(kernel_ms excludes the f32 ray copy, phases_ms.ray_convert_ms)" if guide_ran else
+                            "pure f64: every slab test of the walk in double precision (BVHGPU_TUNE_WIDE_F64_GUIDE = 0)")
     if pmc is not None:
         fr = bound_fractions(pmc, kern_s)
         bound = max(fr, key=fr.get)
@@ -660,6 +664,18 @@ def main():
                 if rank == 0 and not args.no_parity:
                     from oracle import orc
                     r2["parity"] = check_parity(w2, env, orc, min(w2.R, args.parity_max_rays))
+                if dt == "f64":
+                    # the same step with EVERY slab test of the walk in double precision (BASELINE configs[4] names "double-precision slab
+                    # test"): k_traverse_wide<double, …>, its own timing, roofline (its own counter passes when profiles/ holds them) and parity
+                    from bvh_amd._lib import TUNE_WIDE_F64_GUIDE
+                    ctx.set_tuning(TUNE_WIDE_F64_GUIDE, 0)
+                    try:
+                        r3 = run_workload(w2, args, env, args.extra_steps, 3, detailed=False)
+                        if rank == 0 and not args.no_parity:
+                            r3["parity"] = check_parity(w2, env, orc, min(w2.R, args.parity_max_rays))
+                        r2["pure_f64_walk"] = {k: r3[k] for k in ("value", "unit", "ms_per_step", "steps", "phases_ms", "hits_all_ranks", "roofline", "parity") if k in r3}
+                    finally:
+                        ctx.set_tuning(TUNE_WIDE_F64_GUIDE, 1)
                 extras.append(r2)
                 del w2
                 torch.cuda.empty_cache()

@@ -984,6 +984,8 @@ int bvhgpu_last_timings(bvhgpu_ctx* ctx, bvhgpu_timings* out) {
             // (ev[7]: behind the f32 ray copy of an f64 guide walk — the copy counts towards the total, not towards the walk kernel)
             (void)hipEventElapsedTime(&ctx->last.traverse_kernel_ms, (ctx->ev_set & 8u) ? ctx->ev[7] : ctx->ev[4], ctx->ev[5]);
             (void)hipEventElapsedTime(&ctx->last.traverse_total_ms, ctx->ev[4], ctx->ev[6]);
+            ctx->last.ray_convert_ms = 0.0f;
+            if (ctx->ev_set & 8u) (void)hipEventElapsedTime(&ctx->last.ray_convert_ms, ctx->ev[4], ctx->ev[7]);
         }
         *out = ctx->last;
         return (int)BVHGPU_OK;

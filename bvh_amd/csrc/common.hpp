@@ -147,8 +147,16 @@ static_assert(sizeof(WideNode<double>) == 256, "wide f64");
 // the round-to-nearest f32 ray passes whenever the f64 test on the f64 box does: every f32 rounding (origin, inverse direction,
 // difference, product) moves a plane's t by less than |inv_k| * 2^-21 * (S + |o_k|), the growth moves it by |inv_k| * 2^-18 * S the other way
 // (tests/test_guide_cpu.py replays the argument numerically on grazing rays).  Rays outside the range are never walked this way.
+// Worst case, every rounding adversarial (o32 by 2^-24 * 3S, the difference, 1/d and the product by 2^-24 each of a quantity <= 4S(1 + 2^-18)):
+// the near plane's t moves the wrong way by less than |inv_k| * 15 * 2^-24 * S against a growth of |inv_k| * 64 * 2^-24 * S — a factor 4.2;
+// tests/test_guide_cpu.py checks it with DIRECTED roundings (1 ulp each instead of 1/2: 30 against 64) at the edges of the range.
 constexpr double GUIDE_GROW = 1.0 / 262144.0;   // 2^-18
 constexpr double GUIDE_ORIGIN_MAX = 3.0;
+constexpr double GUIDE_SCENE_MIN = 0x1p-125;               // smallest S the argument covers (f32 denormal spacing is 2^-149)
+constexpr double GUIDE_SCENE_MAX = 0x1p125;                // largest: a difference b32 - o32 reaches 4 S (1 + 2^-18) and must stay finite in f32
+                                                           // (found by the directed-rounding test: at S = 0.999 FLT_MAX it overflowed to inf)
+constexpr double GUIDE_F32_MAX = 0x1.fffffep127;           // FLT_MAX
+constexpr double GUIDE_F32_MIN_NORMAL = 0x1p-126;          // FLT_MIN
 __host__ __device__ inline float f32_below(double x) {   // largest float <= x (NaN stays NaN)
     float f = (float)x;
     if ((double)f > x) {

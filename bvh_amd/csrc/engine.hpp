@@ -51,7 +51,7 @@ struct bvhgpu_ctx {
     bool timing = false;
     hipEvent_t ev[8] = {};
     unsigned ev_set = 0;  // bit0 build pair recorded, bit1 flatten, bit2 traverse
-    bvhgpu_timings last = {0, 0, 0, 0};
+    bvhgpu_timings last = {0, 0, 0, 0, 0};
     // scratch
     bvhgpu::DevBuf upload;    // staging for host→device inputs (aabbs / rays)
     bvhgpu::DevBuf counters;  // small device counters

@@ -994,11 +994,18 @@ __global__ __launch_bounds__(256) void k_guide_rays(const bvhgpu_ray_f64* __rest
         const double S = (double)guide_info[0];
         const bvhgpu_ray_f64 q = in[r];
         bvhgpu_ray_f32 o;
+        // The containment argument prices every f32 rounding at 2^-24 RELATIVE: that needs every quantity on the way to a plane's t in the
+        // NORMAL f32 range.  S >= 2^-125 keeps the growth 2^-18 S at 64+ denormal spacings (a smaller scene's coordinates round by up to
+        // 2^-150 absolutely, more than the growth covers); |1/d| must itself be a normal, finite f32 (the scale-relative
+        // test alone lets (float)inv overflow to inf on a very small scene, or underflow on a huge one, unflagged); |o| must fit f32;
+        // S <= 2^125 keeps every difference b32 - o32 (up to 4 S) finite.
+        bad = !(S >= GUIDE_SCENE_MIN) || !(S <= GUIDE_SCENE_MAX);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const double ao = fabs(q.o[k]), ai = fabs(q.inv[k]) * (4.0 * S);
+            const double ao = fabs(q.o[k]), ainv = fabs(q.inv[k]), ai = ainv * (4.0 * S);
             // (NaN fails every comparison; S = 0 — a scene that is one point — leaves no room for the growth)
-            bad = bad || !(ao <= GUIDE_ORIGIN_MAX * S) || !(ai <= 0x1p100) || !(ai >= 0x1p-100);
+            bad = bad || !(ao <= GUIDE_ORIGIN_MAX * S) || !(ao <= GUIDE_F32_MAX) || !(ai <= 0x1p100) || !(ai >= 0x1p-100) ||
+                  !(ainv <= GUIDE_F32_MAX) || !(ainv >= GUIDE_F32_MIN_NORMAL);
             o.o[k] = (float)q.o[k]; o.d[k] = (float)q.d[k]; o.inv[k] = (float)q.inv[k];
         }
         out[r] = o;

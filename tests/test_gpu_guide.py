@@ -140,3 +140,28 @@ def test_guide_boxes_follow_refit_and_scene_import(eng, orc):
     assert not st2["walk"] & WALK_F64_GUIDE and np.array_equal(off, off2) and np.array_equal(idx, idx2)
     ooff2, oidx2, _, _ = orc.traverse_flat(oflat, moved, rays2, threads=orc.max_threads())
     assert np.array_equal(off, ooff2) and np.array_equal(idx, oidx2)
+
+
+@pytest.mark.parametrize("log2_s,log2_inv,guide", [(-124, 30, True), (-101, 0, True), (0, 0, True), (90, -40, True), (124, -90, True),
+                                                   (-130, 40, False), (126, -90, False), (-60, 130, False), (100, -140, False)])
+def test_guide_walk_at_the_edges_of_its_range(eng, orc, log2_s, log2_inv, guide):
+    """VERDICT r3 #6 / ADVICE r3: scenes scaled to the smallest and largest S the containment argument covers (2^-125 .. 2^125, f32 denormal
+    coordinates below that), raw rays whose 1/d is scaled so that 4 S |1/d| sits inside 2^+-100 — the guide walk runs and its lists are
+    the f64 oracle's; one step outside (S too small / too large, (float)(1/d) = inf or denormal) and the batch is replayed in f64."""
+    from bvh_amd._lib import RAY_F64, WALK_F64_GUIDE, WALK_WIDE
+    unit = _cubes64(800)
+    unit = unit / np.abs(unit).max()                                         # largest |coordinate| = 1
+    S = 2.0 ** log2_s
+    aabbs = unit * S
+    assert np.all(np.isfinite(aabbs)) and np.abs(aabbs).max() == S
+    g = _grazing_rays(orc, unit, 30_000, 5 + log2_s)
+    rays = np.zeros(len(g), RAY_F64)
+    rays["o"] = g["o"] * S                                                   # (exact: a power of two)
+    rays["d"] = g["d"]
+    rays["inv"] = g["inv"] * 2.0 ** log2_inv                                 # an unnormalised direction: every t scales alike, the hit set is the same
+    flat = eng.Bvh.from_aabbs(aabbs).flatten()
+    ooff, oidx = _oracle(orc, aabbs, rays)
+    assert len(oidx) > len(rays) // 2                                        # grazing rays: the corner cases are hits
+    off, idx, st = _csr(eng, flat, rays)
+    assert st["walk"] & WALK_WIDE and bool(st["walk"] & WALK_F64_GUIDE) == guide
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
