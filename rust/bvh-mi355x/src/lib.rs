@@ -1,21 +1,31 @@
-//! `GpuBvh`: the `bvh` crate's `BoundingHierarchy` (src/bounding_hierarchy.rs:89-336) on an MI355X, over the C ABI of
-//! libbvh_mi355x.so (include/bvh_mi355x.h).  Build / flatten / batched traversal run on the GPU and give the arrays the
-//! crate's own `Bvh::build` + `Bvh::flatten` + `FlatBvh::traverse` give, bit for bit; queries that need
-//! user callbacks (`IntersectsAabb` for anything but rays, arbitrary `PointDistance`) run the crate's own loops over the
-//! downloaded flat array.
+//! `GpuBvh<T>`: the `bvh` crate's `BoundingHierarchy<T, 3>` (src/bounding_hierarchy.rs:89-336) on an MI355X, for `T = f32`
+//! and `T = f64`, over the C ABI of libbvh_mi355x.so (include/bvh_mi355x.h).  Build / flatten / batched traversal run on the
+//! GPU and give the arrays the crate's own `Bvh::build` + `Bvh::flatten` + `FlatBvh::traverse` give, bit for bit (see
+//! DESIGN.md §2); queries that need user callbacks (`IntersectsAabb` for anything but rays, arbitrary `PointDistance`) run the
+//! crate's own loops over the downloaded flat array.
+//!
+//! The scalar type is a sealed trait (`GpuScalar`, implemented for `f32` and `f64` only — the two instantiations the
+//! engine has): it names the `#[repr(C)]` images of `BvhNode` / `FlatNode` / `Ray` for that type and the `_f32` / `_f64` entry
+//! points, so that `GpuBvh<T>` is written once.  `GpuBvh32` / `GpuBvh64` are the two aliases.
+//!
+//! Which GPU: `GpuBvh::from_aabbs(aabbs, device)` takes it explicitly; the trait's `build` (whose signature the crate fixes
+//! and has no room for it) uses `default_device()`, a process-wide setting (`set_default_device`; initial value 0, or
+//! `BVH_MI355X_DEVICE` from the environment).  Every `GpuBvh` remembers its device (`device()`).
 //!
 //! NOTE: written against bvh 0.12.0 / nalgebra 0.34 by reading their sources; the image this engine was developed in has
-//! no cargo/rustc, so this crate has NOT been compiled there.
+//! no cargo/rustc, so this crate has NOT been compiled there.  tests/test_abi_cpu.py checks every `extern "C"` declaration
+//! of ffi.rs against the header (names, argument counts, argument and return types) on every CPU run.
 #![allow(clippy::missing_safety_doc)]
 pub mod ffi;
 
 use bvh::aabb::{Aabb, IntersectsAabb};
-use bvh::bounding_hierarchy::{BHShape, BoundingHierarchy};
+use bvh::bounding_hierarchy::{BHShape, BHValue, BoundingHierarchy};
 use bvh::bvh::{Bvh, BvhNode, BvhNodeBuildArgs};
 use bvh::flat_bvh::{FlatBvh, FlatNode};
 use bvh::point_query::PointDistance;
-use bvh::ray::Ray;
-use core::ffi::c_int;
+use bvh::ray::{Intersection, Ray};
+use core::ffi::{c_int, c_uint, c_void};
+use core::sync::atomic::{AtomicI32, Ordering};
 use nalgebra::{Point3, Vector3};
 
 /// Panics with the engine's message: the crate has no error type, contract violations panic there too
@@ -27,65 +37,83 @@ fn check(ctx: *const ffi::bvhgpu_ctx, rc: c_int) {
     }
 }
 
-fn aabb_to_6(b: &Aabb<f32, 3>) -> [f32; 6] {
-    [b.min.x, b.min.y, b.min.z, b.max.x, b.max.y, b.max.z]
-}
+static DEFAULT_DEVICE: AtomicI32 = AtomicI32::new(-1);
 
-pub fn ray_to_ffi(r: &Ray<f32, 3>) -> ffi::bvhgpu_ray_f32 {
-    // Ray { origin, direction, inv_direction } (src/ray/ray_impl.rs:17-29): copied field by field, never transmuted
-    ffi::bvhgpu_ray_f32 {
-        o: [r.origin.x, r.origin.y, r.origin.z],
-        d: [r.direction.x, r.direction.y, r.direction.z],
-        inv: [r.inv_direction.x, r.inv_direction.y, r.inv_direction.z],
+/// The GPU the trait's `build` / `build_par` use (their signatures are the crate's and carry no device argument).
+pub fn default_device() -> i32 {
+    let d = DEFAULT_DEVICE.load(Ordering::Relaxed);
+    if d >= 0 {
+        return d;
     }
+    std::env::var("BVH_MI355X_DEVICE").ok().and_then(|s| s.parse().ok()).unwrap_or(0)
+}
+/// One process per GPU: call this once with the local rank before the first `build`.
+pub fn set_default_device(device: i32) {
+    DEFAULT_DEVICE.store(device, Ordering::Relaxed);
+}
+/// Number of MI355X devices the engine sees (0 ⇒ every call fails with `BVHGPU_NO_DEVICE`: there is no CPU fallback)
+pub fn device_count() -> i32 {
+    let mut n: c_int = 0;
+    unsafe { ffi::bvhgpu_device_count(&mut n) };
+    n
 }
 
-pub struct GpuBvh {
-    ctx: *mut ffi::bvhgpu_ctx,
-    tree: *mut ffi::bvhgpu_tree,
-    n_shapes: usize,
-    /// CPU copy of the flat array in the crate's own layout, for the generic queries of the trait
-    flat: FlatBvh<f32, 3>,
+mod sealed {
+    pub trait Sealed {}
+    impl Sealed for f32 {}
+    impl Sealed for f64 {}
 }
 
-// the handles are only used through &self / &mut self; the engine's ctx is not internally locked: one GpuBvh per thread
-unsafe impl Send for GpuBvh {}
+/// The two scalar types the engine is instantiated for.  Everything type-dependent at the boundary lives here.
+pub trait GpuScalar: BHValue + sealed::Sealed + Default + 'static {
+    /// `#[repr(C)]` image of `enum BvhNode<T,3>` (src/bvh/bvh_node.rs:21-47)
+    type Node: Copy + Default;
+    /// `#[repr(C)]` image of `struct FlatNode<T,3>` (src/flat_bvh.rs:17-46)
+    type Flat: Copy + Default;
+    /// `#[repr(C)]` image of `struct Ray<T,3>` (src/ray/ray_impl.rs:17-29)
+    type RayC: Copy + Default;
+    const DTYPE: c_int;
 
-/// CSR result of a batch: ray i hit `indices[offsets[i]..offsets[i+1]]`, in the order `FlatBvh::traverse` returns them
-pub struct BatchHits {
-    pub offsets: Vec<u32>,
-    pub indices: Vec<u32>,
+    unsafe fn build_flat(ctx: *mut ffi::bvhgpu_ctx, aabbs: *const Self, n: usize, mem: c_int, out: *mut *mut ffi::bvhgpu_tree) -> c_int;
+    unsafe fn rebuild_flat(t: *mut ffi::bvhgpu_tree, aabbs: *const Self, n: usize, mem: c_int) -> c_int;
+    unsafe fn refit(t: *mut ffi::bvhgpu_tree, aabbs: *const Self, n: usize, mem: c_int) -> c_int;
+    unsafe fn traverse(t: *mut ffi::bvhgpu_tree, rays: *const Self::RayC, n: usize, mem: c_int, flags: c_uint, hits: *mut *mut ffi::bvhgpu_hits) -> c_int;
+    unsafe fn set_triangles(t: *mut ffi::bvhgpu_tree, verts: *const Self, n: usize, mem: c_int) -> c_int;
+    unsafe fn tree_from_flat(ctx: *mut ffi::bvhgpu_ctx, flat: *const Self::Flat, n_flat: usize, shape_aabbs: *const Self, n: usize, out: *mut *mut ffi::bvhgpu_tree) -> c_int;
+
+    fn node_to_crate(raw: &Self::Node) -> BvhNode<Self, 3>;
+    fn flat_to_crate(raw: &Self::Flat) -> FlatNode<Self, 3>;
+    fn flat_from_parts(aabb: &Aabb<Self, 3>, entry: u32, exit: u32, shape: u32) -> Self::Flat;
+    fn ray_to_ffi(r: &Ray<Self, 3>) -> Self::RayC;
 }
 
-impl GpuBvh {
-    /// Bvh::build_par + Bvh::flatten on the GPU from the shapes' AABBs (n x [min xyz, max xyz])
-    pub fn from_aabbs(aabbs: &[[f32; 6]], device: i32) -> GpuBvh {
-        let mut ctx = core::ptr::null_mut();
-        let mut tree = core::ptr::null_mut();
-        unsafe {
-            check(ctx, ffi::bvhgpu_create(device, core::ptr::null_mut(), &mut ctx));
-            check(ctx, ffi::bvhgpu_build_flat_f32(ctx, aabbs.as_ptr().cast(), aabbs.len(), ffi::BVHGPU_HOST, &mut tree));
-        }
-        let mut me = GpuBvh { ctx, tree, n_shapes: aabbs.len(), flat: Vec::new() };
-        me.flat = me.download_flat();
-        me
-    }
-
-    /// the argument of `BHShape::set_bh_node_index` for every shape (src/bvh/bvh_node.rs:102)
-    pub fn shape_nodes(&self) -> Vec<u32> {
-        let mut sn = vec![0u32; self.n_shapes];
-        unsafe { check(self.ctx, ffi::bvhgpu_tree_shape_nodes(self.tree, sn.as_mut_ptr(), ffi::BVHGPU_HOST)); }
-        sn
-    }
-
-    /// `Vec<BvhNode>` exactly as `Bvh::build` produces it (bit-identical AABBs, same indices)
-    pub fn to_bvh(&self) -> Bvh<f32, 3> {
-        let nn = if self.n_shapes == 0 { 0 } else { 2 * self.n_shapes - 1 };
-        let mut raw = vec![ffi::bvhgpu_node_f32::default(); nn];
-        unsafe { check(self.ctx, ffi::bvhgpu_tree_nodes(self.tree, raw.as_mut_ptr().cast(), ffi::BVHGPU_HOST)); }
-        let nodes = raw
-            .iter()
-            .map(|r| {
+macro_rules! impl_gpu_scalar {
+    ($t:ty, $dtype:expr, $node:ident, $flat:ident, $ray:ident, $build_flat:ident, $rebuild_flat:ident, $refit:ident, $traverse:ident,
+     $set_tris:ident, $from_flat:ident, $flat_ctor:expr) => {
+        impl GpuScalar for $t {
+            type Node = ffi::$node;
+            type Flat = ffi::$flat;
+            type RayC = ffi::$ray;
+            const DTYPE: c_int = $dtype;
+            unsafe fn build_flat(ctx: *mut ffi::bvhgpu_ctx, aabbs: *const $t, n: usize, mem: c_int, out: *mut *mut ffi::bvhgpu_tree) -> c_int {
+                ffi::$build_flat(ctx, aabbs, n, mem, out)
+            }
+            unsafe fn rebuild_flat(t: *mut ffi::bvhgpu_tree, aabbs: *const $t, n: usize, mem: c_int) -> c_int {
+                ffi::$rebuild_flat(t, aabbs, n, mem)
+            }
+            unsafe fn refit(t: *mut ffi::bvhgpu_tree, aabbs: *const $t, n: usize, mem: c_int) -> c_int {
+                ffi::$refit(t, aabbs, n, mem)
+            }
+            unsafe fn traverse(t: *mut ffi::bvhgpu_tree, rays: *const ffi::$ray, n: usize, mem: c_int, flags: c_uint, hits: *mut *mut ffi::bvhgpu_hits) -> c_int {
+                ffi::$traverse(t, rays, n, mem, flags, hits)
+            }
+            unsafe fn set_triangles(t: *mut ffi::bvhgpu_tree, verts: *const $t, n: usize, mem: c_int) -> c_int {
+                ffi::$set_tris(t, verts, n, mem)
+            }
+            unsafe fn tree_from_flat(ctx: *mut ffi::bvhgpu_ctx, flat: *const ffi::$flat, n_flat: usize, shape_aabbs: *const $t, n: usize, out: *mut *mut ffi::bvhgpu_tree) -> c_int {
+                ffi::$from_flat(ctx, flat, n_flat, shape_aabbs, n, out)
+            }
+            fn node_to_crate(r: &ffi::$node) -> BvhNode<$t, 3> {
                 if r.shape != ffi::BVHGPU_NONE {
                     BvhNode::Leaf { parent_index: r.parent as usize, shape_index: r.shape as usize }
                 } else {
@@ -97,32 +125,123 @@ impl GpuBvh {
                         child_r_aabb: Aabb::with_bounds(Point3::from(r.r_min), Point3::from(r.r_max)),
                     }
                 }
-            })
-            .collect();
-        Bvh { nodes }
+            }
+            fn flat_to_crate(f: &ffi::$flat) -> FlatNode<$t, 3> {
+                FlatNode {
+                    aabb: Aabb::with_bounds(Point3::from(f.min), Point3::from(f.max)),
+                    entry_index: f.entry,
+                    exit_index: f.exit,
+                    shape_index: f.shape,
+                }
+            }
+            fn flat_from_parts(aabb: &Aabb<$t, 3>, entry: u32, exit: u32, shape: u32) -> ffi::$flat {
+                let ctor: fn([$t; 3], [$t; 3], u32, u32, u32) -> ffi::$flat = $flat_ctor;
+                ctor([aabb.min.x, aabb.min.y, aabb.min.z], [aabb.max.x, aabb.max.y, aabb.max.z], entry, exit, shape)
+            }
+            fn ray_to_ffi(r: &Ray<$t, 3>) -> ffi::$ray {
+                // Ray { origin, direction, inv_direction } (src/ray/ray_impl.rs:17-29): copied field by field, never transmuted
+                ffi::$ray {
+                    o: [r.origin.x, r.origin.y, r.origin.z],
+                    d: [r.direction.x, r.direction.y, r.direction.z],
+                    inv: [r.inv_direction.x, r.inv_direction.y, r.inv_direction.z],
+                }
+            }
+        }
+    };
+}
+impl_gpu_scalar!(f32, ffi::BVHGPU_F32, bvhgpu_node_f32, bvhgpu_flat_f32, bvhgpu_ray_f32, bvhgpu_build_flat_f32, bvhgpu_rebuild_flat_f32,
+                 bvhgpu_refit_f32, bvhgpu_traverse_f32, bvhgpu_tree_set_triangles_f32, bvhgpu_tree_from_flat_f32,
+                 |min, max, entry, exit, shape| ffi::bvhgpu_flat_f32 { min, max, entry, exit, shape });
+impl_gpu_scalar!(f64, ffi::BVHGPU_F64, bvhgpu_node_f64, bvhgpu_flat_f64, bvhgpu_ray_f64, bvhgpu_build_flat_f64, bvhgpu_rebuild_flat_f64,
+                 bvhgpu_refit_f64, bvhgpu_traverse_f64, bvhgpu_tree_set_triangles_f64, bvhgpu_tree_from_flat_f64,
+                 |min, max, entry, exit, shape| ffi::bvhgpu_flat_f64 { min, max, entry, exit, shape, _pad: 0 });
+
+fn aabb_to_6<T: GpuScalar>(b: &Aabb<T, 3>) -> [T; 6] {
+    [b.min.x, b.min.y, b.min.z, b.max.x, b.max.y, b.max.z]
+}
+
+pub fn ray_to_ffi<T: GpuScalar>(r: &Ray<T, 3>) -> T::RayC {
+    T::ray_to_ffi(r)
+}
+
+pub struct GpuBvh<T: GpuScalar> {
+    ctx: *mut ffi::bvhgpu_ctx,
+    tree: *mut ffi::bvhgpu_tree,
+    device: i32,
+    n_shapes: usize,
+    /// CPU copy of the flat array in the crate's own layout, for the generic queries of the trait
+    flat: FlatBvh<T, 3>,
+}
+/// `BoundingHierarchy<f32, 3>` on the GPU (BASELINE configs[1]-[3])
+pub type GpuBvh32 = GpuBvh<f32>;
+/// `BoundingHierarchy<f64, 3>` on the GPU (BASELINE configs[4]: tree, rays and every test that decides a hit in double precision)
+pub type GpuBvh64 = GpuBvh<f64>;
+
+// the handles are only used through &self / &mut self; the engine's ctx is not internally locked: one GpuBvh per thread
+unsafe impl<T: GpuScalar> Send for GpuBvh<T> {}
+
+/// CSR result of a batch: ray i hit `indices[offsets[i]..offsets[i+1]]`, in the order `FlatBvh::traverse` returns them
+pub struct BatchHits {
+    pub offsets: Vec<u32>,
+    pub indices: Vec<u32>,
+}
+
+/// Result of the reference harness' inner loop for one ray (src/testbase.rs:826-836): the nearest
+/// `Ray::intersects_triangle` over the candidates `FlatBvh::traverse` returns; `shape == u32::MAX` and
+/// `distance == +inf` when the ray hits nothing
+pub struct ClosestHit<T> {
+    pub intersection: Intersection<T>,
+    pub shape: u32,
+}
+
+impl<T: GpuScalar> GpuBvh<T> {
+    /// Bvh::build_par + Bvh::flatten on GPU `device` from the shapes' AABBs (n x [min xyz, max xyz])
+    pub fn from_aabbs(aabbs: &[[T; 6]], device: i32) -> GpuBvh<T> {
+        let mut ctx = core::ptr::null_mut();
+        let mut tree = core::ptr::null_mut();
+        unsafe {
+            check(ctx, ffi::bvhgpu_create(device, core::ptr::null_mut(), &mut ctx));
+            check(ctx, T::build_flat(ctx, aabbs.as_ptr().cast(), aabbs.len(), ffi::BVHGPU_HOST, &mut tree));
+        }
+        let mut me = GpuBvh { ctx, tree, device, n_shapes: aabbs.len(), flat: Vec::new() };
+        me.flat = me.download_flat();
+        me
     }
 
-    fn download_flat(&self) -> FlatBvh<f32, 3> {
+    /// the GPU this hierarchy lives on
+    pub fn device(&self) -> i32 {
+        self.device
+    }
+
+    /// the argument of `BHShape::set_bh_node_index` for every shape (src/bvh/bvh_node.rs:102)
+    pub fn shape_nodes(&self) -> Vec<u32> {
+        let mut sn = vec![0u32; self.n_shapes];
+        unsafe { check(self.ctx, ffi::bvhgpu_tree_shape_nodes(self.tree, sn.as_mut_ptr(), ffi::BVHGPU_HOST)); }
+        sn
+    }
+
+    /// `Vec<BvhNode>` exactly as `Bvh::build` produces it (bit-identical AABBs, same indices)
+    pub fn to_bvh(&self) -> Bvh<T, 3> {
+        let nn = if self.n_shapes == 0 { 0 } else { 2 * self.n_shapes - 1 };
+        let mut raw = vec![T::Node::default(); nn];
+        unsafe { check(self.ctx, ffi::bvhgpu_tree_nodes(self.tree, raw.as_mut_ptr().cast(), ffi::BVHGPU_HOST)); }
+        Bvh { nodes: raw.iter().map(T::node_to_crate).collect() }
+    }
+
+    fn download_flat(&self) -> FlatBvh<T, 3> {
         let nf = if self.n_shapes >= 2 { 3 * self.n_shapes - 2 } else { self.n_shapes };
-        let mut raw = vec![ffi::bvhgpu_flat_f32::default(); nf];
+        let mut raw = vec![T::Flat::default(); nf];
         unsafe { check(self.ctx, ffi::bvhgpu_flat_nodes(self.tree, raw.as_mut_ptr().cast(), ffi::BVHGPU_HOST)); }
-        raw.iter()
-            .map(|f| FlatNode {
-                aabb: Aabb::with_bounds(Point3::from(f.min), Point3::from(f.max)),
-                entry_index: f.entry,
-                exit_index: f.exit,
-                shape_index: f.shape,
-            })
-            .collect()
+        raw.iter().map(T::flat_to_crate).collect()
     }
 
     /// `FlatBvh::traverse` (src/flat_bvh.rs:396-431) for many rays at once — what the GPU is for
-    pub fn traverse_batch(&self, rays: &[Ray<f32, 3>]) -> BatchHits {
-        let r: Vec<ffi::bvhgpu_ray_f32> = rays.iter().map(ray_to_ffi).collect();
+    pub fn traverse_batch(&self, rays: &[Ray<T, 3>]) -> BatchHits {
+        let r: Vec<T::RayC> = rays.iter().map(T::ray_to_ffi).collect();
         let mut hits = core::ptr::null_mut();
         let mut total = 0u64;
         unsafe {
-            check(self.ctx, ffi::bvhgpu_traverse_f32(self.tree, r.as_ptr(), r.len(), ffi::BVHGPU_HOST, 0, &mut hits));
+            check(self.ctx, T::traverse(self.tree, r.as_ptr(), r.len(), ffi::BVHGPU_HOST, 0, &mut hits));
             check(self.ctx, ffi::bvhgpu_hits_info(hits, core::ptr::null_mut(), &mut total, core::ptr::null_mut()));
         }
         let (mut offsets, mut indices) = (vec![0u32; rays.len() + 1], vec![0u32; total as usize]);
@@ -133,9 +252,38 @@ impl GpuBvh {
         BatchHits { offsets, indices }
     }
 
+    /// The triangle stage needs the vertices (one triangle per shape, n x [a xyz, b xyz, c xyz]): src/testbase.rs:325-333
+    pub fn set_triangles(&mut self, verts: &[[T; 9]]) {
+        assert_eq!(verts.len(), self.n_shapes, "one triangle per shape");
+        unsafe { check(self.ctx, T::set_triangles(self.tree, verts.as_ptr().cast(), verts.len(), ffi::BVHGPU_HOST)); }
+    }
+
+    /// The harness loop of the reference's benches for a whole batch (src/testbase.rs:826-836): per ray, `FlatBvh::traverse` then
+    /// `Ray::intersects_triangle` (src/ray/ray_impl.rs:154-213) on every candidate, keeping the nearest — fused into the walk on
+    /// the GPU (`BVHGPU_TRAVERSE_CLOSEST`).  Needs `set_triangles`.
+    pub fn traverse_closest(&self, rays: &[Ray<T, 3>]) -> Vec<ClosestHit<T>> {
+        let r: Vec<T::RayC> = rays.iter().map(T::ray_to_ffi).collect();
+        let mut hits = core::ptr::null_mut();
+        let mut isect = vec![[T::default(); 3]; rays.len()];
+        let mut shape = vec![0u32; rays.len()];
+        unsafe {
+            check(self.ctx, T::traverse(self.tree, r.as_ptr(), r.len(), ffi::BVHGPU_HOST, ffi::BVHGPU_TRAVERSE_CLOSEST, &mut hits));
+            check(self.ctx, ffi::bvhgpu_hits_fetch_closest(hits, isect.as_mut_ptr() as *mut c_void, shape.as_mut_ptr(), ffi::BVHGPU_HOST));
+            ffi::bvhgpu_hits_destroy(hits);
+        }
+        isect.iter().zip(shape).map(|(i, s)| ClosestHit { intersection: Intersection::new(i[0], i[1], i[2]), shape: s }).collect()
+    }
+
+    /// Build again from new AABBs into the same device buffers (a frame loop: no allocation in the steady state)
+    pub fn rebuild(&mut self, aabbs: &[[T; 6]]) {
+        unsafe { check(self.ctx, T::rebuild_flat(self.tree, aabbs.as_ptr().cast(), aabbs.len(), ffi::BVHGPU_HOST)); }
+        self.n_shapes = aabbs.len();
+        self.flat = self.download_flat();
+    }
+
     /// the shapes moved, the topology stays: `Bvh::fix_aabbs_ascending` (src/bvh/optimization.rs:355-391) over the whole tree
-    pub fn refit(&mut self, aabbs: &[[f32; 6]]) {
-        unsafe { check(self.ctx, ffi::bvhgpu_refit_f32(self.tree, aabbs.as_ptr().cast(), aabbs.len(), ffi::BVHGPU_HOST)); }
+    pub fn refit(&mut self, aabbs: &[[T; 6]]) {
+        unsafe { check(self.ctx, T::refit(self.tree, aabbs.as_ptr().cast(), aabbs.len(), ffi::BVHGPU_HOST)); }
         self.flat = self.download_flat();
     }
 
@@ -144,12 +292,12 @@ impl GpuBvh {
     }
 }
 
-impl BoundingHierarchy<f32, 3> for GpuBvh {
-    fn build<Shape: BHShape<f32, 3>>(shapes: &mut [Shape]) -> GpuBvh {
+impl<T: GpuScalar> BoundingHierarchy<T, 3> for GpuBvh<T> {
+    fn build<Shape: BHShape<T, 3>>(shapes: &mut [Shape]) -> GpuBvh<T> {
         // (1) the only callback the device cannot make: shape.aabb(), gathered once per shape
-        let aabbs: Vec<[f32; 6]> = shapes.iter().map(|s| aabb_to_6(&s.aabb())).collect();
-        // (2) Bvh::build_par + Bvh::flatten on the GPU
-        let bh = GpuBvh::from_aabbs(&aabbs, 0);
+        let aabbs: Vec<[T; 6]> = shapes.iter().map(|s| aabb_to_6(&s.aabb())).collect();
+        // (2) Bvh::build_par + Bvh::flatten on the GPU the process chose (set_default_device)
+        let bh = GpuBvh::from_aabbs(&aabbs, default_device());
         // (3) set_bh_node_index for every shape (src/bvh/bvh_node.rs:102)
         for (s, ni) in shapes.iter_mut().zip(bh.shape_nodes()) {
             s.set_bh_node_index(ni as usize);
@@ -158,18 +306,18 @@ impl BoundingHierarchy<f32, 3> for GpuBvh {
     }
 
     fn build_with_executor<
-        Shape: BHShape<f32, 3>,
-        Executor: FnMut(BvhNodeBuildArgs<'_, Shape, f32, 3>, BvhNodeBuildArgs<'_, Shape, f32, 3>),
+        Shape: BHShape<T, 3>,
+        Executor: FnMut(BvhNodeBuildArgs<'_, Shape, T, 3>, BvhNodeBuildArgs<'_, Shape, T, 3>),
     >(
         shapes: &mut [Shape],
         _executor: Executor,
-    ) -> GpuBvh {
+    ) -> GpuBvh<T> {
         // the executor only schedules CPU sub-builds and cannot change the result (node placement is arithmetic,
         // src/bvh/bvh_node.rs:138-142): the GPU schedules its own.  `build_par` lands here through the trait's default.
         Self::build(shapes)
     }
 
-    fn traverse<'a, Query: IntersectsAabb<f32, 3>, Shape: BHShape<f32, 3>>(
+    fn traverse<'a, Query: IntersectsAabb<T, 3>, Shape: BHShape<T, 3>>(
         &'a self,
         query: &Query,
         shapes: &'a [Shape],
@@ -179,11 +327,11 @@ impl BoundingHierarchy<f32, 3> for GpuBvh {
         self.flat.traverse(query, shapes)
     }
 
-    fn nearest_to<'a, Shape: BHShape<f32, 3> + PointDistance<f32, 3>>(
+    fn nearest_to<'a, Shape: BHShape<T, 3> + PointDistance<T, 3>>(
         &'a self,
-        query: Point3<f32>,
+        query: Point3<T>,
         shapes: &'a [Shape],
-    ) -> Option<(&'a Shape, f32)> {
+    ) -> Option<(&'a Shape, T)> {
         self.flat.nearest_to(query, shapes)
     }
 
@@ -192,7 +340,7 @@ impl BoundingHierarchy<f32, 3> for GpuBvh {
     }
 }
 
-impl Drop for GpuBvh {
+impl<T: GpuScalar> Drop for GpuBvh<T> {
     fn drop(&mut self) {
         unsafe {
             ffi::bvhgpu_tree_destroy(self.tree);
@@ -203,24 +351,18 @@ impl Drop for GpuBvh {
 
 /// Traverse a crate-built `Bvh` on the GPU: `Bvh::flatten_custom` (src/flat_bvh.rs:240-251) lets the caller choose the node
 /// type, so the `#[repr(C)]` layout of the C ABI needs no change to the crate.
-pub fn upload_flat(bvh: &Bvh<f32, 3>, shape_aabbs: &[[f32; 6]], device: i32) -> (*mut ffi::bvhgpu_ctx, *mut ffi::bvhgpu_tree) {
-    let flat: Vec<ffi::bvhgpu_flat_f32> = bvh.flatten_custom(&|aabb: &Aabb<f32, 3>, entry, exit, shape| ffi::bvhgpu_flat_f32 {
-        min: [aabb.min.x, aabb.min.y, aabb.min.z],
-        max: [aabb.max.x, aabb.max.y, aabb.max.z],
-        entry,
-        exit,
-        shape,
-    });
+pub fn upload_flat<T: GpuScalar>(bvh: &Bvh<T, 3>, shape_aabbs: &[[T; 6]], device: i32) -> (*mut ffi::bvhgpu_ctx, *mut ffi::bvhgpu_tree) {
+    let flat: Vec<T::Flat> = bvh.flatten_custom(&|aabb: &Aabb<T, 3>, entry, exit, shape| T::flat_from_parts(aabb, entry, exit, shape));
     let mut ctx = core::ptr::null_mut();
     let mut tree = core::ptr::null_mut();
     unsafe {
         check(ctx, ffi::bvhgpu_create(device, core::ptr::null_mut(), &mut ctx));
-        check(ctx, ffi::bvhgpu_tree_from_flat_f32(ctx, flat.as_ptr(), flat.len(), shape_aabbs.as_ptr().cast(), shape_aabbs.len(), &mut tree));
+        check(ctx, T::tree_from_flat(ctx, flat.as_ptr(), flat.len(), shape_aabbs.as_ptr().cast(), shape_aabbs.len(), &mut tree));
     }
     (ctx, tree)
 }
 
 /// `Ray::new` (src/ray/ray_impl.rs:70-80) — re-exported so that callers build rays the crate's way
-pub fn ray(origin: [f32; 3], direction: [f32; 3]) -> Ray<f32, 3> {
+pub fn ray<T: GpuScalar>(origin: [T; 3], direction: [T; 3]) -> Ray<T, 3> {
     Ray::new(Point3::from(origin), Vector3::from(direction))
 }

@@ -282,3 +282,133 @@ def test_rccl_is_shared_with_the_process_not_loaded_twice():
     assert len(r["mapped"]) == 1, r
     assert os.path.realpath(r["info"]["library"]) == r["mapped"][0] and r["info"]["shared_with_process"] is True, r
     assert r["info"]["version_code"] >= 20000
+
+
+# ---- the Rust declarations against the header, signature by signature (no cargo here, so this is the check) ----------
+_C_SCALARS = {"int": "c_int", "unsigned": "c_uint", "size_t": "usize", "uint64_t": "u64", "uint32_t": "u32", "float": "f32",
+              "double": "f64", "char": "c_char", "void": "c_void"}
+
+
+def _c_type_to_rust(decl):
+    """`const float *aabbs` / `bvhgpu_tree **out` / `bvhgpu_ctx *const *ctxs` / `const float bounds[6]` → the Rust spelling ffi.rs must use"""
+    decl = " ".join(decl.replace("*", " * ").split())
+    is_array = bool(re.search(r"\[\d*\]$", decl))
+    decl = re.sub(r"\s*\[\d*\]$", "", decl)
+    toks = decl.split()
+    if toks and re.fullmatch(r"[A-Za-z_]\w*", toks[-1]) and toks[-1] not in _C_SCALARS and not toks[-1].startswith("bvhgpu_") and toks[-1] != "const":
+        toks = toks[:-1]                                         # the parameter's name
+    elif len(toks) >= 2 and re.fullmatch(r"[A-Za-z_]\w*", toks[-1]) and toks[-2] not in ("const",) and toks[-1] not in _C_SCALARS and toks[-1] != "*":
+        toks = toks[:-1]
+    # base type with its own const
+    base_const = False
+    i = 0
+    if toks[i] == "const":
+        base_const, i = True, i + 1
+    base = toks[i]
+    i += 1
+    if i < len(toks) and toks[i] == "const":                     # `T const`
+        base_const, i = True, i + 1
+    rust = _C_SCALARS.get(base, base)
+    pointee_const = base_const
+    for t in toks[i:]:
+        if t == "*":
+            rust = ("*const " if pointee_const else "*mut ") + rust
+            pointee_const = False
+        elif t == "const":
+            pointee_const = True                                 # qualifies the pointer just made: matters for the NEXT level
+        else:
+            raise AssertionError(f"cannot parse C declarator {decl!r}")
+    if is_array:                                                 # `T name[N]` as a parameter is `T *`
+        rust = ("*const " if base_const else "*mut ") + rust
+    return rust
+
+
+def _header_prototypes():
+    h = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    h = re.sub(r"//[^\n]*", "", h)
+    out = {}
+    for ret, name, args in re.findall(r"^\s*((?:const\s+)?[\w]+(?:\s*\*+)?)\s*(bvhgpu_\w+)\s*\(([^;{]*?)\)\s*;", h, flags=re.M):
+        args = " ".join(args.split())
+        params = [] if args in ("", "void") else [_c_type_to_rust(a) for a in args.split(",")]
+        ret = " ".join(ret.replace("*", " * ").split())
+        out[name] = (params, None if ret == "void" else _c_type_to_rust(ret + " x") if not ret.endswith("*") else _c_type_to_rust(ret))
+    return out
+
+
+def _rust_prototypes():
+    src = open(os.path.join(ROOT, "rust", "bvh-mi355x", "src", "ffi.rs")).read()
+    src = re.sub(r"//[^\n]*", "", src)
+    out = {}
+    for name, args, ret in re.findall(r"pub fn (bvhgpu_\w+)\(([^)]*)\)\s*(?:->\s*([^;]+?))?\s*;", src):
+        params = []
+        for a in [x.strip() for x in args.split(",") if x.strip()]:
+            params.append(" ".join(a.split(":", 1)[1].split()))
+        out[name] = (params, " ".join(ret.split()) if ret else None)
+    return out
+
+
+def test_rust_ffi_signatures_match_the_header():
+    c, r = _header_prototypes(), _rust_prototypes()
+    assert len(c) >= 76 and set(c) == set(r), (sorted(set(c) - set(r)), sorted(set(r) - set(c)))
+    for name in sorted(c):
+        cp, cr = c[name]
+        rp, rr = r[name]
+        assert len(cp) == len(rp), f"{name}: {len(cp)} parameters in the header, {len(rp)} in ffi.rs"
+        for k, (a, b) in enumerate(zip(cp, rp)):
+            assert a == b, f"{name}, parameter {k}: header says {a}, ffi.rs says {b}"
+        assert cr == rr, f"{name}: returns {cr} in the header, {rr} in ffi.rs"
+    # the ctypes table has the same arity for every symbol (types are looser there: void* for every pointer)
+    from bvh_amd import _lib
+    table = {n: (len(a), res) for n, res, a in _lib.SYMBOLS}
+    assert set(table) == set(c)
+    for name, (n_args, res) in table.items():
+        assert n_args == len(c[name][0]), f"{name}: {n_args} argtypes in _lib.py, {len(c[name][0])} parameters in the header"
+        assert (res is None) == (c[name][1] is None), name
+
+
+def test_rust_ffi_structs_and_constants_match_the_header():
+    """field order / types of the #[repr(C)] mirrors and every #define / enum value ffi.rs restates"""
+    h = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    src = open(os.path.join(ROOT, "rust", "bvh-mi355x", "src", "ffi.rs")).read()
+    lib_rs = open(os.path.join(ROOT, "rust", "bvh-mi355x", "src", "lib.rs")).read()
+    ty = {"float": "f32", "double": "f64", "uint32_t": "u32", "uint64_t": "u64"}
+    for name, body in re.findall(r"typedef struct\s*\{([^}]*)\}\s*(bvhgpu_\w+);", h):
+        name, body = body, name                                  # (regex groups: body first)
+        fields = []
+        for decl in [d.strip() for d in body.split(";") if d.strip()]:
+            t, rest = decl.split(None, 1)
+            for f in [x.strip() for x in rest.split(",")]:
+                m = re.fullmatch(r"(\w+)(?:\[(\d+)\])?", f)
+                fields.append((m.group(1), f"[{ty[t]}; {m.group(2)}]" if m.group(2) else ty[t]))
+        m = re.search(r"pub struct %s\s*\{([^}]*)\}" % name, src)
+        assert m, f"ffi.rs has no #[repr(C)] struct {name}"
+        rust_fields = [(a.strip().replace("pub ", "").split(":")[0].strip(), a.split(":")[1].strip()) for a in m.group(1).split(",") if a.strip()]
+        assert rust_fields == fields, (name, rust_fields, fields)
+        assert re.search(r"#\[repr\(C\)\][^\n]*\n?\s*pub struct %s\b" % name, src) or re.search(r"#\[repr\(C\)\]\s*#\[derive[^\]]*\]\s*\n?pub struct %s\b" % name, src), name
+    consts = dict(re.findall(r"pub const (BVHGPU_\w+): \w+ = ([^;]+);", src))
+    defines = dict(re.findall(r"#define (BVHGPU_\w+) ([0-9]+)u?\b", h))
+    enums = {}
+    for body in re.findall(r"enum\s+\w*\s*\{([^}]*)\}", h) + re.findall(r"typedef enum\s*\{([^}]*)\}", h):
+        nxt = 0
+        for item in [x.strip() for x in body.split(",") if x.strip()]:
+            m = re.fullmatch(r"(BVHGPU_\w+)(?:\s*=\s*([^,]+))?", item)
+            if not m:
+                continue
+            if m.group(2) is not None:
+                nxt = int(eval(m.group(2).replace("u", ""), {}, {}))
+            enums[m.group(1)] = nxt
+            nxt += 1
+    known = {**{k: int(v) for k, v in defines.items()}, **enums}
+    checked = 0
+    for k, v in consts.items():
+        if k in known:
+            rv = {"u32::MAX": 0xFFFFFFFF}.get(v.strip(), None)
+            rv = int(v) if rv is None else rv
+            assert rv == known[k], f"{k}: {rv} in ffi.rs, {known[k]} in the header"
+            checked += 1
+    assert checked >= 25, checked
+    # the shim implements the trait for both scalar types and knows its device
+    assert "impl<T: GpuScalar> BoundingHierarchy<T, 3> for GpuBvh<T>" in lib_rs
+    assert "pub type GpuBvh64 = GpuBvh<f64>" in lib_rs and "pub fn traverse_closest" in lib_rs and "pub fn device(&self)" in lib_rs
+    for sym in re.findall(r"ffi::(bvhgpu_\w+)\b", lib_rs):       # every entry point / type lib.rs names exists in ffi.rs
+        assert re.search(r"\b%s\b" % sym, src), sym

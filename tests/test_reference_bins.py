@@ -49,8 +49,69 @@ def _oracle_arrays(n_cubes, n_rays):
             "offsets.u32": off.astype("<u4").tobytes(), "indices.u32": idx.astype("<u4").tobytes()}
 
 
+ROOT = os.path.dirname(HERE)
+DUMP_SRC = os.path.join(ROOT, "tools", "golden_dump", "src", "main.rs")
+# the records tools/golden_dump writes, field by field in this order (f = f32, u = u32): what the header's PODs must look like
+DUMP_RECORDS = {
+    "bvhgpu_node_f32": [("l_min", "f", 3), ("l_max", "f", 3), ("r_min", "f", 3), ("r_max", "f", 3), ("parent", "u", 1), ("l", "u", 1), ("r", "u", 1), ("shape", "u", 1)],
+    "bvhgpu_flat_f32": [("min", "f", 3), ("max", "f", 3), ("entry", "u", 1), ("exit", "u", 1), ("shape", "u", 1)],
+    "bvhgpu_ray_f32": [("o", "f", 3), ("d", "f", 3), ("inv", "f", 3)],
+}
+
+
+def _header_layouts():
+    """sizeof / offsetof of the three PODs as a C compiler sees include/bvh_mi355x.h today"""
+    import subprocess
+    import tempfile
+    lines = []
+    for st, fields in DUMP_RECORDS.items():
+        lines.append(f'printf("{st} %zu", sizeof({st}));')
+        for name, _, _ in fields:
+            lines.append(f'printf(" {name}:%zu:%zu", offsetof({st}, {name}), sizeof((({st}*)0)->{name}));')
+        lines.append('printf("\\n");')
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "bvh_mi355x.h"\nint main(void){' + "".join(lines) + "return 0;}\n"
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "l.c")
+        open(c, "w").write(prog)
+        exe = os.path.join(d, "l")
+        subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        out = subprocess.check_output([exe], text=True)
+    lay = {}
+    for ln in out.strip().splitlines():
+        t = ln.split()
+        lay[t[0]] = (int(t[1]), [(f.split(":")[0], int(f.split(":")[1]), int(f.split(":")[2])) for f in t[2:]])
+    return lay
+
+
+def _check_layouts(manifest):
+    """The dump's records are the header's PODs TODAY: sizes, field order and offsets (a changed bvhgpu_node_f32 / flat / ray would
+    otherwise be compared byte-for-byte against a dump taken in the old layout, and the ABI version moves every round)."""
+    lay = _header_layouts()
+    for st, fields in DUMP_RECORDS.items():
+        size, hdr = lay[st]
+        off = 0
+        for (name, _, count), (hname, hoff, hsize) in zip(fields, hdr):
+            assert (name, off, 4 * count) == (hname, hoff, hsize), f"{st}.{name}: the dump writes it at byte {off} ({4 * count} B), the header has it at {hoff} ({hsize} B)"
+            off += 4 * count
+        assert off == size, f"{st}: the dump writes {off} bytes per record, sizeof in the header is {size}"
+        meta = manifest.get("_meta", {}).get("layouts")
+        if meta is not None:
+            assert meta[st] == size, f"{st}: the dump was taken with {meta[st]}-byte records, the header now says {size}"
+    # and tools/golden_dump/src/main.rs still writes exactly these fields in this order
+    src = open(DUMP_SRC).read()
+    assert "f32s(&[l.min.x, l.min.y, l.min.z, l.max.x, l.max.y, l.max.z, r.min.x, r.min.y, r.min.z, r.max.x, r.max.y, r.max.z])" in src
+    assert "u32s(&[*parent_index as u32, *child_l_index as u32, *child_r_index as u32, u32::MAX])" in src
+    assert "f32s(&[0.0; 12])" in src and "u32s(&[*parent_index as u32, u32::MAX, u32::MAX, *shape_index as u32])" in src
+    assert "f32s(&[aabb.min.x, aabb.min.y, aabb.min.z, aabb.max.x, aabb.max.y, aabb.max.z])" in src and "u32s(&[entry, exit, shape])" in src
+    assert ("f32s(&[ray.origin.x, ray.origin.y, ray.origin.z, ray.direction.x, ray.direction.y, ray.direction.z," in src and
+            "ray.inv_direction.x, ray.inv_direction.y, ray.inv_direction.z])" in src)
+    assert '\\"layouts\\": {\\"bvhgpu_node_f32\\": 64, \\"bvhgpu_flat_f32\\": 36, \\"bvhgpu_ray_f32\\": 36}' in src
+    return {st: lay[st][0] for st in DUMP_RECORDS}
+
+
 def _check_schema(manifest):
     """what tools/golden_dump/README.md promises: one {bytes, sha256} entry per file of both scenes"""
+    sizes = _check_layouts(manifest)
     for n in (100, 10_000):
         for f in FILES:
             ent = manifest[f"cubes{n}_{f}"]
@@ -59,10 +120,10 @@ def _check_schema(manifest):
     shapes = {100: 1200, 10_000: 120_000}
     for n, k in shapes.items():   # sizes follow from the C-ABI layouts (include/bvh_mi355x.h)
         assert manifest[f"cubes{n}_aabbs.f32"]["bytes"] == k * 24
-        assert manifest[f"cubes{n}_nodes.bin"]["bytes"] == (2 * k - 1) * 64
+        assert manifest[f"cubes{n}_nodes.bin"]["bytes"] == (2 * k - 1) * sizes["bvhgpu_node_f32"]
         assert manifest[f"cubes{n}_shape_nodes.u32"]["bytes"] == k * 4
-        assert manifest[f"cubes{n}_flat.bin"]["bytes"] == (3 * k - 2) * 36
-        assert manifest[f"cubes{n}_rays.bin"]["bytes"] % 36 == 0
+        assert manifest[f"cubes{n}_flat.bin"]["bytes"] == (3 * k - 2) * sizes["bvhgpu_flat_f32"]
+        assert manifest[f"cubes{n}_rays.bin"]["bytes"] % sizes["bvhgpu_ray_f32"] == 0
 
 
 @needs_dump
@@ -85,7 +146,8 @@ def test_manifest_machinery_with_a_synthetic_dump(tmp_path):
             man[f"cubes{n}_{f}"] = {"bytes": len(data), "sha256": _sha(data)}
             if n == 100:
                 (tmp_path / f"cubes{n}_{f}").write_bytes(data)
-    man["_meta"] = {"crate": "SYNTHETIC (oracle)", "nalgebra": "-", "rustc": "-"}
+    man["_meta"] = {"crate": "SYNTHETIC (oracle)", "nalgebra": "-", "rustc": "-",
+                    "layouts": {"bvhgpu_node_f32": 64, "bvhgpu_flat_f32": 36, "bvhgpu_ray_f32": 36}}
     (tmp_path / "manifest.json").write_text(json.dumps(man))
     manifest = json.load(open(tmp_path / "manifest.json"))
     _check_schema(manifest)
@@ -101,6 +163,11 @@ def test_manifest_machinery_with_a_synthetic_dump(tmp_path):
     with pytest.raises(AssertionError) as e:
         _expect(manifest, "cubes100_nodes.bin", bytes(bad), str(tmp_path))
     assert "first differing byte at 4097" in str(e.value)
+    # a dump taken in another record layout is refused before any byte is compared
+    manifest["_meta"]["layouts"]["bvhgpu_flat_f32"] = 40
+    with pytest.raises(AssertionError) as e:
+        _check_schema(manifest)
+    assert "the header now says 36" in str(e.value)
 
 
 @needs_dump

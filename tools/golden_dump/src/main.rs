@@ -172,7 +172,9 @@ fn main() {
             }
         }
     }
-    manifest.push_str("  \"_meta\": {\"crate\": \"bvh 0.12.0\"}\n}\n");
+    // the record sizes this program writes (field by field, above): tests/test_reference_bins.py compares them — and the field order,
+    // read from this source — with sizeof / offsetof of include/bvh_mi355x.h, so a dump can never be checked against another layout
+    manifest.push_str("  \"_meta\": {\"crate\": \"bvh 0.12.0\", \"layouts\": {\"bvhgpu_node_f32\": 64, \"bvhgpu_flat_f32\": 36, \"bvhgpu_ray_f32\": 36}}\n}\n");
     std::fs::write(format!("{out}/manifest.json"), manifest).unwrap();
     println!("wrote {out}/manifest.json");
 }
