@@ -154,7 +154,7 @@ def test_guide_walk_at_the_edges_of_its_range(eng, orc, log2_s, log2_inv, guide)
     S = 2.0 ** log2_s
     aabbs = unit * S
     assert np.all(np.isfinite(aabbs)) and np.abs(aabbs).max() == S
-    g = _grazing_rays(orc, unit, 30_000, 5 + log2_s)
+    g = _grazing_rays(orc, unit, 30_000, 500 + log2_s)
     rays = np.zeros(len(g), RAY_F64)
     rays["o"] = g["o"] * S                                                   # (exact: a power of two)
     rays["d"] = g["d"]
