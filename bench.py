@@ -390,7 +390,8 @@ def run_workload(wl, args, env, steps, warmup, detailed):
     if wl.dtype_name == "f64":
         roof["f64_walk"] = ("guide: inner-node tests in f32 on boxes that contain the f64 ones, every leaf candidate decided by the f64 slab test "
                             "(kernel_ms excludes the f32 ray copy, phases_ms.ray_convert_ms)" if guide_ran else
-                            "pure f64: every slab test of the walk in double precision (BVHGPU_TUNE_WIDE_F64_GUIDE = 0)")
+                            "pure f64: every slab test of the walk in double precision (BVHGPU_TUNE_WIDE_F64_GUIDE = 0); valu_frac prices every "
+                            "wave64 VALU instruction at 2 cycles, f64 arithmetic issues at half that rate, so it understates this kernel's VALU share by up to 2x")
     if pmc is not None:
         fr = bound_fractions(pmc, kern_s)
         bound = max(fr, key=fr.get)
