@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--scene-dist", choices=["auto", "bcast", "replicate", "bcast-torch"], default="auto",
                     help="N>1: RCCL-broadcast rank 0's flattened tree through the C ABI each step, or rebuild it on every rank; "
                          "auto times both before the warmup and keeps the faster plan; bcast-torch = scene blob over torch.distributed")
+    ap.add_argument("--collective-timeout", type=float, default=60.0,
+                    help="N>1, --scene-dist auto: seconds the exchange plan (RCCL communicator + broadcast steps) may take before the line "
+                         "measured with the replicate plan is printed and the run ends")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs sub-runs")
     ap.add_argument("--no-parity", action="store_true")
@@ -138,6 +141,31 @@ def self_launch(gpus, argv):
         print(json.dumps({"launch": cmd}))
         return 0
     return subprocess.call(cmd, env=env)
+
+
+class Watchdog:
+    """A section that contains a data-path collective nobody has ever run here on more than one GPU (the RCCL broadcast of the C ABI)
+    must not be able to take the whole scaling record down with it: if the section does not finish in `seconds`, `on_fire` runs on a
+    helper thread (the main thread is blocked inside a foreign call, with the GIL released) — rank 0 prints the line measured so far,
+    every rank exits."""
+
+    def __init__(self, seconds, on_fire):
+        import threading
+        self.seconds, self.on_fire = seconds, on_fire
+        self.done = threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        if not self.done.wait(self.seconds):
+            self.on_fire()
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.done.set()
+        return False
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -238,8 +266,9 @@ def bound_fractions(c, seconds):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def run_workload(wl, args, env, steps, warmup, detailed):
-    """K timed steps of one workload on this rank's GPU (all ranks call it together) → result dict"""
+def run_workload(wl, args, env, steps, warmup, detailed, force_plan=None):
+    """K timed steps of one workload on this rank's GPU (all ranks call it together) → result dict.  force_plan: measure exactly
+    this scene-distribution plan (main() runs "replicate" first and the exchange plan afterwards, under a watchdog)"""
     import torch
     import torch.distributed as dist
     from bvh_amd import Bvh, FlatBvh, dist as bdist
@@ -249,6 +278,8 @@ def run_workload(wl, args, env, steps, warmup, detailed):
 
     if n_gpus == 1:
         plans = ["single"]
+    elif force_plan is not None:
+        plans = [force_plan]
     elif args.scene_dist == "auto":
         plans = (["bcast"] if comm is not None else ["bcast-torch"]) + ["replicate"]
     else:
@@ -525,17 +556,7 @@ def main():
     for k, v in os.environ.items():   # developer A/B runs: BVH_TUNE_<knob number>=<value> (tools/ab_tune.sh); results never depend on a knob
         if k.startswith("BVH_TUNE_"):
             ctx.set_tuning(int(k[9:]), int(v))
-    comm, comm_err = None, None
-    if n_gpus > 1 and args.backend == "nccl" and args.scene_dist in ("auto", "bcast"):
-        try:   # the RCCL communicator of the C ABI; torch.distributed only carries the 128-byte id
-            comm = bdist.Communicator.from_torch_distributed(ctx, dev)
-        except Exception as e:   # keep the run alive on the torch transport, and say so
-            comm_err = repr(e)
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            comm = None
-    env = dict(rank=rank, n_gpus=n_gpus, dev=dev, ctx=ctx, comm=comm)
+    env = dict(rank=rank, n_gpus=n_gpus, dev=dev, ctx=ctx, comm=None)
     # how many ranks this job REALLY has, counted three ways: the launcher's WORLD_SIZE (= --gpus, resolve_launch), a sum over the
     # torch.distributed group, and the size the C ABI's RCCL communicator reports for itself (bvhgpu_comm_info)
     ranks_seen, devices_seen = 1, [torch.cuda.current_device()]
@@ -546,41 +567,102 @@ def main():
         dl = [None] * n_gpus
         dist.all_gather_object(dl, f"{os.uname().nodename}:{torch.cuda.current_device()}")
         devices_seen = dl
-    rccl_obj = None
-    if comm is not None:
-        rccl_obj = comm.info()
     launch_obj = {"world_size": n_gpus, "ranks_seen": ranks_seen, "self_launched": bool(os.environ.get("BVH_BENCH_SELF_LAUNCHED")),
                   "backend": args.backend if n_gpus > 1 else None, "devices": devices_seen,
                   "distinct_devices": len(set(devices_seen))}
     if ranks_seen != n_gpus:
         raise SystemExit(f"--gpus {args.gpus}: the process group holds {ranks_seen} ranks")
 
+    line = {}            # the JSON line as far as it has been measured: what the watchdog prints if an exchange section hangs
+    xstate = {"comm_err": None, "tried_comm": False}
+
+    def emit_and_exit(what):
+        line["collective_watchdog"] = (f"{what} did not finish within {args.collective_timeout:.0f} s: this line is what had been measured until "
+                                       "then (the replicate plan has no data-path collective)")
+        if rank == 0 and line.get("value") is not None:
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+        os._exit(0 if line.get("value") is not None else 3)
+
+    def make_comm():
+        """the RCCL communicator of the C ABI (torch.distributed only carries the 128-byte id) — made AFTER the replicate plan has been
+        measured, inside the watchdog: it is the first thing in the run that has never been exercised with more than one rank"""
+        if xstate["tried_comm"] or args.backend != "nccl":
+            return env["comm"]
+        xstate["tried_comm"] = True
+        comm = None
+        try:
+            comm = bdist.Communicator.from_torch_distributed(ctx, dev)
+        except Exception as e:   # keep the run alive on the torch transport, and say so
+            xstate["comm_err"] = repr(e)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            comm = None
+        env["comm"] = comm
+        return comm
+
+    def measure(w, steps, warmup, detailed, publish=None):
+        """one workload → (result dict of the plan that is reported, probe {plan: ms per step}).  N = 1 or an explicit --scene-dist: one
+        run.  N > 1 with --scene-dist auto: the replicate plan first (every rank builds: no data-path collective, so this result is safe
+        — `publish` puts it into the line at once), then the exchange plan under the watchdog; the faster one is reported."""
+        if n_gpus == 1 or args.scene_dist != "auto":
+            if n_gpus > 1 and args.scene_dist == "bcast":
+                with Watchdog(args.collective_timeout, lambda: emit_and_exit("forming the RCCL communicator")):
+                    make_comm()
+            return run_workload(w, args, env, steps, warmup, detailed), None
+        res = run_workload(w, args, env, steps, warmup, detailed, force_plan="replicate")
+        keep = dict(env["last"])
+        if publish:
+            publish(res)
+        with Watchdog(args.collective_timeout, lambda: emit_and_exit(f"the exchange plan of {w.name}")):
+            if os.environ.get("BVH_BENCH_TEST_HANG_EXCHANGE"):   # tests: a collective that never returns (tests/test_gpu_dist.py)
+                time.sleep(10 ** 6)
+            comm = make_comm()
+            xplan = "bcast" if comm is not None else "bcast-torch"
+            res_x = run_workload(w, args, env, steps, warmup, detailed, force_plan=xplan)
+        probe = {"replicate": res["ms_per_step"], xplan: res_x["ms_per_step"]}
+        both = {"replicate": {k: res[k] for k in ("value", "ms_per_step", "phases_ms", "hits_all_ranks")},
+                xplan: {k: res_x[k] for k in ("value", "ms_per_step", "phases_ms", "hits_all_ranks") if k in res_x}}
+        if res_x["ms_per_step"] < res["ms_per_step"]:
+            res = res_x
+        else:
+            env["last"] = keep
+        res["scene_dist_probe_ms_per_step"] = probe
+        res["scene_dist_plans"] = both
+        return res, probe
+
+    def compose(res):
+        out = {
+            "metric": "Mrays/s (build+traverse)", "value": res["value"], "unit": "Mrays/s", "n_gpus": n_gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+            "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "workload_name": wl.name,
+            "config": {
+                "workload": wl.describe(), "triangles": wl.n_tri, "rays_per_gpu": wl.R, "rays_total": wl.total_rays,
+                "scene_dist": res["scene_dist"],
+                "parallelism": f"rays sharded x{n_gpus}" + {
+                    "single": "", "bcast": ", flattened tree RCCL-broadcast from rank 0 every step by the C ABI (bvhgpu_bcast_known)",
+                    "bcast-torch": ", scene blob broadcast from rank 0 every step over torch.distributed",
+                    "replicate": ", every rank rebuilds the scene (deterministic build, no data-path collective)"}[res["scene_dist"]],
+            },
+            "phases_ms": res["phases_ms"], "build_levels": res.get("build_levels"), "hits_all_ranks": res["hits_all_ranks"],
+            "scene_dist_probe_ms_per_step": res.get("scene_dist_probe_ms_per_step"), "scene_dist_plans": res.get("scene_dist_plans"),
+            "roofline": res["roofline"], "roofline_build": res.get("roofline_build"),
+            "launch": launch_obj,
+            # None: no RCCL communicator in this run (N = 1, --backend gloo, --scene-dist replicate, or rccl_comm_error)
+            "rccl": env["comm"].info() if env["comm"] is not None else None,
+        }
+        if xstate["comm_err"]:
+            out["rccl_comm_error"] = xstate["comm_err"]
+        return out
+
     wl = Workload(args.workload, args, args.dtype, rank, n_gpus, dev, ctx, scaling=args.scaling, rays=args.rays)
     torch.cuda.synchronize(dev)
-    res = run_workload(wl, args, env, args.steps, args.warmup, detailed=True)
+    res, _ = measure(wl, args.steps, args.warmup, True, publish=lambda r: line.update(compose(r)))
     main_env = dict(env["last"])
-
-    out = {
-        "metric": "Mrays/s (build+traverse)", "value": res["value"], "unit": "Mrays/s", "n_gpus": n_gpus,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
-        "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "workload_name": wl.name,
-        "config": {
-            "workload": wl.describe(), "triangles": wl.n_tri, "rays_per_gpu": wl.R, "rays_total": wl.total_rays,
-            "scene_dist": res["scene_dist"],
-            "parallelism": f"rays sharded x{n_gpus}" + {
-                "single": "", "bcast": ", flattened tree RCCL-broadcast from rank 0 every step by the C ABI (bvhgpu_bcast_known)",
-                "bcast-torch": ", scene blob broadcast from rank 0 every step over torch.distributed",
-                "replicate": ", every rank rebuilds the scene (deterministic build, no data-path collective)"}[res["scene_dist"]],
-        },
-        "phases_ms": res["phases_ms"], "build_levels": res.get("build_levels"), "hits_all_ranks": res["hits_all_ranks"],
-        "scene_dist_probe_ms_per_step": res["scene_dist_probe_ms_per_step"],
-        "roofline": res["roofline"], "roofline_build": res.get("roofline_build"),
-    }
-    out["launch"] = launch_obj
-    out["rccl"] = rccl_obj     # None: no RCCL communicator in this run (N = 1, --backend gloo, --scene-dist replicate, or rccl_comm_error)
-    if comm_err:
-        out["rccl_comm_error"] = comm_err
+    out = line
+    out.clear()
+    out.update(compose(res))
 
     # ---- parity: the GPU result of the headline batch against the CPU oracle, in-process (BASELINE.md §3 item 4) ----
     parity_run = None
@@ -637,6 +719,7 @@ def main():
     # ---- the other BASELINE configs, driver-observed in the same line ----
     if not args.no_extra and args.workload == "cubes120k" and args.dtype == "f32":
         extras = []
+        out["extra_configs"] = extras
         if n_gpus == 1:
             plan = [("standin-primary", "f32", None, None), ("standin-incoherent", "f32", "weak", 12_500_000), ("cubes120k", "f64", None, None),
                     ("standin-incoherent", "f32", "strong", 100_000_000)]   # configs[3] whole on ONE GPU: the N = 1 point of the strong curve
@@ -649,7 +732,7 @@ def main():
                     from bvh_amd import RayBatch
                     w2.first = 62_500_000
                     w2.rays = RayBatch.generate(w2.first, w2.R, w2.bounds, w2.rays_buf, w2.np_dtype, ctx)
-                r2 = run_workload(w2, args, env, args.extra_steps, 3, detailed=False)
+                r2, _ = measure(w2, args.extra_steps, 3, False)
                 if name == "standin-incoherent" and n_gpus == 1:
                     r2["note"] = ("one GPU's share of configs[3]: rays [62.5 M, 75 M) of the 100 M-ray stream (rank 5 of 8)" if scaling == "weak" else
                                   "configs[3] whole: all 100 M rays of the stream on one GPU in one batch — the N = 1 point of the strong-scaling "
@@ -743,8 +826,8 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if comm is not None:
-        comm.close()
+    if env["comm"] is not None:
+        env["comm"].close()
     if n_gpus > 1:
         dist.destroy_process_group()
 

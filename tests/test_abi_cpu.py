@@ -412,3 +412,29 @@ def test_rust_ffi_structs_and_constants_match_the_header():
     assert "pub type GpuBvh64 = GpuBvh<f64>" in lib_rs and "pub fn traverse_closest" in lib_rs and "pub fn device(&self)" in lib_rs
     for sym in re.findall(r"ffi::(bvhgpu_\w+)\b", lib_rs):       # every entry point / type lib.rs names exists in ffi.rs
         assert re.search(r"\b%s\b" % sym, src), sym
+
+
+def test_bench_watchdog_prints_what_was_measured():
+    """bench.py's guard around the never-yet-run N > 1 exchange (RCCL communicator + broadcast steps): a section that blocks inside a
+    foreign call is abandoned after the timeout by a helper thread that prints the line measured so far and ends the process."""
+    code = ("import os, sys, time, json, importlib.util\n"
+            "spec = importlib.util.spec_from_file_location('bench_mod', %r)\n"
+            "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            "line = {'value': 123.0, 'scene_dist': 'replicate'}\n"
+            "def fire():\n"
+            "    line['collective_watchdog'] = 'timed out'\n"
+            "    os.write(1, (json.dumps(line) + '\\n').encode()); os._exit(0)\n"
+            "with b.Watchdog(0.2, fire):\n"
+            "    pass\n"                              # a section that finishes in time: nothing fires
+            "time.sleep(0.5)\n"
+            "with b.Watchdog(0.5, fire):\n"
+            "    time.sleep(60)\n"                   # (blocks with the GIL released, like a hung ncclGroupEnd under ctypes)
+            "print('NOT REACHED')\n") % os.path.join(ROOT, "bench.py")
+    import json
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and time.time() - t0 < 30, p.stderr[-1000:]
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 1 and "NOT REACHED" not in p.stdout
+    assert json.loads(lines[0]) == {"value": 123.0, "scene_dist": "replicate", "collective_watchdog": "timed out"}

@@ -115,6 +115,35 @@ def test_bench_launches_its_own_ranks():
         assert bad.returncode != 0 and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
 
 
+def test_bench_exchange_plan_cannot_take_the_line_down():
+    """N > 1, --scene-dist auto: the replicate plan (no data-path collective) is measured FIRST; the exchange plan — whose RCCL form has
+    never run on more than one GPU — runs under a watchdog.  A collective that never returns (simulated) ends the run after
+    --collective-timeout with the replicate line on stdout, rc 0, and the line says what happened."""
+    import bvh_amd
+    if bvh_amd.device_count() <= 0:
+        pytest.fail("GPU test selected but no HIP device is visible (no CPU fallback exists)")
+    cubes, R = 2000, 60_000
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--cubes", str(cubes),
+           "--rays", str(R), "--backend", "gloo", "--one-device", "--no-extra", "--no-parity", "--collective-timeout", "8"]
+    p = subprocess.run(cmd, env=dict(env, BVH_BENCH_TEST_HANG_EXCHANGE="1"), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["scene_dist"] == "replicate" and out["value"] > 0
+    assert "did not finish within 8 s" in out["collective_watchdog"]
+    assert out["roofline"]["kernel"] and out["launch"]["ranks_seen"] == 2
+    # without the simulated hang both plans are on the line, the faster one is the headline
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert "collective_watchdog" not in out and set(out["scene_dist_plans"]) == {"replicate", "bcast-torch"}
+    best = min(out["scene_dist_plans"], key=lambda k: out["scene_dist_plans"][k]["ms_per_step"])
+    assert out["config"]["scene_dist"] == best and out["ms_per_step"] == out["scene_dist_plans"][best]["ms_per_step"]
+    assert out["scene_dist_plans"]["replicate"]["hits_all_ranks"] == out["scene_dist_plans"]["bcast-torch"]["hits_all_ranks"]
+
+
 def test_rccl_info_names_the_one_rccl_of_the_process():
     """bvhgpu_rccl_info names the RCCL the C ABI resolved (the copy torch already holds must be shared, not a second one),
     and a communicator reports its own size."""
