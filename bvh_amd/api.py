@@ -76,7 +76,27 @@ class Context:
         check(lib.bvhgpu_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
         self._h = h
         self.device = int(device)
+        # The C ABI wants a ctx to outlive what was made on it (bvhgpu_tree_destroy / bvhgpu_hits_destroy / bvhgpu_comm_destroy look at
+        # their ctx).  Reference counts normally give that order, but objects caught in a reference cycle (a pytest.raises traceback is
+        # enough) are finalised by the cyclic collector in ARBITRARY order — so the ctx counts its children and, if it is closed while
+        # some are alive, hands its destruction to the last of them.
+        self._nchildren = 0
+        self._deferred = False
         _live.add(self)
+
+    def _child_add(self):
+        self._nchildren += 1
+
+    def _child_drop(self):
+        self._nchildren -= 1
+        if self._nchildren <= 0 and self._deferred:
+            self._destroy()
+
+    def _destroy(self):
+        if getattr(self, "_h", None) and not _closing:
+            _lib.load().bvhgpu_destroy(self._h)
+        self._h = None
+        self._deferred = False
 
     def synchronize(self):
         check(_lib.load().bvhgpu_synchronize(self._h), self._h)
@@ -95,9 +115,12 @@ class Context:
         check(_lib.load().bvhgpu_set_tuning(self._h, int(knob), int(value)), self._h)
 
     def close(self):
-        if getattr(self, "_h", None) and not _closing:
-            _lib.load().bvhgpu_destroy(self._h)
-        self._h = None
+        if getattr(self, "_h", None) is None:
+            return
+        if getattr(self, "_nchildren", 0) > 0 and not _closing:
+            self._deferred = True      # the last tree / result object / communicator made on it destroys it
+            return
+        self._destroy()
 
     def __del__(self):
         try:
@@ -288,12 +311,23 @@ class _Hits:
     def __init__(self, ctx: Context):
         self.ctx = ctx
         self.h = C.c_void_p()
+        self._counted = True
+        ctx._child_add()
         _live.add(self)
 
     def wait(self) -> dict:
         """bvhgpu_hits_wait: complete an asynchronous batch; returns the stats dict of traverse_batch."""
         lib = _lib.load()
         check(lib.bvhgpu_hits_wait(self.h), self.ctx._h)
+        total = C.c_uint64()
+        st = _lib.TraverseStats()
+        check(lib.bvhgpu_hits_info(self.h, None, C.byref(total), C.byref(st)), self.ctx._h)
+        return dict(hits=int(st.hits), visited=int(st.visited), leaf_visits=int(st.leaf_visits),
+                    device_steps=int(st.device_steps), wave_steps=int(st.wave_steps), total=int(total.value))
+
+    def info(self) -> dict:
+        """stats of the completed batch (bvhgpu_hits_info)"""
+        lib = _lib.load()
         total = C.c_uint64()
         st = _lib.TraverseStats()
         check(lib.bvhgpu_hits_info(self.h, None, C.byref(total), C.byref(st)), self.ctx._h)
@@ -314,6 +348,9 @@ class _Hits:
         if getattr(self, "h", None) and not _closing:
             _lib.load().bvhgpu_hits_destroy(self.h)
         self.h = None
+        if getattr(self, "_counted", False):
+            self._counted = False
+            self.ctx._child_drop()
 
     def __del__(self):
         try:
@@ -328,6 +365,8 @@ class _TreeBase:
         self._t = handle
         self.sfx = sfx
         self._hits = _Hits(ctx)
+        self._counted = True
+        ctx._child_add()
         _live.add(self)
 
     def close(self):
@@ -337,6 +376,9 @@ class _TreeBase:
             if not _closing:
                 _lib.load().bvhgpu_tree_destroy(self._t)
         self._t = None
+        if getattr(self, "_counted", False):
+            self._counted = False
+            self.ctx._child_drop()
 
     def __del__(self):
         try:

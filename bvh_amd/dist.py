@@ -50,6 +50,8 @@ class Communicator:
         self.ctx = ctx
         self.nranks = int(nranks)
         self.rank = int(rank)
+        ctx._child_add()      # (bvhgpu_comm_destroy synchronises the ctx's stream: the ctx must outlive the communicator, api.Context)
+        self._counted = True
 
     @staticmethod
     def unique_id() -> bytes:
@@ -98,6 +100,9 @@ class Communicator:
         if getattr(self, "_h", None):
             _lib.load().bvhgpu_comm_destroy(self._h)
         self._h = None
+        if getattr(self, "_counted", False):
+            self._counted = False
+            self.ctx._child_drop()
 
     def __del__(self):
         try:
@@ -179,6 +184,9 @@ class LocalCommunicator:
         check(lib.bvhgpu_comm_init_all(arr, len(self.ctxs), C.byref(h)), self.ctxs[0]._h)
         self._h = h
         self.nranks = len(self.ctxs)
+        for c in self.ctxs:
+            c._child_add()
+        self._counted = True
 
     def bcast(self, trees: Sequence, root: int = 0, dtype: Optional[str] = None, n_shapes: Optional[int] = None, triangles: bool = False,
               raise_on_error: bool = True):
@@ -211,6 +219,10 @@ class LocalCommunicator:
         if getattr(self, "_h", None):
             _lib.load().bvhgpu_comm_destroy(self._h)
         self._h = None
+        if getattr(self, "_counted", False):
+            self._counted = False
+            for c in self.ctxs:
+                c._child_drop()
 
     def __del__(self):
         try:

@@ -226,3 +226,38 @@ def test_rebuild_with_other_shape_count_drops_triangles(eng):
         bvh.closest_hits(rb)
     bvh.set_triangles(tris2)
     bvh.closest_hits(rb)
+
+
+def test_ctx_may_be_finalised_before_what_was_made_on_it(eng, orc):
+    """The cyclic collector finalises objects of a reference cycle in arbitrary order (a pytest.raises traceback holding a test's locals
+    is enough): a Context closed while trees / result objects made on it are alive hands its destruction to the last of them instead
+    of leaving them with a dangling ctx (round 4: this crashed the interpreter at the end of a test session)."""
+    import gc
+    from bvh_amd import Bvh, Context, RayBatch, testbase as tb
+    from bvh_amd.api import _Hits
+    _, aabbs = tb.create_n_cubes(200)
+    rays = orc.create_rays(0, 2000)
+    for order in ("ctx_first", "tree_first", "cycle"):
+        ctx = Context(0)
+        tree = Bvh.from_aabbs(aabbs, ctx)
+        flat = tree.flatten()
+        extra = _Hits(ctx)
+        off, idx, _, _ = flat.traverse_batch(RayBatch(len(rays), np.float32, host=rays))
+        assert ctx._nchildren == 3                      # the tree, its result object, the extra one
+        if order == "ctx_first":
+            ctx.close()                                 # deferred: the handle stays valid
+            assert ctx._h is not None and ctx._deferred
+            off2, idx2, _, _ = flat.traverse_batch(RayBatch(len(rays), np.float32, host=rays))
+            assert np.array_equal(idx, idx2)
+            extra.close(); tree.close()
+            assert ctx._h is None                       # the last child destroyed it
+        elif order == "tree_first":
+            tree.close(); extra.close(); ctx.close()
+            assert ctx._h is None
+        else:
+            cyc = {"ctx": ctx, "tree": tree, "flat": flat, "extra": extra}
+            cyc["self"] = cyc                           # a cycle that owns everything
+            del ctx, tree, flat, extra, cyc
+            gc.collect()
+    gc.collect()
+
