@@ -149,7 +149,6 @@ TUNE_WIDE_STAGE_SHIFT = 12       # wide walk, whole rays, indices only: 2^v shap
 TUNE_WIDE_REC8 = 13              # wide walk, whole rays, indices only: 8-byte pool records (1, default) or the 12-byte HitRec (0)
 TUNE_BUILD_LEVEL_LAUNCHES = 10   # builder, level tier: 1 one launch per level, 2 k_bin + k_split per level, 0 (default) by scene size
 TUNE_WIDE_F64_GUIDE = 14        # wide walk, f64 trees, indices only: walk the f32 guide boxes, test leaf candidates in f64 (1, default) or the f64 walk (0)
-TUNE_BUILD_LOWER_FUSED = 15     # builder: workgroup tier + wave tier in one launch (k_lower) 1 / two launches 0 / -1 default
 WALK_WIDE, WALK_STAGED, WALK_REC8, WALK_F64_GUIDE = 1, 2, 4, 8   # bvhgpu_hits_walk_info
 ABI_VERSION = 5
 

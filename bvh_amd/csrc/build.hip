@@ -30,14 +30,13 @@ namespace bvhgpu {
 
 constexpr int MAXLV = 96;        // counter slots (levels beyond reuse the last two, host-synchronised)
 constexpr int CTR_SMALL = 0;     // u32: number of small items (<= 64 shapes, wave-subtree tier)
+// (u32 slot 3 is unused: it was the arrival ticket of a k_prep that created the root item itself)
 constexpr int CTR_MID2 = 2;      // u32: number of workgroup-tier items (65 .. BuildArgs::mid_max shapes)
-constexpr int CTR_MID_DONE = 3;  // u32: workgroups of k_lower that have finished their workgroup-tier items (the wave-tier queue is final once all have)
 constexpr int CTR_FLAGS = 4;     // u32: BUILD_FLAG_* bits raised by the kernels, read back by the host with the counters
 constexpr int CTR_TOPMASK = BUILD_CTR_TOPMASK;   // u32: bit h set when the level tier has written the BvhNode of heap number h < 16 (levels 0..3):
                                  // once bits 1..15 are there, the walk's item filter can run beside the rest of the build (traverse.hip k_wide_items)
 constexpr uint32_t BUILD_FLAG_NONFINITE = 1u;    // a shape AABB holds NaN / ±inf, or the root centroid extent overflows: the
                                                  // reference panics there (bvh_node.rs:214-217, `to_usize().unwrap()`); nothing is built
-constexpr uint32_t BUILD_FLAG_LOWER_TIMEOUT = 4u; // a consumer wave of k_lower gave up waiting for its wave-tier item: the host finishes the build with k_small
 constexpr uint32_t BUILD_FLAG_EMPTY_SPLIT = 2u;  // some node had no winning SAH candidate (NaN / inf costs): its children carry
                                                  // Aabb::empty() bounds (bvh_node.rs:225-230), so a child box is NOT the join of its
                                                  // grandchildren and traversal must test every ancestor (no wide walk)
@@ -128,21 +127,7 @@ template <typename T> struct BuildArgs {
     typename Traits<T>::Key* rootkeys;   // [gridDim of k_prep][12]: every workgroup's bounds (joined by k_root / k_level<ROOT>)
     uint32_t prep_wgs;                   // gridDim of k_prep
     uint32_t n;
-    uint32_t gen;                        // stamp of this build (never 0): a wave-tier item whose `_r1` carries it is complete (k_lower)
 };
-
-// ---- device-scope loads / stores for data that crosses workgroups INSIDE one launch (k_lower: the workgroup tier's children are
-// picked up by wave-tier consumers of the same launch).  The XCDs' L2s are not coherent with each other: a plain store stays in the
-// writer's L2 until the kernel ends, a plain load may be served from a stale line — relaxed agent-scope atomics compile to sc1
-// accesses that write through to / read from the memory side.  Ordering: the writer waits for its stores (s_waitcnt vmcnt(0)) before
-// it publishes the ready stamp; no fence (an agent-scope fence writes back the whole L2: 6.5 µs on this chip, EXPERIMENTS.md).
-__device__ __forceinline__ void st_dev(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_dev(float* p, float v) { __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_dev(double* p, double v) { __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t ld_dev(const uint32_t* p) { return __hip_atomic_load(const_cast<uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_dev(const float* p) { return __uint_as_float(__hip_atomic_load(reinterpret_cast<uint32_t*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-__device__ __forceinline__ double ld_dev(const double* p) { return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(const_cast<double*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
-__device__ __forceinline__ void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // is key slot j of a bucket a "min" slot?  layout: aabb.min[3] aabb.max[3] cen.min[3] cen.max[3]
 __device__ __forceinline__ bool key_is_min(int j) { return j < 3 || (j >= 6 && j < 9); }
@@ -301,7 +286,7 @@ __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, ui
     Item<T>* it = is_small ? &a.small[slot] : (is_mid2 ? &a.mid2[slot] : &a.big[npar][slot]);
     if (lane == 0) {
         it->ni = ni; it->parent = parent; it->start = start; it->count = count;
-        it->tile_base = tb; it->parity = (uint32_t)npar; it->heap = heap; it->_r1 = a.gen;
+        it->tile_base = tb; it->parity = (uint32_t)npar; it->heap = heap; it->_r1 = 0;
     }
     if (lane < 6) { it->A[lane] = A[lane]; it->C[lane] = C[lane]; }
     if (!is_small && !is_mid2) {
@@ -340,7 +325,7 @@ __device__ void push_pair(const BuildArgs<T>& a, int next_level, uint32_t parent
         Item<T>* it = kind == 0 ? &a.small[cslot] : (kind == 1 ? &a.mid2[cslot] : &a.big[npar][cslot]);
         if (lane == 0) {
             it->ni = side ? ri : li; it->parent = parent; it->start = side ? rstart : lstart; it->count = ccount;
-            it->tile_base = ctb; it->parity = (uint32_t)npar; it->heap = side ? rheap : lheap; it->_r1 = a.gen;
+            it->tile_base = ctb; it->parity = (uint32_t)npar; it->heap = side ? rheap : lheap; it->_r1 = 0;
         }
         if (lane < 6) { it->A[lane] = side ? AR[lane] : AL[lane]; it->C[lane] = side ? CR[lane] : CL[lane]; }
         if (kind == 3) {
@@ -1239,7 +1224,7 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
                 Item<T>* it = c.kind == 0u ? &a.small[cq] : (c.kind == 1u ? &a.mid2[cq] : &v.item[L & 1][c.slot]);
                 if (lane == 0) {
                     it->ni = side ? ri : li; it->parent = ni; it->start = c.start; it->count = c.count;
-                    it->tile_base = c.tile0; it->parity = (uint32_t)(L & 1); it->heap = heap_child(heap, (uint32_t)side); it->_r1 = a.gen;
+                    it->tile_base = c.tile0; it->parity = (uint32_t)(L & 1); it->heap = heap_child(heap, (uint32_t)side); it->_r1 = 0;
                 }
                 if (lane < 6) { it->A[lane] = side ? sel.AR[lane] : sel.AL[lane]; it->C[lane] = side ? sel.CR[lane] : sel.CL[lane]; }
                 if (c.kind == 3u) {
@@ -1377,10 +1362,8 @@ __device__ unsigned long long g_mid_prof[8];
 #define MID_T(i)
 #endif
 
-// FUSED (k_lower): children that leave for the wave tier are picked up by consumer waves of the SAME launch — their Item records and
-// index slices are written through (st_dev), and an item's `_r1` gets the build's stamp once both are in memory.
-template <typename T, typename Cfg, bool FUSED>
-__device__ __forceinline__ void mid_body(const BuildArgs<T>& a, uint32_t first) {
+template <typename T, typename Cfg>
+__global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t first) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
     constexpr int MAXN = Cfg::MAXN, MID_THREADS = Cfg::THREADS, PPT = MAXN / MID_THREADS;
@@ -1399,11 +1382,8 @@ __device__ __forceinline__ void mid_body(const BuildArgs<T>& a, uint32_t first) 
     __shared__ unsigned long long s_wlo[MID_THREADS / WAVE];
     __shared__ uint32_t s_whi[MID_THREADS / WAVE];
     __shared__ uint32_t s_nsub;
-    __shared__ uint32_t s_ready[2 * MAXSUB];   // FUSED: wave-tier queue slots filled at this level (NONE: none), stamped after phase 5
 
-    // (FUSED: the counters' cache line is polled by this launch's consumers with device-scope loads — a plain load here would leave a
-    //  copy in the XCD's L2 that those loads then hit for ever: k_lower's first version timed out exactly so)
-    const uint32_t n_mid = FUSED ? ld_dev(&a.ctr[CTR_MID2]) : a.ctr[CTR_MID2];
+    const uint32_t n_mid = a.ctr[CTR_MID2];
     const Item<T>* queue = a.mid2;
     const int tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     const unsigned long long lt = lanemask_lt();
@@ -1668,7 +1648,6 @@ __device__ __forceinline__ void mid_body(const BuildArgs<T>& a, uint32_t first) 
 #ifdef BVH_PROFILE_MID
                 const long long _ta = clock64();
 #endif
-                if (FUSED && lane < MAXSUB) { s_ready[2 * lane] = NONE; s_ready[2 * lane + 1] = NONE; }
                 if (lane == 0 && nsmall) sbase = atomicAdd(&a.ctr[CTR_SMALL], nsmall);
                 if (lane == 0 && nmid2) wbase = atomicAdd(&a.ctr[CTR_MID2], nmid2);
                 sbase = __shfl(sbase, 0);
@@ -1702,18 +1681,10 @@ __device__ __forceinline__ void mid_body(const BuildArgs<T>& a, uint32_t first) 
                         } else {
                             const bool to_small = side ? smR : smL;
                             Item<T>* g = to_small ? &a.small[side ? slR : slL] : &a.mid2[side ? w2R : w2L];
-                            if (FUSED && to_small) {   // read by a consumer wave of this launch, possibly on another XCD: written through
-                                st_dev(&g->ni, cni); st_dev(&g->parent, ni); st_dev(&g->start, istart + cstart); st_dev(&g->count, ccount);
-                                st_dev(&g->tile_base, 0u); st_dev(&g->parity, out_parity); st_dev(&g->heap, heap_child(m->heap, (uint32_t)side));
+                            g->ni = cni; g->parent = ni; g->start = istart + cstart; g->count = ccount;
+                            g->tile_base = 0; g->parity = out_parity; g->heap = heap_child(m->heap, (uint32_t)side); g->_r1 = 0;
 #pragma unroll
-                                for (int k = 0; k < 6; k++) { st_dev(&g->A[k], CA[k]); st_dev(&g->C[k], CC[k]); }
-                                s_ready[2 * lane + side] = side ? slR : slL;
-                            } else {
-                                g->ni = cni; g->parent = ni; g->start = istart + cstart; g->count = ccount;
-                                g->tile_base = 0; g->parity = out_parity; g->heap = heap_child(m->heap, (uint32_t)side); g->_r1 = a.gen;
-#pragma unroll
-                                for (int k = 0; k < 6; k++) { g->A[k] = CA[k]; g->C[k] = CC[k]; }
-                            }
+                            for (int k = 0; k < 6; k++) { g->A[k] = CA[k]; g->C[k] = CC[k]; }
                         }
                     }
                 }
@@ -1730,30 +1701,14 @@ __device__ __forceinline__ void mid_body(const BuildArgs<T>& a, uint32_t first) 
                 const MidSub<T>* m = &s_sub[cur][sg[j]];
                 const uint32_t ch = m->child[(p - m->start) < m->nl ? 0 : 1];
                 if (ch != NONE) s_seg[p] = (uint8_t)ch;
-                else { s_seg[p] = SEG_NONE; if (FUSED) st_dev(&gdst[istart + p], s_idx[p]); else gdst[istart + p] = s_idx[p]; }
+                else { s_seg[p] = SEG_NONE; gdst[istart + p] = s_idx[p]; }
             }
-            if (FUSED) wait_stores();   // this thread's share of the leaving children's index slices is in memory
             __syncthreads();
             MID_T(5);
-            if (FUSED && wv == 0) {     // every slice and every Item record of this level is in memory: the children may be picked up
-                wait_stores();          // (the Item records were written by this wave, in phase 4b)
-                if ((uint32_t)lane < nsub) {
-#pragma unroll
-                    for (int side = 0; side < 2; side++) {
-                        const uint32_t slot = s_ready[2 * lane + side];
-                        if (slot != NONE) st_dev(&a.small[slot]._r1, a.gen);
-                    }
-                }
-            }
             cur ^= 1;
             nsub = s_nsub;
         }
     }
-}
-
-template <typename T, typename Cfg>
-__global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t first) {
-    mid_body<T, Cfg, false>(a, first);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1779,19 +1734,24 @@ void debug_small_prof(unsigned long long* out, size_t n) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_prof), sizeof(unsigned long long) * n);
 }
 #endif
-// one wave-tier item, all its levels.  DEV: the item was queued by a workgroup of the SAME launch (k_lower): its record and its index
-// slice are read with device-scope loads (ld_dev); `wave` only names the item for the profile build
-template <typename T, bool DEV>
-__device__ __forceinline__ void small_body(const BuildArgs<T>& a, const Item<T>* it, uint32_t wave, uint32_t first, uint32_t wave0, int lane,
-                                           unsigned long long lt, unsigned long long sp_t0) {
+template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T> a, uint32_t first) {
     using Tr = Traits<T>;
-    {
-    const uint32_t istart = DEV ? ld_dev(&it->start) : it->start;
-    const int n = (int)(DEV ? ld_dev(&it->count) : it->count);
-    const uint32_t* idx = a.idx[DEV ? ld_dev(&it->parity) : it->parity];
+#ifdef BVH_SMALL_PROFILE
+    const unsigned long long sp_t0 = wall_clock64();
+#endif
+    const uint32_t n_small = a.ctr[CTR_SMALL];
+    const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const int lane = lane_id();
+    const unsigned long long lt = lanemask_lt();
+    for (uint32_t wave = first + wave0; wave < n_small; wave += nwaves) {
+    const Item<T>* it = &a.small[wave];
+    const uint32_t istart = it->start;
+    const int n = (int)it->count;
+    const uint32_t* idx = a.idx[it->parity];
 
     bool done = lane >= n;
-    uint32_t shape = done ? 0u : (DEV ? ld_dev(&idx[istart + lane]) : idx[istart + lane]);
+    uint32_t shape = done ? 0u : idx[istart + lane];
     T box[6];
     if (!done) {
         const T* b = a.aabbs + 6 * (size_t)shape;
@@ -1802,10 +1762,10 @@ __device__ __forceinline__ void small_body(const BuildArgs<T>& a, const Item<T>*
     }
     // per-lane copy of the segment (= BvhNodeBuildArgs) the lane currently belongs to
     int lo = done ? lane : 0, hi = done ? lane + 1 : n;
-    uint32_t ni = DEV ? ld_dev(&it->ni) : it->ni, parent = DEV ? ld_dev(&it->parent) : it->parent, heap = DEV ? ld_dev(&it->heap) : it->heap;
+    uint32_t ni = it->ni, parent = it->parent, heap = it->heap;
     T Cb[6], A0[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) { Cb[k] = DEV ? ld_dev(&it->C[k]) : it->C[k]; A0[k] = DEV ? ld_dev(&it->A[k]) : it->A[k]; }
+    for (int k = 0; k < 6; k++) { Cb[k] = it->C[k]; A0[k] = it->A[k]; }
     T saA = surface_area(A0);
 #ifdef BVH_SMALL_PROFILE
     int sp_level = 0;
@@ -1958,69 +1918,6 @@ __device__ __forceinline__ void small_body(const BuildArgs<T>& a, const Item<T>*
     }
 }
 
-template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T> a, uint32_t first) {
-    unsigned long long sp_t0 = 0;
-#ifdef BVH_SMALL_PROFILE
-    sp_t0 = wall_clock64();
-#endif
-    const uint32_t n_small = a.ctr[CTR_SMALL];
-    const uint32_t wave0 = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    const int lane = lane_id();
-    const unsigned long long lt = lanemask_lt();
-    for (uint32_t wave = first + wave0; wave < n_small; wave += nwaves)
-        small_body<T, false>(a, &a.small[wave], wave, first, wave0, lane, lt, sp_t0);
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_lower — workgroup tier and wave tier in ONE launch (round 4; scenes up to MID_SCENE_SPLIT shapes, optimistic schedule only).
-// k_mid is a latency chain that leaves the chip nearly idle (about one 384-thread workgroup per CU, VALU 0.08 of peak) and k_small
-// is bound by issue slots per SIMD; launched one after the other they cost their sum plus a boundary.  Here the grid's first
-// workgroups run the workgroup tier (mid_body<FUSED>) and every workgroup WITHOUT a workgroup-tier item is a team of wave-tier
-// consumers: item i belongs to consumer wave (i mod C) — no ticket atomics — which waits for the item's `_r1` to carry the build's
-// stamp (written through once its record and index slice are in memory), walks it, and goes on to item i + C.  The queue is final
-// when every workgroup has passed its workgroup-tier phase (CTR_MID_DONE == gridDim).  Nothing can hang: the grid never exceeds what is
-// resident at once (host: occupancy query), producers never wait, and a consumer that waits longer than LOWER_TIMEOUT_US gives up and
-// raises BUILD_FLAG_LOWER_TIMEOUT — the host then finishes with k_small, like the slow path of an unbalanced tree.
-// ------------------------------------------------------------------------------------------------
-constexpr unsigned long long LOWER_TIMEOUT_TICKS = 200000ull;   // 2 ms of the 100 MHz wall clock
-template <typename T, typename Cfg>
-__global__ __launch_bounds__(Cfg::THREADS) void k_lower(BuildArgs<T> a) {
-    const uint32_t n_mid = ld_dev(&a.ctr[CTR_MID2]);   // final: the level tier is complete (the workgroup tier queues none at this hand-off size)
-    mid_body<T, Cfg, true>(a, 0u);
-    __syncthreads();
-    if (threadIdx.x == 0) { wait_stores(); atomicAdd(&a.ctr[CTR_MID_DONE], 1u); }
-    if (blockIdx.x < n_mid) return;           // this workgroup had workgroup-tier items: its CU has done its share
-    const uint32_t ncwg = gridDim.x - min(n_mid, gridDim.x), cwg = blockIdx.x - n_mid;
-    constexpr uint32_t WPW = Cfg::THREADS / WAVE;
-    const uint32_t wv = threadIdx.x >> 6;
-    const int lane = lane_id();
-    const unsigned long long lt = lanemask_lt();
-    const unsigned long long t0 = wall_clock64();
-    // item i → consumer workgroup i mod ncwg, wave (i / ncwg) mod WPW: consecutive items spread over the workgroups first
-    for (uint32_t i = cwg + wv * ncwg; ; i += ncwg * WPW) {
-        const Item<T>* it = &a.small[i];
-        bool have = false, over = false;
-        while (true) {
-            uint32_t stamp = 0, done = 0, total = 0;
-            if (lane == 0) {
-                stamp = ld_dev(&it->_r1);
-                if (stamp != a.gen) { done = ld_dev(&a.ctr[CTR_MID_DONE]); if (done >= gridDim.x) { total = ld_dev(&a.ctr[CTR_SMALL]); stamp = ld_dev(&it->_r1); } }
-            }
-            stamp = __builtin_amdgcn_readfirstlane(stamp); done = __builtin_amdgcn_readfirstlane(done); total = __builtin_amdgcn_readfirstlane(total);
-            if (stamp == a.gen) { have = true; break; }
-            if (done >= gridDim.x && i >= total) { over = true; break; }   // every producer is through and the queue ends before item i
-            if (wall_clock64() - t0 > LOWER_TIMEOUT_TICKS) {
-                if (lane == 0) { atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_LOWER_TIMEOUT); atomicAdd(&a.ctr[6], 1u); atomicMin(&a.ctr[7], i + 1u); atomicMax(&a.ctr[8], i + 1u); a.ctr[9] = stamp; }
-                over = true; break;
-            }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        if (over || !have) break;
-        small_body<T, true>(a, it, i, 0u, 0u, lane, lt, 0ull);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // host driver.  build_enqueue puts the whole optimistic schedule (and the counter readback) on the stream without
 // a host round trip; build_finalize waits for it, validates the input contract and finishes an unbalanced tree level by
@@ -2069,7 +1966,6 @@ template <typename T> static BuildArgs<T> make_args(bvhgpu_tree* t, const T* src
     a.ctr = t->ctr.as<uint32_t>();
     a.rootkeys = reinterpret_cast<Key*>(reinterpret_cast<char*>(t->ctr.p) + ROOTKEY_OFF);
     a.n = (uint32_t)t->n;
-    a.gen = (uint32_t)(t->gen % 0xFFFFFFFEull) + 1u;
     a.prep_wgs = 0;
     const bool small_scene = t->n <= MID_SCENE_SPLIT;
     a.mid_max = (uint32_t)(small_scene ? MidSmallScene<T>::MAXN : MidLargeScene<T>::MAXN);
@@ -2124,34 +2020,10 @@ template <typename T> static void run_level(bvhgpu_tree* t, const BuildArgs<T>& 
     hipLaunchKernelGGL(k_bin<T>, dim3(g.tile_grid), dim3(256), 0, st, a, L);
     hipLaunchKernelGGL(k_split<T>, dim3(g.sel_grid + g.tile_grid), dim3(256), 0, st, a, L, (uint32_t)g.sel_grid);
 }
-// how many workgroups of k_lower are resident at once on this device (its consumers wait for its producers: the grid must not exceed it)
-template <typename T> static int lower_resident(const bvhgpu_ctx* ctx) {
-    static thread_local int cache[16] = {};
-    int& c = cache[ctx->device & 15];
-    if (c == 0) {
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_lower<T, MidSmallScene<T>>),
-                                                         MidSmallScene<T>::THREADS, 0) != hipSuccess) per_cu = 0;
-        c = per_cu > 0 ? per_cu * ctx->n_cu : -1;
-    }
-    return c;
-}
 // workgroup tier over the items queued from `mid2_done` on, then the wave tier from `small_done` on
 template <typename T> static void run_lower_tiers(bvhgpu_tree* t, const BuildArgs<T>& a, const BuildGrid<T>& g, uint32_t mid2_done,
                                                   uint32_t small_done) {
     hipStream_t st = t->ctx->stream;
-    // both tiers in one launch (k_lower): the optimistic schedule of scenes up to MID_SCENE_SPLIT shapes
-    if (t->ctx->tune[BVHGPU_TUNE_BUILD_LOWER_FUSED] > 0 && mid2_done == 0u && small_done == 0u && t->n > (size_t)SMALL_MAX && t->n <= MID_SCENE_SPLIT) {
-        const int resident = lower_resident<T>(t->ctx);
-        int grid = std::min(g.mid2_grid, resident);
-        if (t->ctx->tune[BVHGPU_TUNE_BUILD_LOWER_FUSED] > 1) grid = std::min(grid, t->ctx->tune[BVHGPU_TUNE_BUILD_LOWER_FUSED]);   // (developer: cap)
-        if (std::getenv("BVHGPU_DEBUG_LOWER")) fprintf(stderr, "k_lower: resident %d mid2_grid %d grid %d\n", resident, g.mid2_grid, grid);
-        // (every workgroup-tier item needs a workgroup that is resident from the start, and the consumers need room beside them)
-        if (grid >= 2 * (int)(t->n / (MidSmallScene<T>::MAXN / 2) + 1)) {
-            hipLaunchKernelGGL((k_lower<T, MidSmallScene<T>>), dim3(grid), dim3(MidSmallScene<T>::THREADS), 0, st, a);
-            return;
-        }
-    }
     if (t->n > (size_t)SMALL_MAX) {
         if (t->n <= MID_SCENE_SPLIT) hipLaunchKernelGGL((k_mid<T, MidSmallScene<T>>), dim3(g.mid2_grid), dim3(MidSmallScene<T>::THREADS), 0, st, a, mid2_done);
         else hipLaunchKernelGGL((k_mid<T, MidLargeScene<T>>), dim3(g.mid2_grid), dim3(MidLargeScene<T>::THREADS), 0, st, a, mid2_done);
@@ -2195,7 +2067,7 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
         t->tile_item[i].reserve(g.max_tiles * 4);
     }
     t->mid2.reserve(g.max_mid2 * sizeof(Item<T>));
-    if (t->small.reserve((n + 1) * sizeof(Item<T>))) BVH_HIP(hipMemsetAsync(t->small.p, 0, t->small.cap, st));   // (k_lower reads `_r1` stamps: never garbage)
+    t->small.reserve((n + 1) * sizeof(Item<T>));
     t->tile_cnt.reserve(g.max_tiles * NUM_BUCKETS * 4);
     if (t->ctr.reserve(ROOTKEY_OFF + (size_t)PREP_MAX_WG * STAT_KEYS * sizeof(Key))) t->ctr_ready = false;   // a fresh buffer has not been zeroed by the previous build
     if (!t->pin) BVH_HIP(hipHostMalloc(&t->pin, ROOTKEY_OFF, hipHostMallocDefault));
@@ -2267,37 +2139,14 @@ template <typename T> void build_finalize(bvhgpu_tree* t) {
         throw HipFail{hipErrorInvalidValue, "NONFINITE", __LINE__};
     }
     int level = t->pend_level;
-    const bool lower_timeout = (pin[CTR_FLAGS] & BUILD_FLAG_LOWER_TIMEOUT) != 0u;   // k_lower: a consumer wave gave up — wave-tier items are left over
-    if (lower_timeout && std::getenv("BVHGPU_DEBUG_LOWER"))
-        fprintf(stderr, "k_lower timeout: n %zu small %u mid2 %u mid_done %u flags %u dbg %u %u %u %u\n", n, pin[CTR_SMALL], pin[CTR_MID2], pin[CTR_MID_DONE], pin[CTR_FLAGS], pin[6], pin[7], pin[8], pin[9]);
-    if (lower_timeout && !(n > (size_t)MID_MAX && pin[CTR_LEVEL0 + 2 * lvl_slot(level)] != 0)) {
-        // finish with the wave tier's own kernel over ALL its items (re-doing a finished item rewrites the same nodes), flatten again
-        const BuildGrid<T> g(t, MID_MAX);
-        const BuildArgs<T> a = make_args<T>(t, nullptr);
-        pin[CTR_FLAGS] &= ~BUILD_FLAG_LOWER_TIMEOUT;
-        BVH_HIP(hipMemcpyAsync(a.ctr, t->pin, ROOTKEY_OFF, hipMemcpyHostToDevice, st));   // (the counters were zeroed behind the readback)
-        t->ctr_ready = false;
-        hipLaunchKernelGGL(k_small<T>, dim3(g.small_grid), dim3(256), 0, st, a, 0u);
-        hipLaunchKernelGGL(k_publish_build<T>, dim3(1), dim3(256), 0, st, a, reinterpret_cast<uint32_t*>(t->pin));
-        t->ctr_ready = true;
-        if (t->pend_flatten) {
-            BVH_HIP(hipMemsetAsync(t->wslot_node.p, 0xFF, WIDE_SLOTS * 4, st));
-            BVH_HIP(hipMemsetAsync(t->slot_entry.p, 0xFF, TopCfg<T>::SLOTS * 4, st));
-            flatten_tree<T>(t);
-        }
-        BVH_HIP(hipStreamSynchronize(st));
-        BVH_HIP(hipGetLastError());
-        t->redone_gen = t->gen;
-    }
     if (n > (size_t)MID_MAX && pin[CTR_LEVEL0 + 2 * lvl_slot(level)] != 0) {
         // slow path: the level queue is not empty yet (unbalanced tree) — one more level per host round trip.  The counters
         // were zeroed behind the readback: put them back first.
         const BuildGrid<T> g(t, MID_MAX);
         const BuildArgs<T> a = make_args<T>(t, nullptr);
-        pin[CTR_FLAGS] &= ~BUILD_FLAG_LOWER_TIMEOUT;
         BVH_HIP(hipMemcpyAsync(a.ctr, t->pin, ROOTKEY_OFF, hipMemcpyHostToDevice, st));
         t->ctr_ready = false;
-        uint32_t mid2_done = pin[CTR_MID2], small_done = lower_timeout ? 0u : pin[CTR_SMALL];   // (after a k_lower time-out every wave-tier item is redone)
+        uint32_t mid2_done = pin[CTR_MID2], small_done = pin[CTR_SMALL];
         while (true) {
             if (level + 1 >= MAXLV - 2)  // recycle the slot the next level will append to
                 BVH_HIP(hipMemsetAsync(a.ctr + CTR_LEVEL0 + 2 * lvl_slot(level + 1), 0, 8, st));

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BVHGPU_ABI_VERSION 5 /* 5: bvhgpu_rccl_info, bvhgpu_timings.ray_convert_ms, BVHGPU_TUNE_COUNT 16 (slot 15 = BUILD_LOWER_FUSED).  4: BVHGPU_TUNE_COUNT 15 (slot 14 = WIDE_F64_GUIDE), bvhgpu_hits_walk_info.  3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 14 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT, 13 = WIDE_REC8), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
+#define BVHGPU_ABI_VERSION 5 /* 5: bvhgpu_rccl_info, bvhgpu_timings.ray_convert_ms.  4: BVHGPU_TUNE_COUNT 15 (slot 14 = WIDE_F64_GUIDE), bvhgpu_hits_walk_info.  3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 14 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT, 13 = WIDE_REC8), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
 #define BVHGPU_NONE 0xFFFFFFFFu /* u32::MAX marker (flat_bvh.rs:51-53, :124, :137) */
 
 typedef enum {
@@ -376,10 +376,7 @@ typedef enum {
                                               candidates in f64 — the hit lists are the same, the walk runs at the f32 rate; a batch with a ray outside
                                               the range the argument covers (|origin| > 3 x scene, |1/d| x scene outside 2^+-100, non-finite) is replayed
                                               with the f64 walk and the result object stays with it; 0 = always the f64 walk */
-    BVHGPU_TUNE_BUILD_LOWER_FUSED = 15,    /* builder, scenes up to 250 k shapes: 1 = workgroup tier and wave tier in ONE launch (k_lower: the wave tier's items are picked
-                                              up by consumer waves of the same launch as soon as the workgroup tier has written them through), 0 = two launches
-                                              (k_mid, k_small); default -1 = the measured choice */
-    BVHGPU_TUNE_COUNT = 16
+    BVHGPU_TUNE_COUNT = 15
 } bvhgpu_tune;
 int bvhgpu_set_tuning(bvhgpu_ctx *ctx, int knob, int value);
 int bvhgpu_get_tuning(const bvhgpu_ctx *ctx, int knob, int *value);
