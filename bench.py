@@ -550,7 +550,9 @@ def main():
     from bvh_amd._lib import TRAVERSE_RAYS_READY as RAYS_READY
     from bvh_amd.api import _Hits
 
-    # the engine enqueues on torch's current stream: torch events / synchronize see all of it
+    # the engine enqueues on torch's current stream when that is a stream of its own; torch's DEFAULT stream has handle 0, for which
+    # the ctx creates a non-blocking stream of its own — either way the timed region is bracketed by torch.cuda.synchronize(dev)
+    # (device-wide), and everything the engine does for one step is on that one stream
     stream = torch.cuda.current_stream(dev)
     ctx = Context(local_rank, stream=stream.cuda_stream)
     for k, v in os.environ.items():   # developer A/B runs: BVH_TUNE_<knob number>=<value> (tools/ab_tune.sh); results never depend on a knob

@@ -234,9 +234,16 @@ class LocalCommunicator:
 def broadcast_scene(blob, src: int = 0):
     """Fallback transport: broadcast the scene blob tensor in place with torch.distributed (uint8 tensor on the GPU for
     nccl/RCCL, CPU for gloo)."""
+    import torch
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.broadcast(blob, src)
+        # The receive lands on torch's stream; bvhgpu_scene_import reads the blob on the ctx's stream, which is another one unless the ctx
+        # was created on torch's (a ctx made on the DEFAULT stream — handle 0 — gets a stream of its own).  This transport is the
+        # host-synchronised fallback anyway: wait for the blob.  (Found by an 8-rank rehearsal on one GPU: a peer imported a blob that
+        # had not arrived yet — "not a bvhgpu scene blob".)
+        if getattr(blob, "is_cuda", False):
+            torch.cuda.current_stream(blob.device).synchronize()
     return blob
 
 

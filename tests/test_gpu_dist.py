@@ -144,6 +144,28 @@ def test_bench_exchange_plan_cannot_take_the_line_down():
     assert out["scene_dist_plans"]["replicate"]["hits_all_ranks"] == out["scene_dist_plans"]["bcast-torch"]["hits_all_ranks"]
 
 
+def test_bench_four_ranks_share_the_gpu():
+    """More ranks than the two-rank tests: four processes on cuda:0 over gloo, both plans (the 8-rank rehearsal of round 4 found a peer
+    importing a scene blob that had not arrived yet — the torch transport now waits for it)."""
+    import bvh_amd
+    if bvh_amd.device_count() <= 0:
+        pytest.fail("GPU test selected but no HIP device is visible (no CPU fallback exists)")
+    cubes, R = 3000, 50_000
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "4", "--warmup", "2", "--cubes", str(cubes),
+           "--rays", str(R), "--backend", "gloo", "--one-device", "--no-extra"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 4 and out["launch"]["ranks_seen"] == 4 and out["parity"]["equal"] is True
+    assert set(out["scene_dist_plans"]) == {"replicate", "bcast-torch"}
+    from bvh_amd import testbase as tb
+    from oracle import orc
+    _, aabbs = tb.create_n_cubes(cubes)
+    off, idx, _, _ = orc.traverse_flat(orc.flatten(orc.build(aabbs).nodes), aabbs, orc.create_rays(0, 4 * R))
+    assert out["scene_dist_plans"]["replicate"]["hits_all_ranks"] == out["scene_dist_plans"]["bcast-torch"]["hits_all_ranks"] == len(idx)
+
+
 def test_rccl_info_names_the_one_rccl_of_the_process():
     """bvhgpu_rccl_info names the RCCL the C ABI resolved (the copy torch already holds must be shared, not a second one),
     and a communicator reports its own size."""
