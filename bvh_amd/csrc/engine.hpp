@@ -157,7 +157,8 @@ struct bvhgpu_hits {
     bool pend_staged = false;
     bool pend_rec8 = false, no_rec8 = false;   // 8-byte pool records in the batch in flight / never again for this result object
     bvhgpu::DevBuf guide_rays;                 // f64 batches walked over the tree's f32 guide boxes: the batch as f32 rays (traverse.hip "guide walk")
-    bool pend_guide = false, no_guide = false; // guide walk in the batch in flight / never again for this result object (a ray was out of its range)
+    bool pend_guide = false, no_guide = false; // guide walk in the batch in flight / the batch is being replayed in f64 (a ray was out of the guide's range)
+    uint32_t guide_backoff = 0, guide_skip = 0; // f64 index batches that skip the guide after such a replay: 1, 2, 4 … 64 on consecutive failures / still to skip
     bool ctr_clean = false;  // the counters were zeroed behind the previous call's readback
     int ctr_set = 0;         // which of the two counter sets the next batch uses
     int bsum_set = 0;        // likewise for the wide walk's scan-block sums

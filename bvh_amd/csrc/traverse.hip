@@ -1715,8 +1715,18 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
                              t->ev_top_gen == t->gen && ctx->tune[BVHGPU_TUNE_WIDE_EARLY_ITEMS] != 0;
     // f64 index batches: the f32 walk over the tree's guide boxes, leaf candidates confirmed in f64 (k_guide_rays; a result object that met
     // a ray outside the guide walk's range stays with the f64 walk)
-    const bool use_guide = sizeof(T) == 8 && use_wide && mode == MODE_INDICES && t->has_guide && !h->no_guide && !early_items &&
-                           ctx->tune[BVHGPU_TUNE_WIDE_F64_GUIDE] != 0;
+    // A result object that met a ray outside the guide walk's range backs off: the next `guide_skip` f64 index batches take the f64 walk
+    // straight away (1, 2, 4 … 64 batches on consecutive failures — a workload of axis-parallel rays pays one wasted guide walk in 65),
+    // then the guide is tried again; a batch that stays in range resets the back-off (the fall-back used to be for ever).
+    const bool guide_ok = sizeof(T) == 8 && use_wide && mode == MODE_INDICES && t->has_guide && !early_items && ctx->tune[BVHGPU_TUNE_WIDE_F64_GUIDE] != 0;
+    const bool replaying_out_of_range = h->no_guide;      // traverse_check sent this very batch back
+    if (guide_ok && !replaying_out_of_range && h->guide_skip > 0) h->guide_skip--;
+    const bool use_guide = guide_ok && !replaying_out_of_range && h->guide_skip == 0;
+    if (replaying_out_of_range) {
+        h->no_guide = false;
+        h->guide_backoff = h->guide_backoff ? std::min(2 * h->guide_backoff, 64u) : 1u;
+        h->guide_skip = h->guide_backoff + 1u;             // (+1: the decrement of the next batch's enqueue)
+    }
     h->pend_guide = use_guide;
     const size_t n_items = split_at ? 2 * n_rays : n_rays;
     h->ctx = ctx; h->dtype = Traits<T>::dtype; h->n_rays = n_rays; h->flags = flags; h->total = 0;
@@ -1975,7 +1985,7 @@ bool traverse_check(bvhgpu_hits* h) {
     }
     if (ordered && (pin[7] & 1ull)) throw HipFail{hipErrorInvalidValue, "ORDERED_DEPTH", __LINE__};
     if (h->pend_guide && (pin[7] & WALK_FLAG_GUIDE_RANGE)) {   // a ray outside the guide walk's range: this result object goes back to the f64 walk
-        h->no_guide = true; h->wcounts_clean = false; return false;
+        h->no_guide = true; h->wcounts_clean = false; return false;   // (the replay of this batch walks in f64; traverse_enqueue sets the back-off)
     }
     if (h->pend_rec8 && (pin[7] & 8ull)) {   // a ray with 128+ hits (or a shape index beyond 2^25): this result object goes back to 12-byte records
         h->no_rec8 = true; h->wcounts_clean = false; return false;
@@ -2009,6 +2019,7 @@ bool traverse_check(bvhgpu_hits* h) {
         h->idx_cap = (size_t)total + (size_t)total / 8 + 1024;
         return false;
     }
+    if (h->pend_guide) h->guide_backoff = 0;   // an f64 batch that stayed inside the guide walk's range
     h->total = total;
     h->stats.hits = total;
     if (stats) {

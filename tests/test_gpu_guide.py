@@ -101,7 +101,23 @@ def test_ray_outside_the_guide_range_replays_in_f64(eng, orc):
         off, idx, st = _csr(eng, flat, rays)
         assert st["walk"] & WALK_WIDE and not st["walk"] & WALK_F64_GUIDE   # replayed with the f64 walk
         assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
-    # the tree's result object stays with the f64 walk; a fresh tree object walks its guide again
+    # the result object backs off — 1, 2, 4 … batches in f64 after consecutive out-of-range batches — and then tries its guide again
+    # (round 4: the fall-back used to be for ever)
+    ooff, oidx = _oracle(orc, aabbs, good)
+
+    def guided(r):
+        off, idx, st = _csr(eng, flat, r)
+        if r is good:
+            assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+        return bool(st["walk"] & WALK_F64_GUIDE)
+    # (above: `far` failed → one batch of back-off, which the `axis` batch used up in f64) → the guide is back
+    assert guided(good) and guided(good)
+    bad = np.concatenate([good[:100], axis, good[100:]])
+    assert not guided(bad)                                 # out of range: replayed in f64, back-off one batch
+    assert [guided(good), guided(good)] == [False, True]
+    assert not guided(bad) and not guided(good)            # fails (1 batch of back-off, used up by the good batch) …
+    assert not guided(bad)                                 # … the guide is tried, fails again: second failure in a row → two batches
+    assert [guided(good), guided(good), guided(good)] == [False, False, True]
     flat2 = eng.Bvh.from_aabbs(aabbs).flatten()
     ooff, oidx = _oracle(orc, aabbs, good)
     off, idx, st = _csr(eng, flat2, good)
