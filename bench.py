@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--collective-timeout", type=float, default=60.0,
                     help="N>1, --scene-dist auto: seconds the exchange plan (RCCL communicator + broadcast steps) may take before the line "
                          "measured with the replicate plan is printed and the run ends")
+    ap.add_argument("--settle-steps", type=int, default=300,
+                    help="untimed steps before the W warmup steps (clock ramp after start-up: ~0.1 s of the headline step; at most 20 for batches above 2 M rays)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs sub-runs")
     ap.add_argument("--no-parity", action="store_true")
@@ -349,6 +351,11 @@ def run_workload(wl, args, env, steps, warmup, detailed, force_plan=None):
             step(); step()
             probe_ms[pl] = timed(5) / 5 * 1e3
         state["plan"] = min(plans, key=lambda q: probe_ms[q])
+    # Settle the GPU's clocks before the W warmup steps: a 0.34 ms step timed over K = 20 steps right after start-up reads 2 % low
+    # (0.3417 against 0.334–0.337 ms over K >= 100).  Untimed, the same step, a fixed count on every rank (no collective decides it).
+    # (plans with an exchange step — a collective per step, possibly the slow torch transport — and big batches settle in 20 steps)
+    for _ in range(args.settle_steps if (wl.R <= 2_000_000 and state["plan"] in ("single", "replicate")) else min(args.settle_steps, 20)):
+        step()
     for _ in range(warmup):
         step()
     elapsed = timed(steps)
