@@ -1514,6 +1514,9 @@ __global__ __launch_bounds__(256) void k_hits_scatter8(const uint2* __restrict__
 #ifndef GATHER_RAYS
 #define GATHER_RAYS 1
 #endif
+#ifndef BVH_GATHER_LDS
+#define BVH_GATHER_LDS 1
+#endif
 template <int SHIFT>
 __global__ __launch_bounds__(256) void k_hits_gather_staged(const uint32_t* __restrict__ raybuf, const uint32_t* __restrict__ offsets, uint32_t n_rays,
                                                             const unsigned long long* __restrict__ ctr, unsigned long long idx_cap,
@@ -1537,6 +1540,38 @@ __global__ __launch_bounds__(256) void k_hits_gather_staged(const uint32_t* __re
             if (4u * q < cnt[u]) { const uint4 x = src[q]; v[u][4 * q] = x.x; v[u][4 * q + 1] = x.y; v[u][4 * q + 2] = x.z; v[u][4 * q + 3] = x.w; }
         }
     }
+#if BVH_GATHER_LDS
+    // The workgroup's rays are consecutive, so their CSR ranges form ONE contiguous span of indices[] (≈ 6 shapes x 256 rays = 6 KB on
+    // configs[2]).  Written straight from the lanes, a store instruction scatters 64 dwords over that span and the L2 evicts partial
+    // lines (PMC: 353 MB written for 165 MB of hits); staged through LDS the span goes out as whole 256-byte rows.  Positions k >= CAP
+    // of a long ray are not the slot's: they are left out here and written by k_hits_scatter8 (which runs behind this kernel).
+    if (R == 1) {
+        constexpr uint32_t SPAN_MAX = 4096;                     // entries of the staging buffer (16 KB); a denser workgroup stores directly
+        __shared__ uint32_t s_out[SPAN_MAX];
+        __shared__ uint32_t s_base, s_span;
+        const uint32_t r0 = blockIdx.x * blockDim.x;
+        if (threadIdx.x == 0) {
+            const uint32_t r1 = min(r0 + blockDim.x, n_rays);
+            s_base = r0 < n_rays ? offsets[r0] : 0u;
+            s_span = r0 < n_rays ? offsets[r1] - s_base : 0u;
+        }
+        __syncthreads();
+        const uint32_t base = s_base, span = s_span;
+        if (span <= SPAN_MAX) {                                 // (workgroup-uniform)
+            for (uint32_t p = threadIdx.x; p < span; p += blockDim.x) s_out[p] = NONE;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t k = 0; k < CAP; k++)
+                if (k < cnt[0]) s_out[o0[0] - base + k] = v[0][k];
+            __syncthreads();
+            for (uint32_t p = threadIdx.x; p < span; p += blockDim.x) {
+                const uint32_t x = s_out[p];
+                if (x != NONE) indices[base + p] = x;           // (NONE: a long ray's later hits — k_hits_scatter8's)
+            }
+            return;
+        }
+    }
+#endif
 #pragma unroll
     for (uint32_t u = 0; u < R; u++) {
 #pragma unroll

@@ -4,7 +4,7 @@
 out=$1; args=$2; A=$3; B=$4; reps=${5:-2}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-: > $out
+mkdir -p $(dirname $out); : > $out
 for rep in $(seq $reps); do
   for so in "$A" "$B"; do
     if [ "$so" = "-" ]; then unset BVH_AMD_SO; else export BVH_AMD_SO=$R/$so; fi
