@@ -1053,8 +1053,12 @@ def test_fuzz_all_queries(eng, orc, seed):
     wctx.set_tuning(TUNE_BUILD_LEVEL_LAUNCHES, 1 + seed % 2)
     wb = eng.Bvh.from_aabbs(aabbs, wctx)
     assert wb.nodes.tobytes() == ot.nodes.tobytes()
-    woff, widx, _, _ = wb.flatten().traverse_batch(eng.RayBatch(len(rays), dtype, host=np.ascontiguousarray(rays)))
+    wflat = wb.flatten()
+    woff, widx, _, _ = wflat.traverse_batch(eng.RayBatch(len(rays), dtype, host=np.ascontiguousarray(rays)))
     assert np.array_equal(woff, ooff) and np.array_equal(widx, oidx)
+    if (seed // 2) % 3 == 0:   # whole rays: also the staged hand-over of COHERENT batches (per-ray slots, the slot copy through LDS, 8-byte records)
+        woff, widx, _, _ = wflat.traverse_batch(eng.RayBatch(len(rays), dtype, host=np.ascontiguousarray(rays)), coherent=True)
+        assert np.array_equal(woff, ooff) and np.array_equal(widx, oidx)
     oisect, oclosest, oprim = orc.triangle_stage(tri, rays, ooff, oidx)
     _, _, isect, _ = flat.intersect_triangles(rb)
     cl, prim, _ = flat.closest_hits(rb)
