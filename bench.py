@@ -367,7 +367,7 @@ def run_workload(wl, args, env, steps, warmup, detailed, force_plan=None):
     ctx.enable_timing(True)
     builder = plan not in ("bcast", "bcast-torch") or rank == 0
     tree = bvh if builder else state["peer"]
-    ph = dict(build_ms=[], flatten_ms=[], traverse_kernel_ms=[], traverse_total_ms=[], ray_convert_ms=[])
+    ph = dict(build_ms=[], flatten_ms=[], traverse_kernel_ms=[], traverse_total_ms=[])
     stats_walk = 0
     for _ in range(max(5, min(steps, 20))):
         if builder:
@@ -427,7 +427,7 @@ def run_workload(wl, args, env, steps, warmup, detailed, force_plan=None):
     }
     if wl.dtype_name == "f64":
         roof["f64_walk"] = ("guide: inner-node tests in f32 on boxes that contain the f64 ones, every leaf candidate decided by the f64 slab test "
-                            "(kernel_ms excludes the f32 ray copy, phases_ms.ray_convert_ms)" if guide_ran else
+                            "(the f64 rays are converted where the walk loads them: no separate copy pass)" if guide_ran else
                             "pure f64: every slab test of the walk in double precision (BVHGPU_TUNE_WIDE_F64_GUIDE = 0); valu_frac prices every "
                             "wave64 VALU instruction at 2 cycles, f64 arithmetic issues at half that rate, so it understates this kernel's VALU share by up to 2x")
     if pmc is not None:

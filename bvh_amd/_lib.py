@@ -57,7 +57,7 @@ class TraverseStats(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [("build_ms", C.c_float), ("flatten_ms", C.c_float), ("traverse_kernel_ms", C.c_float),
-                ("traverse_total_ms", C.c_float), ("ray_convert_ms", C.c_float)]
+                ("traverse_total_ms", C.c_float)]
 
 
 # every symbol include/bvh_mi355x.h declares: (name, restype, argtypes)

@@ -108,7 +108,7 @@ class Context:
         t = _lib.Timings()
         check(_lib.load().bvhgpu_last_timings(self._h, C.byref(t)), self._h)
         return dict(build_ms=t.build_ms, flatten_ms=t.flatten_ms, traverse_kernel_ms=t.traverse_kernel_ms,
-                    traverse_total_ms=t.traverse_total_ms, ray_convert_ms=t.ray_convert_ms)
+                    traverse_total_ms=t.traverse_total_ms)
 
     def set_tuning(self, knob: int, value: int):
         """performance knobs (include/bvh_mi355x.h bvhgpu_tune); results never change."""

@@ -961,7 +961,7 @@ void bvhgpu_hits_destroy(bvhgpu_hits* h) {
     h->indices.release(); h->tslice.release(); h->blocksums.release(); h->scan_sums.release(); h->ctr.release();
     h->isect.release(); h->closest.release(); h->closest_prim.release();
     h->heap_dist.release(); h->heap_node.release();
-    h->wg_items.release(); h->raybuf.release(); h->guide_rays.release();
+    h->wg_items.release(); h->raybuf.release();
     if (h->ev_items) (void)hipEventDestroy(h->ev_items);
     h->wcounts.release(); h->ray_mask.release(); h->item_cnt.release(); h->wstack.release(); h->ray_items.release(); h->witems.release();
     if (h->pin) (void)hipHostFree(h->pin);
@@ -981,11 +981,8 @@ int bvhgpu_last_timings(bvhgpu_ctx* ctx, bvhgpu_timings* out) {
         if (ctx->ev_set & 1u) (void)hipEventElapsedTime(&ctx->last.build_ms, ctx->ev[0], ctx->ev[1]);
         if (ctx->ev_set & 2u) (void)hipEventElapsedTime(&ctx->last.flatten_ms, ctx->ev[2], ctx->ev[3]);
         if (ctx->ev_set & 4u) {
-            // (ev[7]: behind the f32 ray copy of an f64 guide walk — the copy counts towards the total, not towards the walk kernel)
-            (void)hipEventElapsedTime(&ctx->last.traverse_kernel_ms, (ctx->ev_set & 8u) ? ctx->ev[7] : ctx->ev[4], ctx->ev[5]);
+            (void)hipEventElapsedTime(&ctx->last.traverse_kernel_ms, ctx->ev[4], ctx->ev[5]);
             (void)hipEventElapsedTime(&ctx->last.traverse_total_ms, ctx->ev[4], ctx->ev[6]);
-            ctx->last.ray_convert_ms = 0.0f;
-            if (ctx->ev_set & 8u) (void)hipEventElapsedTime(&ctx->last.ray_convert_ms, ctx->ev[4], ctx->ev[7]);
         }
         *out = ctx->last;
         return (int)BVHGPU_OK;

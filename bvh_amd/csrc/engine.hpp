@@ -51,7 +51,7 @@ struct bvhgpu_ctx {
     bool timing = false;
     hipEvent_t ev[8] = {};
     unsigned ev_set = 0;  // bit0 build pair recorded, bit1 flatten, bit2 traverse
-    bvhgpu_timings last = {0, 0, 0, 0, 0};
+    bvhgpu_timings last = {0, 0, 0, 0};
     // scratch
     bvhgpu::DevBuf upload;    // staging for host→device inputs (aabbs / rays)
     bvhgpu::DevBuf counters;  // small device counters
@@ -156,7 +156,6 @@ struct bvhgpu_hits {
     bvhgpu::DevBuf raybuf;   // staged output of the wide walk: 2^shift shape indices per ray (traverse.hip WalkOut::raybuf)
     bool pend_staged = false;
     bool pend_rec8 = false, no_rec8 = false;   // 8-byte pool records in the batch in flight / never again for this result object
-    bvhgpu::DevBuf guide_rays;                 // f64 batches walked over the tree's f32 guide boxes: the batch as f32 rays (traverse.hip "guide walk")
     bool pend_guide = false, no_guide = false; // guide walk in the batch in flight / the batch is being replayed in f64 (a ray was out of the guide's range)
     uint32_t guide_backoff = 0, guide_skip = 0; // f64 index batches that skip the guide after such a replay: 1, 2, 4 … 64 on consecutive failures / still to skip
     bool ctr_clean = false;  // the counters were zeroed behind the previous call's readback

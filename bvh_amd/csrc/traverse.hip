@@ -142,6 +142,11 @@ template <typename T, int MODE> struct LaneRay {
         best_prim = NONE; r = ray; cnt = 0;
         fin = ray_is_finite<T>(o, inv);
     }
+    // o / inv were filled by the caller (the guide walk's f32 view of an f64 ray): the rest of load()
+    __device__ __forceinline__ void loaded(uint32_t ray) {
+        best_prim = NONE; r = ray; cnt = 0;
+        fin = ray_is_finite<T>(o, inv);
+    }
     // the ray has left the tree: its Vec / closest hit is complete
     __device__ __forceinline__ void retire(const WalkOut<T>& w) {
         if (MODE == MODE_CLOSEST) {
@@ -872,18 +877,31 @@ template <int ITEMS_LOG4> __device__ __forceinline__ uint32_t item_slot(uint32_t
 // wave and list end).  Items whose ray stays long inside their subtree's box (long walks expected) fill the list from the
 // front, the others from the back — the walk draws from the front, so that the longest chains start first instead of setting
 // the end of the launch.  Called by the walk's prologue or, earlier and beside the build, by k_wide_items.
-template <typename T, int L4>
+struct GuideArgs;
+__device__ __forceinline__ void guide_ray_load(const bvhgpu_ray_f64* __restrict__ rays64, uint32_t r, double S, float o[3], float inv[3], bool& bad);
+// rays64 != NULL (GUIDE, T = float): the batch is an f64 one — every ray is converted where it is loaded (guide_ray_load) and *any_bad
+// collects whether one of them lies outside the guide walk's range
+template <typename T, int L4, bool GUIDE = false>
 __device__ __forceinline__ void filter_rays_into_list(const ItemTable<T>* tb, const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_rays,
                                                       uint32_t* __restrict__ list, uint32_t per_wg, uint32_t my_rays, uint32_t G, uint32_t b,
-                                                      uint32_t tid, uint32_t bd, int lane, uint32_t* s_nlist, uint32_t* s_nback) {
+                                                      uint32_t tid, uint32_t bd, int lane, uint32_t* s_nlist, uint32_t* s_nback,
+                                                      const bvhgpu_ray_f64* __restrict__ rays64 = nullptr, double guide_S = 0.0, bool* any_bad = nullptr) {
     constexpr uint32_t ITEMS = 1u << (2 * L4);
     for (uint32_t l0 = 0; l0 < my_rays; l0 += bd) {   // workgroup-uniform
         const uint32_t local = l0 + tid;
         const uint32_t r = local < my_rays ? ((((local >> 6) * G + b) << 6) | (local & 63u)) : n_rays;
         uint32_t mask = 0, longm = 0;
         if (r < n_rays) {
-            const typename Traits<T>::Ray* rp = rays + r;
-            const T o[3] = {rp->o[0], rp->o[1], rp->o[2]}, inv[3] = {rp->inv[0], rp->inv[1], rp->inv[2]};
+            T o[3], inv[3];
+            if constexpr (GUIDE) {
+                bool bad;
+                guide_ray_load(rays64, r, guide_S, o, inv, bad);
+                *any_bad = *any_bad || bad;
+            } else {
+                const typename Traits<T>::Ray* rp = rays + r;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { o[k] = rp->o[k]; inv[k] = rp->inv[k]; }
+            }
             if (!ray_is_finite<T>(o, inv)) {
                 mask = 1u << WIDE_ITEM_WHOLE; longm = mask;
             } else {
@@ -981,36 +999,26 @@ __global__ __launch_bounds__(256) void k_wide_items(const typename Traits<T>::No
 
 // ---- guide walk: an f64 index batch walked over the tree's f32 guide boxes (common.hpp "guide boxes") -----------------------------------
 // The f64 wide walk costs 1.9 x the f32 one (half-rate VALU, 13 instead of 7 chunks per node).  Only leaf tests decide a ray's list
-// (monotonicity), so every inner test may be conservative: k_guide_rays writes the batch as f32 rays (round to nearest) and
+// (monotonicity), so every inner test may be conservative: the walk converts every f64 ray to f32 (round to nearest) where it loads it (guide_ray_load) and
 // flags rays the containment argument does not cover; the f32 wide walk then runs over `wide_guide` unchanged, except that a leaf
 // CANDIDATE is confirmed by the f64 slab test of the shape's own f64 box with the f64 ray before it is reported.  Same lists, same order.
 constexpr unsigned long long WALK_FLAG_GUIDE_RANGE = 16ull;   // ctr[7] bit: a ray was outside the guide walk's range — the host replays in f64
-struct GuideArgs { const bvhgpu_ray_f64* rays64; const double* aabbs64; };
-__global__ __launch_bounds__(256) void k_guide_rays(const bvhgpu_ray_f64* __restrict__ in, uint32_t n, const float* __restrict__ guide_info,
-                                                    bvhgpu_ray_f32* __restrict__ out, uint32_t* __restrict__ flags) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    bool bad = false;
-    if (r < n) {
-        const double S = (double)guide_info[0];
-        const bvhgpu_ray_f64 q = in[r];
-        bvhgpu_ray_f32 o;
-        // The containment argument prices every f32 rounding at 2^-24 RELATIVE: that needs every quantity on the way to a plane's t in the
-        // NORMAL f32 range.  S >= 2^-125 keeps the growth 2^-18 S at 64+ denormal spacings (a smaller scene's coordinates round by up to
-        // 2^-150 absolutely, more than the growth covers); |1/d| must itself be a normal, finite f32 (the scale-relative
-        // test alone lets (float)inv overflow to inf on a very small scene, or underflow on a huge one, unflagged); |o| must fit f32;
-        // S <= 2^125 keeps every difference b32 - o32 (up to 4 S) finite.
-        bad = !(S >= GUIDE_SCENE_MIN) || !(S <= GUIDE_SCENE_MAX);
+struct GuideArgs { const bvhgpu_ray_f64* rays64; const double* aabbs64; const float* info; };   // info[0] = S (tree->guide_info)
+// The guide walk's f32 view of an f64 ray, made where the ray is loaded (round 4: a kernel of its own wrote an f32 copy of the batch first
+// — 72 B read + 36 B written per ray and a launch, 19-22 µs per 1 M rays): origin and 1/d rounded to nearest, and the range test of the
+// containment argument (common.hpp "guide boxes"); `bad` = the argument does not cover this ray.
+__device__ __forceinline__ void guide_ray_load(const bvhgpu_ray_f64* __restrict__ rays64, uint32_t r, double S, float o[3], float inv[3], bool& bad) {
+    const bvhgpu_ray_f64* q = rays64 + r;
+    bad = !(S >= GUIDE_SCENE_MIN) || !(S <= GUIDE_SCENE_MAX);
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const double ao = fabs(q.o[k]), ainv = fabs(q.inv[k]), ai = ainv * (4.0 * S);
-            // (NaN fails every comparison; S = 0 — a scene that is one point — leaves no room for the growth)
-            bad = bad || !(ao <= GUIDE_ORIGIN_MAX * S) || !(ao <= GUIDE_F32_MAX) || !(ai <= 0x1p100) || !(ai >= 0x1p-100) ||
-                  !(ainv <= GUIDE_F32_MAX) || !(ainv >= GUIDE_F32_MIN_NORMAL);
-            o.o[k] = (float)q.o[k]; o.d[k] = (float)q.d[k]; o.inv[k] = (float)q.inv[k];
-        }
-        out[r] = o;
+    for (int k = 0; k < 3; k++) {
+        const double ok = q->o[k], ik = q->inv[k];
+        const double ao = fabs(ok), ainv = fabs(ik), ai = ainv * (4.0 * S);
+        // (NaN fails every comparison; S = 0 — a scene that is one point — leaves no room for the growth)
+        bad = bad || !(ao <= GUIDE_ORIGIN_MAX * S) || !(ao <= GUIDE_F32_MAX) || !(ai <= 0x1p100) || !(ai >= 0x1p-100) ||
+              !(ainv <= GUIDE_F32_MAX) || !(ainv >= GUIDE_F32_MIN_NORMAL);
+        o[k] = (float)ok; inv[k] = (float)ik;
     }
-    if (__any(bad) && (threadIdx.x & 63u) == 0u) atomicOr(flags, (uint32_t)WALK_FLAG_GUIDE_RANGE);
 }
 // the f64 test of a leaf candidate (finite ray: the NaN-free form is exact, common.hpp slab_hit_finite)
 __device__ __forceinline__ bool guide_leaf_hit(const GuideArgs& ga, uint32_t ray, uint32_t shape) {
@@ -1057,6 +1065,11 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     const size_t G = (size_t)gridDim.x * bd, gid = (size_t)blockIdx.x * bd + tid;
     const int lane = lane_id();
     const unsigned long long lt = lanemask_lt();
+    // GUIDE: `rays` is unused — the batch is ga.rays64, every ray converted to f32 where it is loaded; guide_bad = one of this lane's
+    // rays was outside the range the containment argument covers (the wave raises WALK_FLAG_GUIDE_RANGE at the end: the host replays in f64)
+    double guide_S = 0.0;
+    bool guide_bad = false;
+    if constexpr (GUIDE != 0) guide_S = (double)ga.info[0];
 #ifdef BVH_WIDE_PROFILE
     const unsigned long long prof_t0 = wall_clock64();
     unsigned long long prof_steps = 0;
@@ -1107,7 +1120,9 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
         if (pre_front != NONE) {
             if (tid == 0) { s_nlist = pre_front; s_nback = wg_items[2u * blockIdx.x + 1u]; }
         } else {
-            filter_rays_into_list<T, L4>(&tb, rays, n_rays, list, per_wg, my_rays, gridDim.x, blockIdx.x, tid, bd, lane, &s_nlist, &s_nback);
+            if constexpr (GUIDE != 0) filter_rays_into_list<T, L4, true>(&tb, rays, n_rays, list, per_wg, my_rays, gridDim.x, blockIdx.x, tid, bd, lane, &s_nlist, &s_nback,
+                                                                            ga.rays64, guide_S, &guide_bad);
+            else filter_rays_into_list<T, L4>(&tb, rays, n_rays, list, per_wg, my_rays, gridDim.x, blockIdx.x, tid, bd, lane, &s_nlist, &s_nback);
         }
         __threadfence_block();
     }
@@ -1173,7 +1188,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                     if (ITEMS_LOG4 == 0) {
                         item = ray_of(mine);
                         if (item < n_rays) {
-                            ray.load(rays, item);
+                            if constexpr (GUIDE != 0) { bool bad; guide_ray_load(ga.rays64, item, guide_S, ray.o, ray.inv, bad); guide_bad = guide_bad || bad; ray.loaded(item); }
+                            else ray.load(rays, item);
                             cur = WIDE_INNER | WIDE_RESIDENT | 0u;   // the root is heap slot 0 (K >= 1)
                         } else {
                             item = NONE;                         // padding of the batch's last 64-ray block
@@ -1181,7 +1197,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                     } else {
                         item = list[mine < n_front ? mine : per_wg * ITEMS - 1u - (mine - n_front)];
                         const uint32_t j = item & ((1u << WIDE_ITEM_BITS) - 1u);
-                        ray.load(rays, item >> WIDE_ITEM_BITS);
+                        if constexpr (GUIDE != 0) { bool bad; guide_ray_load(ga.rays64, item >> WIDE_ITEM_BITS, guide_S, ray.o, ray.inv, bad); ray.loaded(item >> WIDE_ITEM_BITS); }   // (the filter has looked at its range)
+                        else ray.load(rays, item >> WIDE_ITEM_BITS);
                         cur = j == WIDE_ITEM_WHOLE ? (WIDE_INNER | WIDE_RESIDENT | 0u) : s_item_ref[j];
                         if (j == WIDE_ITEM_WHOLE) item = item & ~((1u << WIDE_ITEM_BITS) - 1u);   // filed under j = 0
                     }
@@ -1259,6 +1276,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
         if (ovf) { cur = CUR_NONE; sp = 0; }
     }
     if (__any(ovf) && lane == 0) atomicOr(overflow, 4u);
+    if constexpr (GUIDE != 0) { if (__any(guide_bad) && lane == 0) atomicOr(overflow, (uint32_t)WALK_FLAG_GUIDE_RANGE); }
     if (MODE == MODE_INDICES && ITEMS_LOG4 == 0 && w.pool8) {
         if (__any(rec8_big) && lane == 0) atomicOr(overflow, 8u);   // a hit did not fit the 8-byte record: the host replays with HitRec
         pool_invalidate_tail8(w.pool8, w.pool_cap, pc, lane);
@@ -1662,10 +1680,10 @@ template <typename T> struct WideGeom {
 };
 constexpr uint32_t WIDE_GSTACK = 24;   // stack entries per lane beyond the LDS part, in HBM (a walk pushes at most 3 per wide level)
 
-// GUIDE: T = float on an f64 tree — the nodes are the tree's guide boxes, rays_dev the batch's f32 copy, ga the f64 originals (see k_guide_rays)
+// GUIDE: T = float on an f64 tree — the nodes are the tree's guide boxes, rays_dev unused (NULL), ga the f64 batch: every ray is converted where the walk loads it (guide_ray_load)
 template <typename T, int MODE, int ITEMS_LOG4, int GUIDE = 0>
 static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, const WalkOut<T>& w, bvhgpu_hits* h,
-                        uint32_t* ovf_flag, bool early_items, GuideArgs ga = GuideArgs{nullptr, nullptr}) {
+                        uint32_t* ovf_flag, bool early_items, GuideArgs ga = GuideArgs{nullptr, nullptr, nullptr}) {
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
     const WideGeom<T> g(ctx, ITEMS_LOG4 == 0, (h->flags & BVHGPU_TRAVERSE_COHERENT) != 0);
@@ -1748,7 +1766,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     // the pass that splits level 3, and the caller says that the rays do not depend on anything enqueued since
     const bool early_items = use_wide && items_log4 == 2 && (flags & BVHGPU_TRAVERSE_RAYS_READY) != 0 && t->pending_build && t->ev_top != nullptr &&
                              t->ev_top_gen == t->gen && ctx->tune[BVHGPU_TUNE_WIDE_EARLY_ITEMS] != 0;
-    // f64 index batches: the f32 walk over the tree's guide boxes, leaf candidates confirmed in f64 (k_guide_rays; a result object that met
+    // f64 index batches: the f32 walk over the tree's guide boxes, leaf candidates confirmed in f64 (guide_ray_load; a result object that met
     // a ray outside the guide walk's range stays with the f64 walk)
     // A result object that met a ray outside the guide walk's range backs off: the next `guide_skip` f64 index batches take the f64 walk
     // straight away (1, 2, 4 … 64 batches on consecutive failures — a workload of axis-parallel rays pays one wasted guide walk in 65),
@@ -1807,16 +1825,12 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         constexpr int M = decltype(mode_tag)::value;
         if constexpr (sizeof(T) == 8 && M == MODE_INDICES) {
             if (use_guide) {
-                h->guide_rays.reserve(std::max<size_t>(n_rays, 1) * sizeof(bvhgpu_ray_f32));
-                bvhgpu_ray_f32* r32 = h->guide_rays.as<bvhgpu_ray_f32>();
-                hipLaunchKernelGGL(k_guide_rays, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const bvhgpu_ray_f64*>(rays_dev),
-                                   (uint32_t)n_rays, t->guide_info.as<float>(), r32, ovf_flag);
-                if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[7], st)); ctx->ev_set |= 8u; }   // traverse_kernel_ms = the walk kernel alone
+                const bvhgpu_ray_f32* r32 = nullptr;   // (the guide walk converts every f64 ray where it loads it: no f32 copy of the batch)
                 WalkOut<float> wg;   // the same outputs: an index batch touches none of the T-typed ones
                 wg.counts = w.counts; wg.pool = w.pool; wg.pool_v = nullptr; wg.pool_cap = w.pool_cap; wg.ctr = w.ctr; wg.tris = nullptr;
                 wg.closest = nullptr; wg.closest_prim = nullptr; wg.item_cnt = w.item_cnt; wg.ray_items = w.ray_items; wg.scan_sums = w.scan_sums;
                 wg.pool8 = w.pool8; wg.raybuf = w.raybuf; wg.stage_shift = w.stage_shift;
-                const GuideArgs ga{reinterpret_cast<const bvhgpu_ray_f64*>(rays_dev), t->aabbs.as<double>()};
+                const GuideArgs ga{reinterpret_cast<const bvhgpu_ray_f64*>(rays_dev), t->aabbs.as<double>(), t->guide_info.as<float>()};
                 if (items_log4 == 2) launch_wide<float, MODE_INDICES, 2, 1>(t, r32, n_rays, wg, h, ovf_flag, false, ga);
                 else if (items_log4 == 1) launch_wide<float, MODE_INDICES, 1, 1>(t, r32, n_rays, wg, h, ovf_flag, false, ga);
                 else launch_wide<float, MODE_INDICES, 0, 1>(t, r32, n_rays, wg, h, ovf_flag, false, ga);
@@ -1864,7 +1878,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         h->closest_prim.reserve(std::max<size_t>(n_rays, 1) * 4);
         if (n_rays == 0) { h->pend_tree = nullptr; return; }
         w.closest = h->closest.as<T>(); w.closest_prim = h->closest_prim.as<uint32_t>();
-        if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); ctx->ev_set &= ~8u; }
+        if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
         DISPATCH_WALK();
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
         hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);   // readback + reset for the next call
@@ -1939,7 +1953,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     }
     w.counts = counts; w.pool = h->pool.as<HitRec>(); w.pool_v = h->pool_t.as<T>(); w.pool_cap = cap;
     w.pool8 = rec8 ? h->pool.as<uint2>() : nullptr;
-    if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); ctx->ev_set &= ~8u; }
+    if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
     DISPATCH_WALK();
     if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); }
     unsigned long long* bs = h->blocksums.as<unsigned long long>();

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BVHGPU_ABI_VERSION 5 /* 5: bvhgpu_rccl_info, bvhgpu_timings.ray_convert_ms.  4: BVHGPU_TUNE_COUNT 15 (slot 14 = WIDE_F64_GUIDE), bvhgpu_hits_walk_info.  3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 14 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT, 13 = WIDE_REC8), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
+#define BVHGPU_ABI_VERSION 5 /* 5: bvhgpu_rccl_info.  4: BVHGPU_TUNE_COUNT 15 (slot 14 = WIDE_F64_GUIDE), bvhgpu_hits_walk_info.  3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 14 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT, 13 = WIDE_REC8), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
 #define BVHGPU_NONE 0xFFFFFFFFu /* u32::MAX marker (flat_bvh.rs:51-53, :124, :137) */
 
 typedef enum {
@@ -327,9 +327,7 @@ void bvhgpu_hits_destroy(bvhgpu_hits *hits);
 
 /* ---- timing hook used by bench.py: HIP-event time (ms) of the kernels of the last call of each
  * phase on this ctx's stream (build / flatten / traverse main kernel / traverse total). ---- */
-/* ray_convert_ms (ABI 5): f64 index batches walked over the tree's f32 guide boxes first copy the batch as f32 rays; that pass is
- * part of traverse_total_ms but NOT of traverse_kernel_ms (the walk kernel alone), so it is reported on its own; 0 for every other batch. */
-typedef struct { float build_ms, flatten_ms, traverse_kernel_ms, traverse_total_ms, ray_convert_ms; } bvhgpu_timings;
+typedef struct { float build_ms, flatten_ms, traverse_kernel_ms, traverse_total_ms; } bvhgpu_timings;
 int bvhgpu_enable_timing(bvhgpu_ctx *ctx, int on);
 int bvhgpu_last_timings(bvhgpu_ctx *ctx, bvhgpu_timings *out);
 

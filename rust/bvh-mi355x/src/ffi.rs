@@ -69,7 +69,7 @@ pub struct bvhgpu_ray_f64 { pub o: [f64; 3], pub d: [f64; 3], pub inv: [f64; 3] 
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
 pub struct bvhgpu_traverse_stats { pub hits: u64, pub visited: u64, pub leaf_visits: u64, pub device_steps: u64, pub wave_steps: u64 }
 #[repr(C)] #[derive(Clone, Copy, Debug, Default)]
-pub struct bvhgpu_timings { pub build_ms: f32, pub flatten_ms: f32, pub traverse_kernel_ms: f32, pub traverse_total_ms: f32, pub ray_convert_ms: f32 }
+pub struct bvhgpu_timings { pub build_ms: f32, pub flatten_ms: f32, pub traverse_kernel_ms: f32, pub traverse_total_ms: f32 }
 
 const _: () = assert!(core::mem::size_of::<bvhgpu_node_f32>() == 64 && core::mem::size_of::<bvhgpu_node_f64>() == 112);
 const _: () = assert!(core::mem::size_of::<bvhgpu_flat_f32>() == 36 && core::mem::size_of::<bvhgpu_flat_f64>() == 64);

@@ -72,8 +72,8 @@ int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(bvhgpu_node_f3
         exe = os.path.join(d, "t")
         subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = subprocess.check_output([exe], text=True).split()
-    assert sizes == ["64", "112", "36", "64", "36", "72", "40", "20"]
-    assert C.sizeof(built.TraverseStats) == 40 and C.sizeof(built.Timings) == 20
+    assert sizes == ["64", "112", "36", "64", "36", "72", "40", "16"]
+    assert C.sizeof(built.TraverseStats) == 40 and C.sizeof(built.Timings) == 16
     # oracle layouts are the same PODs (tests byte-compare across the two)
     from oracle import orc
     assert orc.NODE_F32 == built.NODE_F32 and orc.FLAT_F32 == built.FLAT_F32 and orc.RAY_F32 == built.RAY_F32

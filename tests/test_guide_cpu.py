@@ -78,7 +78,7 @@ def _above(x):
 
 
 def _in_range_v2(o, inv, S):
-    """k_guide_rays' range test as of round 4 (scale-relative AND absolute conditions)"""
+    """guide_ray_load's range test as of round 4 (scale-relative AND absolute conditions)"""
     ai = np.abs(inv) * (4.0 * S)
     per_axis = ((np.abs(o) <= ORIGIN_MAX * S) & (np.abs(o) <= F32_MAX) & (ai <= 2.0 ** 100) & (ai >= 2.0 ** -100) &
                 (np.abs(inv) <= F32_MAX) & (np.abs(inv) >= F32_MIN_NORMAL))
