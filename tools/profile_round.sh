@@ -23,3 +23,5 @@ python $R/tools/pmc_summary.py $out $db > $out/pmc_summary.md
 cat $out/pmc_summary.md
 mkdir -p $R/gpurun_out/profiles_$tag
 for f in kernel_stats.md pmc_summary.md bound.json bench_under_rocprof.json; do cp $out/$f $R/gpurun_out/profiles_$tag/${tag}_$f 2>/dev/null; done
+# keep the merge-back small (gpurun copies at most 64 MiB of gpurun_out): the rocpd database and the counter CSVs have been summarised
+if [ -z "$KEEP_RAW" ]; then rm -rf $out/trace $out/pmc_*; fi
