@@ -146,7 +146,7 @@ TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_TRAVERSE_LDS_SLOTS, TUNE_TRAVERSE_LDS_THREADS, 
 TUNE_WIDE_ITEMS_LOG4, TUNE_WIDE_STACK_LDS, TUNE_WIDE_WG_PER_CU, TUNE_WIDE_THREADS, TUNE_WIDE_SLOTS = 1, 2, 7, 8, 9
 TUNE_WIDE_EARLY_ITEMS = 11       # wide walk on a tree being rebuilt, RAYS_READY batches: item filter beside the build (1) or in the walk's prologue (0, default)
 TUNE_WIDE_STAGE_SHIFT = 12       # wide walk, whole rays, indices only: 2^v shapes per ray staged without pool records (-1 default = 3, 0 off)
-TUNE_WIDE_REC8 = 13              # wide walk, whole rays, indices only: 8-byte pool records (1, default) or the 12-byte HitRec (0)
+TUNE_WIDE_REC8 = 13              # wide walk, whole rays, indices only: pair records, 8 bytes per hit (1, default) or the 12-byte HitRec (0)
 TUNE_BUILD_LEVEL_LAUNCHES = 10   # builder, level tier: 1 one launch per level, 2 k_bin + k_split per level, 0 (default) by scene size
 TUNE_WIDE_F64_GUIDE = 14        # wide walk, f64 trees, indices only: walk the f32 guide boxes, test leaf candidates in f64 (1, default) or the f64 walk (0)
 WALK_WIDE, WALK_STAGED, WALK_REC8, WALK_F64_GUIDE = 1, 2, 4, 8   # bvhgpu_hits_walk_info

@@ -73,7 +73,7 @@ template <typename T> struct WalkOut {
     uint32_t* item_cnt;          // wide walk with several items per ray: hits of item (ray, j), written only when non-zero
     uint32_t* ray_items;         // ... and per ray the set of j that wrote one (kept all-zero between batches like counts)
     uint32_t* scan_sums;         // wide walk: hits per SCAN_BLOCK rays, added up by the workgroups as they finish (a zeroed set; NULL: k_scan_reduce does the sums)
-    uint2* pool8;                // wide walk, whole rays, indices only: 8-byte records {ray, k << 25 | shape} in the pool's memory instead of the 12-byte
+    uint4* pool_pair;            // wide walk, whole rays, indices only: pair records {ray, k, shape, shape | NONE} (report_pair) in the pool's memory instead of the 12-byte
                                  // HitRec (k < 128 and shape < 2^25, else overflow bit 3 and the host replays with HitRec).  NULL: HitRec
     uint32_t* raybuf;            // wide walk, whole rays, indices only: the first 2^stage_shift shapes of ray r go straight to raybuf[r << stage_shift | k]
     uint32_t stage_shift;        // (4 bytes per hit, no record, no atomic); only later hits of a ray become pool records.  NULL: everything through the pool
@@ -216,41 +216,46 @@ __device__ __forceinline__ void report(bool rec, uint32_t shape, T t0, T t1, Lan
     pc.pos += h; pc.left -= h;
 }
 
-// The same for the 8-byte record of whole-ray index batches (WalkOut::pool8): a third less to write, and to read back in the scatter —
-// the CSR assembly of a hit-heavy batch is bound by exactly these bytes (457 M records for configs[3]'s 100 M rays).
-constexpr uint32_t REC8_SHAPE_BITS = 25;
 #ifndef SCATTER8_UNROLL
 #define SCATTER8_UNROLL 16
 #endif
-__device__ __forceinline__ void pool_invalidate_tail8(uint2* pool, unsigned long long pool_cap, const PoolCursor& pc, int lane) {
+// Whole-ray index batches (WalkOut::pool_pair) write PAIR records, 16 bytes for two hits: {ray, k of the first, shape, shape | NONE}.  A lane
+// keeps one hit pending and writes a record when its ray's next hit arrives — or, alone, when the ray retires (flush) — so the pool holds
+// 8 bytes per hit instead of HitRec's 12, and the scatter reads one ray offset per TWO hits: the CSR assembly of a hit-heavy batch (457 M
+// hits for configs[3]'s 100 M rays) is bound by exactly those dependent gathers.  Measured against the 8-byte single-hit record
+// {ray, k << 25 | shape} it replaced (profiles/r4_pair_records_*_ab.log): 12.5 M incoherent rays 2.88 -> 2.75 ms per step, 10 M primary
+// rays 1.914 -> 1.868; and no limit on hits per ray or shapes per scene, so no fallback format.
+__device__ __forceinline__ void pool_invalidate_tail16(uint4* pool, unsigned long long pool_cap, const PoolCursor& pc, int lane) {
     for (uint32_t j = (uint32_t)lane; j < pc.left; j += WAVE)
         if (pc.pos + j < pool_cap) pool[pc.pos + j].x = NONE;
 }
 template <typename RAY>
-__device__ __forceinline__ void report8(bool rec, uint32_t shape, RAY& ray, uint2* pool, unsigned long long pool_cap, unsigned long long* ctr,
-                                        PoolCursor& pc, int lane, unsigned long long lt, bool& too_big) {
-    const unsigned long long m = __ballot(rec);
-    if (!m) return;
-    const uint32_t h = (uint32_t)__popcll(m);
-    if (h > pc.left) {   // wave-uniform: start a new chunk, invalidate what is left of the old one
-        pool_invalidate_tail8(pool, pool_cap, pc, lane);
-        unsigned int blo = 0, bhi = 0;
-        if (lane == 0) {
-            unsigned long long b = atomicAdd(&ctr[0], (unsigned long long)pc.next);
-            blo = (unsigned int)b; bhi = (unsigned int)(b >> 32);
+__device__ __forceinline__ void report_pair(bool rec, bool flush, uint32_t shape, RAY& ray, uint32_t& pend, uint4* pool, unsigned long long pool_cap,
+                                            unsigned long long* ctr, PoolCursor& pc, int lane, unsigned long long lt) {
+    const bool emit = (rec || flush) && pend != NONE;
+    const unsigned long long m = __ballot(emit);
+    if (m) {
+        const uint32_t h = (uint32_t)__popcll(m);
+        if (h > pc.left) {   // wave-uniform: start a new chunk, invalidate what is left of the old one
+            pool_invalidate_tail16(pool, pool_cap, pc, lane);
+            unsigned int blo = 0, bhi = 0;
+            if (lane == 0) {
+                unsigned long long b = atomicAdd(&ctr[0], (unsigned long long)pc.next);
+                blo = (unsigned int)b; bhi = (unsigned int)(b >> 32);
+            }
+            blo = __builtin_amdgcn_readfirstlane(blo); bhi = __builtin_amdgcn_readfirstlane(bhi);
+            pc.pos = ((unsigned long long)bhi << 32) | blo;
+            pc.left = pc.next;
+            pc.next = pc.next < POOL_CHUNK_MAX ? pc.next * 2 : POOL_CHUNK_MAX;
         }
-        blo = __builtin_amdgcn_readfirstlane(blo); bhi = __builtin_amdgcn_readfirstlane(bhi);
-        pc.pos = ((unsigned long long)bhi << 32) | blo;
-        pc.left = pc.next;
-        pc.next = pc.next < POOL_CHUNK_MAX ? pc.next * 2 : POOL_CHUNK_MAX;
+        if (emit) {
+            const unsigned long long slot = pc.pos + __popcll(m & lt);
+            if (slot < pool_cap) pool[slot] = make_uint4(ray.r, ray.cnt - 1u, pend, rec ? shape : NONE);   // (the pending hit is number cnt - 1)
+        }
+        pc.pos += h; pc.left -= h;
     }
-    if (rec) {
-        const unsigned long long slot = pc.pos + __popcll(m & lt);
-        too_big = too_big || (ray.cnt >> (32u - REC8_SHAPE_BITS)) != 0u || (shape >> REC8_SHAPE_BITS) != 0u;
-        if (slot < pool_cap) pool[slot] = make_uint2(ray.r, (ray.cnt << REC8_SHAPE_BITS) | (shape & ((1u << REC8_SHAPE_BITS) - 1u)));
-        ray.cnt++;
-    }
-    pc.pos += h; pc.left -= h;
+    if (rec) { pend = emit ? NONE : shape; ray.cnt++; }
+    else if (emit) pend = NONE;
 }
 
 template <typename T, int MODE>
@@ -1138,7 +1143,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     ray.clear();
     uint32_t cur = CUR_NONE, sp = 0, item = NONE;
     bool exhausted = wg_begin >= wg_end;   // wave-uniform: the workgroup's range has been handed out
-    bool ovf = false, rec8_big = false;
+    bool ovf = false;
+    uint32_t pair_pend = NONE;   // pair records: the lane's hit that waits for its ray's next one
     PoolCursor pc;
     auto push_slow = [&](uint32_t v) {
         if (sp < stack_lds) s_stack[sp * SB + tid] = v;
@@ -1157,6 +1163,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
         bool run = cur != CUR_NONE;
         const unsigned long long idle = __ballot(!run);
         if (idle) {
+            if (MODE == MODE_INDICES && ITEMS_LOG4 == 0 && w.pool_pair)   // (wave-uniform) a retiring ray's unpaired last hit
+                report_pair(false, !run && item != NONE, 0u, ray, pair_pend, w.pool_pair, w.pool_cap, w.ctr, pc, lane, lt);
             if (!run && item != NONE) {   // the item has left the tree: its part of the ray's list is complete
                 if (MODE == MODE_CLOSEST) {
                     const size_t r = item;
@@ -1270,16 +1278,15 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                     rec = false;
                 }
             }
-            if (MODE == MODE_INDICES && ITEMS_LOG4 == 0 && w.pool8) report8(rec, shape, ray, w.pool8, w.pool_cap, w.ctr, pc, lane, lt, rec8_big);   // (wave-uniform)
+            if (MODE == MODE_INDICES && ITEMS_LOG4 == 0 && w.pool_pair) report_pair(rec, false, shape, ray, pair_pend, w.pool_pair, w.pool_cap, w.ctr, pc, lane, lt);   // (wave-uniform)
             else report<T, MODE>(rec, shape, (T)0, (T)0, ray, w, pc, lane, lt);
         }
         if (ovf) { cur = CUR_NONE; sp = 0; }
     }
     if (__any(ovf) && lane == 0) atomicOr(overflow, 4u);
     if constexpr (GUIDE != 0) { if (__any(guide_bad) && lane == 0) atomicOr(overflow, (uint32_t)WALK_FLAG_GUIDE_RANGE); }
-    if (MODE == MODE_INDICES && ITEMS_LOG4 == 0 && w.pool8) {
-        if (__any(rec8_big) && lane == 0) atomicOr(overflow, 8u);   // a hit did not fit the 8-byte record: the host replays with HitRec
-        pool_invalidate_tail8(w.pool8, w.pool_cap, pc, lane);
+    if (MODE == MODE_INDICES && ITEMS_LOG4 == 0 && w.pool_pair) {
+        pool_invalidate_tail16(w.pool_pair, w.pool_cap, pc, lane);
         pc.left = 0;                                                // (nothing left for the epilogue's HitRec form to invalidate)
     }
     walk_epilogue<T, MODE>(w, pc, lane, false, 0, 0, 0, 0);
@@ -1492,35 +1499,38 @@ __global__ __launch_bounds__(256) void k_hits_scatter_wide(const HitRec* __restr
     }
 }
 
-// the 8-byte records of a whole-ray index batch (WalkOut::pool8) → indices[offsets[ray] + k]
-__device__ __forceinline__ void scatter8_role(uint32_t block, uint32_t nblocks, const uint2* __restrict__ pool, const unsigned long long* __restrict__ ctr,
+// the pair records of a whole-ray index batch (WalkOut::pool_pair) → indices[offsets[ray] + k], + k + 1
+__device__ __forceinline__ void scatter_pair_role(uint32_t block, uint32_t nblocks, const uint4* __restrict__ pool, const unsigned long long* __restrict__ ctr,
                                               unsigned long long pool_cap, unsigned long long idx_cap, const uint32_t* __restrict__ offsets,
                                               uint32_t* __restrict__ indices) {
     const unsigned long long n = ctr[0];
-    if (n > pool_cap || ctr[3] > idx_cap || (ctr[7] & 8ull)) return;   // too small / a record did not fit: the host grows / switches and replays
+    if (n > pool_cap || ctr[3] > idx_cap) return;   // too small: the host grows and replays
     // SCATTER8_UNROLL records per thread and round, loads first: a record costs two dependent reads (the record, then its ray's offset)
     // and the kernel is latency-bound (PMC: 0.40 of the HBM rate, 82 % of wave-time waiting with one record in flight per thread)
     constexpr uint32_t U = SCATTER8_UNROLL;
     const unsigned long long span = (unsigned long long)blockDim.x * U;
     for (unsigned long long j0 = block * span + threadIdx.x; j0 < n; j0 += (unsigned long long)nblocks * span) {
-        uint2 h[U];
+        uint4 h[U];
         uint32_t o[U];
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) {
             const unsigned long long j = j0 + (unsigned long long)u * blockDim.x;
-            h[u] = j < n ? pool[j] : make_uint2(NONE, 0u);   // (NONE also marks the unused tail of a per-wave chunk)
+            h[u] = j < n ? pool[j] : make_uint4(NONE, 0u, 0u, 0u);   // (NONE also marks the unused tail of a per-wave chunk)
         }
 #pragma unroll
         for (uint32_t u = 0; u < U; u++) o[u] = h[u].x != NONE ? offsets[h[u].x] : 0u;
 #pragma unroll
         for (uint32_t u = 0; u < U; u++)
-            if (h[u].x != NONE) indices[o[u] + (h[u].y >> REC8_SHAPE_BITS)] = h[u].y & ((1u << REC8_SHAPE_BITS) - 1u);
+            if (h[u].x != NONE) {
+                indices[o[u] + h[u].y] = h[u].z;
+                if (h[u].w != NONE) indices[o[u] + h[u].y + 1u] = h[u].w;
+            }
     }
 }
-__global__ __launch_bounds__(256) void k_hits_scatter8(const uint2* __restrict__ pool, const unsigned long long* __restrict__ ctr,
+__global__ __launch_bounds__(256) void k_hits_scatter_pair(const uint4* __restrict__ pool, const unsigned long long* __restrict__ ctr,
                                                        unsigned long long pool_cap, unsigned long long idx_cap, const uint32_t* __restrict__ offsets,
                                                        uint32_t* __restrict__ indices) {
-    scatter8_role(blockIdx.x, gridDim.x, pool, ctr, pool_cap, idx_cap, offsets, indices);
+    scatter_pair_role(blockIdx.x, gridDim.x, pool, ctr, pool_cap, idx_cap, offsets, indices);
 }
 
 // Staged hits (WalkOut::raybuf) → CSR: one thread per ray copies the ray's first min(count, 2^shift) shapes from its own 2^shift-word
@@ -1562,7 +1572,7 @@ __global__ __launch_bounds__(256) void k_hits_gather_staged(const uint32_t* __re
     // The workgroup's rays are consecutive, so their CSR ranges form ONE contiguous span of indices[] (≈ 6 shapes x 256 rays = 6 KB on
     // configs[2]).  Written straight from the lanes, a store instruction scatters 64 dwords over that span and the L2 evicts partial
     // lines (PMC: 353 MB written for 165 MB of hits); staged through LDS the span goes out as whole 256-byte rows.  Positions k >= CAP
-    // of a long ray are not the slot's: they are left out here and written by k_hits_scatter8 (which runs behind this kernel).
+    // of a long ray are not the slot's: they are left out here and written by k_hits_scatter_pair (which runs behind this kernel).
     if (R == 1) {
         constexpr uint32_t SPAN_MAX = 4096;                     // entries of the staging buffer (16 KB); a denser workgroup stores directly
         __shared__ uint32_t s_out[SPAN_MAX];
@@ -1584,7 +1594,7 @@ __global__ __launch_bounds__(256) void k_hits_gather_staged(const uint32_t* __re
             __syncthreads();
             for (uint32_t p = threadIdx.x; p < span; p += blockDim.x) {
                 const uint32_t x = s_out[p];
-                if (x != NONE) indices[base + p] = x;           // (NONE: a long ray's later hits — k_hits_scatter8's)
+                if (x != NONE) indices[base + p] = x;           // (NONE: a long ray's later hits — k_hits_scatter_pair's)
             }
             return;
         }
@@ -1795,7 +1805,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     WalkOut<T> w;
     w.counts = nullptr; w.pool = nullptr; w.pool_v = nullptr; w.pool_cap = 0; w.ctr = ctr;
     w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr; w.item_cnt = nullptr; w.ray_items = nullptr; w.scan_sums = nullptr;
-    w.raybuf = nullptr; w.stage_shift = 0; w.pool8 = nullptr;
+    w.raybuf = nullptr; w.stage_shift = 0; w.pool_pair = nullptr;
 
     uint32_t* ovf_flag = reinterpret_cast<uint32_t*>(ctr + 7);   // bit 0 ordered-iterator stack, bit 1 heap workspace, bit 2 wide-walk stack
     const bool best_first = ordered && (flags & BVHGPU_TRAVERSE_BEST_FIRST) != 0;
@@ -1829,7 +1839,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
                 WalkOut<float> wg;   // the same outputs: an index batch touches none of the T-typed ones
                 wg.counts = w.counts; wg.pool = w.pool; wg.pool_v = nullptr; wg.pool_cap = w.pool_cap; wg.ctr = w.ctr; wg.tris = nullptr;
                 wg.closest = nullptr; wg.closest_prim = nullptr; wg.item_cnt = w.item_cnt; wg.ray_items = w.ray_items; wg.scan_sums = w.scan_sums;
-                wg.pool8 = w.pool8; wg.raybuf = w.raybuf; wg.stage_shift = w.stage_shift;
+                wg.pool_pair = w.pool_pair; wg.raybuf = w.raybuf; wg.stage_shift = w.stage_shift;
                 const GuideArgs ga{reinterpret_cast<const bvhgpu_ray_f64*>(rays_dev), t->aabbs.as<double>(), t->guide_info.as<float>()};
                 if (items_log4 == 2) launch_wide<float, MODE_INDICES, 2, 1>(t, r32, n_rays, wg, h, ovf_flag, false, ga);
                 else if (items_log4 == 1) launch_wide<float, MODE_INDICES, 1, 1>(t, r32, n_rays, wg, h, ovf_flag, false, ga);
@@ -1908,15 +1918,15 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     h->pool.reserve(h->pool_cap * sizeof(HitRec));
     h->indices.reserve(h->idx_cap * 4);
     if (staged) { h->raybuf.reserve(((size_t)n_rays << stage_shift) * 4 + 64); w.raybuf = h->raybuf.as<uint32_t>(); w.stage_shift = (uint32_t)stage_shift; }
-    // 8-byte pool records for whole-ray index batches, unless this result object has met a batch that did not fit them
-    const bool rec8 = use_wide && items_log4 == 0 && mode == MODE_INDICES && !h->no_rec8 && t->n <= ((size_t)1 << REC8_SHAPE_BITS) &&
-                      ctx->tune[BVHGPU_TUNE_WIDE_REC8] != 0;
+    // pair records (8 bytes per hit) for whole-ray index batches
+    const bool rec8 = use_wide && items_log4 == 0 && mode == MODE_INDICES && ctx->tune[BVHGPU_TUNE_WIDE_REC8] != 0;
     h->pend_rec8 = rec8;
     if (nv) {
         h->pool_t.reserve(h->pool_cap * nv * sizeof(T));
         (mode == MODE_T_SLICE ? h->tslice : h->isect).reserve(h->pool_cap * nv * sizeof(T));
     }
-    const unsigned long long cap = h->pool_cap;
+    // (the pool's bytes then hold 16-byte pair records: three for every four HitRec slots)
+    const unsigned long long cap = rec8 ? (unsigned long long)h->pool_cap * sizeof(HitRec) / 16u : h->pool_cap;
     uint32_t* counts;
     uint32_t* bsum_other = nullptr;
     if (use_wide) {   // per-ray words kept all-zero between batches (k_scan_final puts the zeros back)
@@ -1952,7 +1962,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         counts = h->counts.as<uint32_t>();
     }
     w.counts = counts; w.pool = h->pool.as<HitRec>(); w.pool_v = h->pool_t.as<T>(); w.pool_cap = cap;
-    w.pool8 = rec8 ? h->pool.as<uint2>() : nullptr;
+    w.pool_pair = rec8 ? h->pool.as<uint4>() : nullptr;
     if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
     DISPATCH_WALK();
     if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); }
@@ -1993,7 +2003,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         }
     }
     if (rec8) {
-        hipLaunchKernelGGL(k_hits_scatter8, dim3(sgrid), dim3(256), 0, st, w.pool8, ctr, cap, (unsigned long long)h->idx_cap, offs, indices);
+        hipLaunchKernelGGL(k_hits_scatter_pair, dim3(sgrid), dim3(256), 0, st, w.pool_pair, ctr, cap, (unsigned long long)h->idx_cap, offs, indices);
     } else if (use_wide) {
         const uint32_t* icnt = h->item_cnt.as<uint32_t>();
 #define SCATTER_WIDE(NV, L4) hipLaunchKernelGGL((k_hits_scatter_wide<T, NV, L4>), dim3(sgrid), dim3(256), 0, st, w.pool, w.pool_v, ctr, cap, (unsigned long long)h->idx_cap, offs, icnt, rmask, indices, vals)
@@ -2036,9 +2046,6 @@ bool traverse_check(bvhgpu_hits* h) {
     if (h->pend_guide && (pin[7] & WALK_FLAG_GUIDE_RANGE)) {   // a ray outside the guide walk's range: this result object goes back to the f64 walk
         h->no_guide = true; h->wcounts_clean = false; return false;   // (the replay of this batch walks in f64; traverse_enqueue sets the back-off)
     }
-    if (h->pend_rec8 && (pin[7] & 8ull)) {   // a ray with 128+ hits (or a shape index beyond 2^25): this result object goes back to 12-byte records
-        h->no_rec8 = true; h->wcounts_clean = false; return false;
-    }
     if (h->pend_wide && (pin[7] & 4ull)) {   // a lane's stack outgrew LDS + workspace: the binary walks need no stack
         h->force_binary = true; h->wcounts_clean = false; h->bs_clean = false; h->ray_items.release(); return false;
     }
@@ -2056,11 +2063,13 @@ bool traverse_check(bvhgpu_hits* h) {
     }
     const unsigned long long used = pin[0];   // pool slots taken (whole chunks)
     const unsigned long long total = pin[3];  // sum of the per-ray counts = number of hits
-    if (used < total && !h->pend_staged) throw HipFail{hipErrorUnknown, "hit pool / count scan mismatch", __LINE__};
+    if (used < total && !h->pend_staged && !h->pend_rec8) throw HipFail{hipErrorUnknown, "hit pool / count scan mismatch", __LINE__};
     if (total > 0xFFFFFFFFull) throw HipFail{hipErrorInvalidValue, "OVERFLOW", __LINE__};
-    if (used > h->pool_cap) {  // pool too small: grow to the need (deterministic: same chunks on replay) and replay
+    const bool pair_recs = h->pend_rec8;   // `used` counts 16-byte records, pool_cap 12-byte slots
+    if (used > (pair_recs ? (unsigned long long)h->pool_cap * sizeof(HitRec) / 16u : (unsigned long long)h->pool_cap)) {  // pool too small: grow to the need (deterministic: same chunks on replay) and replay
         if (++h->pend_attempts > 3) throw HipFail{hipErrorUnknown, "hit pool did not converge", __LINE__};
-        h->pool_cap = (size_t)used + (size_t)used / 8 + 1024;
+        const size_t need = pair_recs ? ((size_t)used * 16u + sizeof(HitRec) - 1) / sizeof(HitRec) : (size_t)used;
+        h->pool_cap = need + need / 8 + 1024;
         return false;
     }
     if (total > h->idx_cap) {   // staged output: more hits than indices[] holds (the pool no longer sizes it) — grow and replay

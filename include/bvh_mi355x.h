@@ -312,7 +312,7 @@ int bvhgpu_hits_info(const bvhgpu_hits *hits, size_t *n_rays, uint64_t *total, b
 /* Which form of the walk produced the batch the result object holds (diagnostic; the lists never depend on it): */
 #define BVHGPU_WALK_WIDE 1u       /* the 4-wide walk (batches of BVHGPU_TUNE_TRAVERSE_LDS_MIN_RAYS rays and more) */
 #define BVHGPU_WALK_STAGED 2u     /* ... with a ray's first hits handed over through its own slot (BVHGPU_TUNE_WIDE_STAGE_SHIFT) */
-#define BVHGPU_WALK_REC8 4u       /* ... with 8-byte pool records (BVHGPU_TUNE_WIDE_REC8) */
+#define BVHGPU_WALK_REC8 4u       /* ... with pool records of 8 bytes per hit (BVHGPU_TUNE_WIDE_REC8) */
 #define BVHGPU_WALK_F64_GUIDE 8u  /* ... over the f32 guide boxes of an f64 tree, leaf candidates confirmed in f64 (BVHGPU_TUNE_WIDE_F64_GUIDE) */
 int bvhgpu_hits_walk_info(const bvhgpu_hits *hits, unsigned *flags);
 /* copy out; indices / tslice may be NULL.  tslice: 2 scalars of the tree's dtype per hit (flag T_SLICE). */
@@ -367,8 +367,8 @@ typedef enum {
                                               per-ray slot (4 bytes per hit) and gathered into the CSR; only later hits of a ray go through 12-byte pool
                                               records.  -1 (default) = 3 for batches flagged BVHGPU_TRAVERSE_COHERENT, off otherwise; 0 = off (every hit
                                               through the pool); 2 .. 5 = on for every such batch */
-    BVHGPU_TUNE_WIDE_REC8 = 13,            /* variant 3, whole rays, indices only: pool records of 8 bytes {ray, k << 25 | shape} instead of 12 (a ray with 128+
-                                              hits or a scene beyond 2^25 shapes falls back by itself); 1 (default) on, 0 off */
+    BVHGPU_TUNE_WIDE_REC8 = 13,            /* variant 3, whole rays, indices only: pool records of 8 bytes per hit (16-byte records {ray, k, shape, shape} for two
+                                              consecutive hits of a ray) instead of 12; 1 (default) on, 0 off */
     BVHGPU_TUNE_WIDE_F64_GUIDE = 14,       /* variant 3, f64 trees, indices only: 1 (default) = walk the tree's f32 guide boxes (the f64 boxes grown by 2^-18 of the
                                               scene's largest |coordinate| and rounded outward) with f32 copies of the rays and test only the leaf
                                               candidates in f64 — the hit lists are the same, the walk runs at the f32 rate; a batch with a ray outside

@@ -1056,7 +1056,7 @@ def test_fuzz_all_queries(eng, orc, seed):
     wflat = wb.flatten()
     woff, widx, _, _ = wflat.traverse_batch(eng.RayBatch(len(rays), dtype, host=np.ascontiguousarray(rays)))
     assert np.array_equal(woff, ooff) and np.array_equal(widx, oidx)
-    if (seed // 2) % 3 == 0:   # whole rays: also the staged hand-over of COHERENT batches (per-ray slots, the slot copy through LDS, 8-byte records)
+    if (seed // 2) % 3 == 0:   # whole rays: also the staged hand-over of COHERENT batches (per-ray slots, the slot copy through LDS, pair records)
         woff, widx, _, _ = wflat.traverse_batch(eng.RayBatch(len(rays), dtype, host=np.ascontiguousarray(rays)), coherent=True)
         assert np.array_equal(woff, ooff) and np.array_equal(widx, oidx)
     oisect, oclosest, oprim = orc.triangle_stage(tri, rays, ooff, oidx)
@@ -1077,3 +1077,39 @@ def test_fuzz_all_queries(eng, orc, seed):
         s_, d_ = flat.nearest_batch(pts, triangles=use_tris)
         os_, od_ = orc.nearest(oflat, aabbs, pts, tri if use_tris else None)
         assert np.array_equal(s_, os_) and d_.tobytes() == od_.tobytes()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("coherent", [False, True])
+def test_pair_records_every_hit_count(eng, orc, dtype, coherent):
+    """Whole-ray index batches hand their hits over as PAIR records (traverse.hip report_pair: two consecutive hits of a ray per 16-byte
+    record, the last one alone when the count is odd; behind the first 8 per-ray slot entries when the batch is COHERENT).  Rays with
+    exactly 0, 1, 2, ... 90 hits, interleaved so that one wave holds odd and even counts, retiring rays and fresh ones at once; a small
+    batch first, so that the large one finds the pool too small (grow + replay), then the large one again on the grown pool."""
+    from bvh_amd import Context
+    from bvh_amd._lib import TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_WIDE_ITEMS_LOG4, WALK_REC8, WALK_WIDE
+    ctx = Context(0)
+    ctx.set_tuning(TUNE_TRAVERSE_LDS_MIN_RAYS, 0)
+    ctx.set_tuning(TUNE_WIDE_ITEMS_LOG4, 0)
+    m = 90
+    x = np.arange(m, dtype=dtype) * dtype(2.0)
+    lo = np.stack([x, np.zeros(m, dtype), np.zeros(m, dtype)], axis=1)
+    aabbs = np.concatenate([lo, lo + dtype(1.0)], axis=1)               # unit boxes at x = 0, 2, 4, ...: a +x ray from the gap before box j hits m - j of them
+    rng = np.random.default_rng(5)
+    starts = rng.integers(0, m + 1, size=20_000)                         # (m: behind the last box — no hit)
+    starts[:m + 1] = np.arange(m + 1)
+    o = np.stack([2.0 * starts - 0.5, np.full(len(starts), 0.5), np.full(len(starts), 0.5)], axis=1).astype(dtype)
+    d = np.tile(np.array([1, 0, 0], dtype), (len(starts), 1))
+    rays = orc.make_rays(o, d, dtype)
+    oflat = orc.flatten(orc.build(aabbs).nodes)
+    ooff, oidx, _, _ = orc.traverse_flat(oflat, aabbs, rays)
+    assert np.array_equal(np.diff(ooff.astype(np.int64)), m - starts)
+    tree = eng.Bvh.from_aabbs(aabbs, ctx).flatten()
+    few = eng.RayBatch(m + 1, dtype, host=np.ascontiguousarray(rays[:m + 1]))   # 91 rays first: the pool is sized for them ...
+    off, idx, _, _ = tree.traverse_batch(few, coherent=coherent)
+    assert np.array_equal(off, ooff[:m + 2]) and np.array_equal(idx, oidx[:ooff[m + 1]])
+    rb = eng.RayBatch(len(rays), dtype, host=np.ascontiguousarray(rays))
+    for _ in range(2):                                                           # ... and must grow for 20 000 (replay), then is reused
+        off, idx, _, st = tree.traverse_batch(rb, coherent=coherent)
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+        assert st["walk"] & WALK_WIDE and st["walk"] & WALK_REC8
