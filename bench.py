@@ -33,6 +33,7 @@ The JSON line (rank 0) follows the task contract, plus:
   cpu_baseline — the oracle (C restatement of the reference, kind "port"), rebuilt on this box with -O3 -march=native,
                  timed on this box's host cores; rank 0, N = 1 only
   pipelined    — the same steps kept in flight on two streams by ONE host thread through the asynchronous C ABI
+  back_to_back — the same steps on ONE stream, the host one step behind (what the per-step wait of `value` costs)
 """
 from __future__ import annotations
 
@@ -724,6 +725,42 @@ def main():
         }
         for c, tr, h, _ in lanes:
             h.close(); tr.close(); c.close()
+
+    # ---- supplementary: the same steps on ONE stream with the host one step behind (N = 1) ----
+    # `value` waits for every step before it enqueues the next one, so its step contains a host round trip (completion seen → next
+    # launch reaches the GPU: ≈ 12 µs in the kernel trace, EXPERIMENTS.md "Where the step's 342 µs are").  Here the host enqueues step
+    # k + 1 behind step k on the same stream and only then waits for step k (two result objects used alternately): the GPU runs exactly
+    # the same kernels, serially, with no overlap between steps — the difference to `value` is the host's share of the step.
+    if n_gpus == 1 and args.pipeline_streams > 0:
+        c = Context(local_rank)
+        tr = Bvh.from_aabbs(wl.aabbs, c)
+        tr.flatten_in_place()
+        hs = [_Hits(c), _Hits(c)]
+        for k in range(6):
+            tr.rebuild_async(wl.aabbs); tr.traverse_async(wl.rays, hs[k % 2], flags=RAYS_READY); hs[k % 2].wait()
+        torch.cuda.synchronize(dev)
+        K = max(args.steps, 200)
+        hits_b = []
+        t0 = time.perf_counter()
+        for k in range(K):
+            tr.rebuild_async(wl.aabbs)
+            tr.traverse_async(wl.rays, hs[k % 2], flags=RAYS_READY)
+            if k:
+                hits_b.append(hs[(k - 1) % 2].wait()["hits"])
+        hits_b.append(hs[(K - 1) % 2].wait()["hits"])
+        torch.cuda.synchronize(dev)
+        dtb = time.perf_counter() - t0
+        out["back_to_back"] = {
+            "streams": 1, "host_threads": 1, "steps": K, "value": round(K * wl.R / dtb / 1e6, 3), "unit": "Mrays/s",
+            "ms_per_step": round(dtb * 1e3 / K, 4), "hits_every_step_equal": bool(len(set(hits_b)) == 1 and len(hits_b) == K),
+            "hits": hits_b[0] if hits_b else None,
+            "note": f"{K} steps enqueued back to back on ONE stream, the host waiting for step k after it has enqueued step k + 1 (two result "
+                    "objects): the same kernels in the same order with no overlap between steps; ms_per_step - this = the host round trip "
+                    "inside every step of `value` — never reported as `value`",
+        }
+        for h in hs:
+            h.close()
+        tr.close(); c.close()
 
     # ---- the other BASELINE configs, driver-observed in the same line ----
     if not args.no_extra and args.workload == "cubes120k" and args.dtype == "f32":

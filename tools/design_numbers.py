@@ -14,6 +14,10 @@ print(f"  Walk roofline: bound `{r['bound']}` at {r['frac']:.3f} of peak (VALU {
       f"{rb.get('frac')} of HBM (a latency chain of {j.get('build_levels')} level launches + 4).")
 if j.get("pipelined"):
     print(f"  `pipelined` (one host thread, two streams, never `value`): {j['pipelined']['value']:.0f} Mrays/s.")
+if j.get("back_to_back"):
+    b = j["back_to_back"]
+    print(f"  `back_to_back` (ONE stream, the host one step behind, no overlap between steps; never `value`): {b['value']:.0f} Mrays/s, {b['ms_per_step']:.4f} ms per step — "
+          f"the per-step wait of `value` costs {1e3 * (j['ms_per_step'] - b['ms_per_step']):.0f} µs of host round trip.")
 for e in j.get("extra_configs", []):
     if "error" in e:
         print(f"* {e['workload']} {e['dtype']}: ERROR {e['error']}")

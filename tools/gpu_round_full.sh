@@ -1,7 +1,7 @@
 #!/bin/bash
 # full validation of a round on the GPU box: every GPU test, smoke, the default bench line, the per-config evidence profiles
 #   bash tools/gpu_round_full.sh <tag>      → gpurun_out/full_*.{log,json}, gpurun_out/profiles_<tag>_c{1,2,3,4,4f64}/
-tag=${1:-r4_v2}
+tag=${1:-r4_v4}
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 ( timeout 1800 python -X faulthandler -m pytest tests -x -q -m gpu --durations=12 2>&1 | tail -45 ) > gpurun_out/full_tests.log 2>&1
