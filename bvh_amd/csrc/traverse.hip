@@ -74,7 +74,7 @@ template <typename T> struct WalkOut {
     uint32_t* ray_items;         // ... and per ray the set of j that wrote one (kept all-zero between batches like counts)
     uint32_t* scan_sums;         // wide walk: hits per SCAN_BLOCK rays, added up by the workgroups as they finish (a zeroed set; NULL: k_scan_reduce does the sums)
     uint4* pool_pair;            // wide walk, whole rays, indices only: pair records {ray, k, shape, shape | NONE} (report_pair) in the pool's memory instead of the 12-byte
-                                 // HitRec (k < 128 and shape < 2^25, else overflow bit 3 and the host replays with HitRec).  NULL: HitRec
+                                 // HitRec: 8 bytes per hit, one offset gather per two hits in the scatter.  NULL: HitRec
     uint32_t* raybuf;            // wide walk, whole rays, indices only: the first 2^stage_shift shapes of ray r go straight to raybuf[r << stage_shift | k]
     uint32_t stage_shift;        // (4 bytes per hit, no record, no atomic); only later hits of a ray become pool records.  NULL: everything through the pool
 };
@@ -2067,18 +2067,20 @@ bool traverse_check(bvhgpu_hits* h) {
     }
     const unsigned long long used = pin[0];   // pool slots taken (whole chunks)
     const unsigned long long total = pin[3];  // sum of the per-ray counts = number of hits
-    if (used < total && !h->pend_staged && !h->pend_rec8) throw HipFail{hipErrorUnknown, "hit pool / count scan mismatch", __LINE__};
+    const bool pair_recs = h->pend_rec8;   // `used` counts 16-byte records of two hits, pool_cap 12-byte slots
+    if ((pair_recs ? 2 * used : used) < total && !h->pend_staged) throw HipFail{hipErrorUnknown, "hit pool / count scan mismatch", __LINE__};
     if (total > 0xFFFFFFFFull) throw HipFail{hipErrorInvalidValue, "OVERFLOW", __LINE__};
-    const bool pair_recs = h->pend_rec8;   // `used` counts 16-byte records, pool_cap 12-byte slots
-    if (used > (pair_recs ? (unsigned long long)h->pool_cap * sizeof(HitRec) / 16u : (unsigned long long)h->pool_cap)) {  // pool too small: grow to the need (deterministic: same chunks on replay) and replay
-        if (++h->pend_attempts > 3) throw HipFail{hipErrorUnknown, "hit pool did not converge", __LINE__};
-        const size_t need = pair_recs ? ((size_t)used * 16u + sizeof(HitRec) - 1) / sizeof(HitRec) : (size_t)used;
-        h->pool_cap = need + need / 8 + 1024;
-        return false;
-    }
-    if (total > h->idx_cap) {   // staged output: more hits than indices[] holds (the pool no longer sizes it) — grow and replay
-        if (++h->pend_attempts > 3) throw HipFail{hipErrorUnknown, "index array did not converge", __LINE__};
-        h->idx_cap = (size_t)total + (size_t)total / 8 + 1024;
+    // Pool or index array too small: grow to the need and replay — both in ONE replay (the count scan is complete even when records were
+    // dropped, and pair records need fewer pool slots than there are hits, so the pool no longer sizes the index array).
+    const bool pool_small = used > (pair_recs ? (unsigned long long)h->pool_cap * sizeof(HitRec) / 16u : (unsigned long long)h->pool_cap);
+    const bool idx_small = total > h->idx_cap;
+    if (pool_small || idx_small) {
+        if (++h->pend_attempts > 3) throw HipFail{hipErrorUnknown, pool_small ? "hit pool did not converge" : "index array did not converge", __LINE__};
+        if (pool_small) {
+            const size_t need = pair_recs ? ((size_t)used * 16u + sizeof(HitRec) - 1) / sizeof(HitRec) : (size_t)used;
+            h->pool_cap = need + need / 8 + 1024;
+        }
+        if (idx_small) h->idx_cap = (size_t)total + (size_t)total / 8 + 1024;
         return false;
     }
     if (h->pend_guide) h->guide_backoff = 0;   // an f64 batch that stayed inside the guide walk's range
