@@ -76,6 +76,9 @@ def parse():
                     help="untimed steps before the W warmup steps (clock ramp after start-up: ~0.1 s of the headline step; at most 20 for batches above 2 M rays)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs sub-runs")
+    ap.add_argument("--extras-timeout", type=float, default=300.0,
+                    help="N > 1: seconds after which the extra_configs section is given up and the line measured so far is printed (a rank that "
+                         "fails alone would leave the others in a barrier for ever)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--parity-max-rays", type=int, default=200_000_000,
@@ -586,8 +589,8 @@ def main():
     line = {}            # the JSON line as far as it has been measured: what the watchdog prints if an exchange section hangs
     xstate = {"comm_err": None, "tried_comm": False}
 
-    def emit_and_exit(what):
-        line["collective_watchdog"] = (f"{what} did not finish within {args.collective_timeout:.0f} s: this line is what had been measured until "
+    def emit_and_exit(what, seconds=None):
+        line["collective_watchdog"] = (f"{what} did not finish within {seconds if seconds is not None else args.collective_timeout:.0f} s: this line is what had been measured until "
                                        "then (the replicate plan has no data-path collective)")
         if rank == 0 and line.get("value") is not None:
             os.write(json_fd, (json.dumps(line) + "\n").encode())
@@ -771,6 +774,12 @@ def main():
                     ("standin-incoherent", "f32", "strong", 100_000_000)]   # configs[3] whole on ONE GPU: the N = 1 point of the strong curve
         else:
             plan = [("standin-incoherent", "f32", "strong", 100_000_000)]
+        # N > 1: the section's barriers and all-reduces are only safe while every rank gets through it — a rank that fails alone (its
+        # `except` below skips the collectives) would leave the others waiting for ever, and the headline with them
+        import contextlib
+        guard = (Watchdog(args.extras_timeout, lambda: emit_and_exit("the extra_configs section", args.extras_timeout)) if n_gpus > 1
+                 else contextlib.nullcontext())
+        guard.__enter__()
         for name, dt, scaling, nrays in plan:
             try:
                 w2 = Workload(name, args, dt, rank, n_gpus, dev, ctx, scaling=scaling, rays=nrays)
@@ -811,6 +820,7 @@ def main():
                 torch.cuda.empty_cache()
             except Exception as e:   # an extra config must never take the headline line down
                 extras.append({"workload": name, "dtype": dt, "error": repr(e)})
+        guard.__exit__(None, None, None)
         out["extra_configs"] = extras
 
     # ---- CPU baseline: the oracle (C port of the reference algorithm) on this box's host cores ----
