@@ -149,8 +149,10 @@ TUNE_WIDE_STAGE_SHIFT = 12       # wide walk, whole rays, indices only: 2^v shap
 TUNE_WIDE_REC8 = 13              # wide walk, whole rays, indices only: pair records, 8 bytes per hit (1, default) or the 12-byte HitRec (0)
 TUNE_BUILD_LEVEL_LAUNCHES = 10   # builder, level tier: 1 one launch per level, 2 k_bin + k_split per level, 0 (default) by scene size
 TUNE_WIDE_F64_GUIDE = 14        # wide walk, f64 trees, indices only: walk the f32 guide boxes, test leaf candidates in f64 (1, default) or the f64 walk (0)
+TUNE_FLATTEN_LAZY = 15           # the flatten behind a build writes the wide walk's arrays; FlatNode / binary arrays follow on first use (1, default) or at once (0)
+TUNE_BUILD_LEVEL_PERSIST = 16    # builder, level tier: tree levels 3.. of the tier as ONE persistent launch, one level-3 subtree per XCD (1) or a launch per level (0)
 WALK_WIDE, WALK_STAGED, WALK_REC8, WALK_F64_GUIDE = 1, 2, 4, 8   # bvhgpu_hits_walk_info
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 

@@ -114,6 +114,11 @@ class Context:
         """performance knobs (include/bvh_mi355x.h bvhgpu_tune); results never change."""
         check(_lib.load().bvhgpu_set_tuning(self._h, int(knob), int(value)), self._h)
 
+    def get_tuning(self, knob: int) -> int:
+        v = C.c_int(0)
+        check(_lib.load().bvhgpu_get_tuning(self._h, int(knob), C.byref(v)), self._h)
+        return int(v.value)
+
     def close(self):
         if getattr(self, "_h", None) is None:
             return

@@ -2036,7 +2036,7 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     using Key = typename Tr::Key;
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
-    t->built = false; t->flattened = false; t->pending_build = false; t->exact_only = false; t->pending_recv = false;
+    t->built = false; t->flattened = false; t->lazy_flat = false; t->pending_build = false; t->exact_only = false; t->pending_recv = false;
     t->gen++;   // results enqueued from here on belong to this build (bvhgpu_hits_wait compares generations)
     if (n != t->n) t->has_tris = false;   // one triangle per shape: a different shape count invalidates the vertex array
     t->n = n; t->n_nodes = n ? 2 * n - 1 : 0;
@@ -2117,7 +2117,8 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     t->bstat.reserve(64);
     if (flatten_after && n >= 1)
         flatten_tree<T>(t, a.ctr, reinterpret_cast<uint32_t*>(t->pin), (uint32_t)(ROOTKEY_OFF / 4), t->bstat.as<uint32_t>(), (uint32_t)CTR_FLAGS,
-                        n > (size_t)MID_MAX ? (uint32_t)(CTR_LEVEL0 + 2 * lvl_slot(level)) : (uint32_t)CTR_FLAGS);
+                        n > (size_t)MID_MAX ? (uint32_t)(CTR_LEVEL0 + 2 * lvl_slot(level)) : (uint32_t)CTR_FLAGS,
+                        ctx->tune[BVHGPU_TUNE_FLATTEN_LAZY] != 0);
     else hipLaunchKernelGGL(k_publish_build<T>, dim3(1), dim3(256), 0, st, a, reinterpret_cast<uint32_t*>(t->pin));
     t->ctr_ready = true;
     t->pending_build = true; t->pend_level = level; t->pend_flatten = flatten_after;

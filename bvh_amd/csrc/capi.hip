@@ -363,7 +363,7 @@ int tree_from_flat(bvhgpu_ctx* ctx, const typename Traits<T>::Flat* flat, size_t
         return (int)BVHGPU_OK;
     });
     if (rc != BVHGPU_OK) { free_tree_buffers(t); delete t; return rc; }
-    t->built = false; t->flattened = true; t->unfolded = true;
+    t->built = false; t->flattened = true; t->unfolded = true; t->lazy_flat = false;
     *out = t;
     return BVHGPU_OK;
 }
@@ -681,7 +681,8 @@ int bvhgpu_flatten(bvhgpu_tree* t) {
     return guarded(ctx, [&] {
         use_device(ctx);
         if (ctx->timing) BVH_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
-        if (t->dtype == BVHGPU_F32) flatten_tree<float>(t); else flatten_tree<double>(t);
+        const bool lazy = ctx->tune[BVHGPU_TUNE_FLATTEN_LAZY] != 0;   // (the FlatNode array then follows on first use: bvhgpu_flat_nodes, a binary walk …)
+        if (t->dtype == BVHGPU_F32) flatten_tree<float>(t, nullptr, nullptr, 0, nullptr, 0, 0, lazy); else flatten_tree<double>(t, nullptr, nullptr, 0, nullptr, 0, 0, lazy);
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[3], ctx->stream)); ctx->ev_set |= 2u; }
         return (int)BVHGPU_OK;
     });
@@ -695,6 +696,7 @@ int bvhgpu_flat_nodes(bvhgpu_tree* t, void* out, int mem) {
     return guarded(t->ctx, [&] {
         use_device(t->ctx);
         size_t sz = t->dtype == BVHGPU_F32 ? sizeof(bvhgpu_flat_f32) : sizeof(bvhgpu_flat_f64);
+        ensure_flat_arrays(t);
         copy_out(t->ctx, out, t->flat.p, t->n_flat * sz, mem);
         return (int)BVHGPU_OK;
     });
@@ -734,6 +736,7 @@ int bvhgpu_scene_export(bvhgpu_tree* t, void* dst, int mem) {
     bvhgpu_ctx* ctx = t->ctx;
     return guarded(ctx, [&] {
         use_device(ctx);
+        ensure_flat_arrays(t);
         size_t tsz = t->dtype == BVHGPU_F32 ? sizeof(TravNode<float>) : sizeof(TravNode<double>);
         size_t ssz = t->dtype == BVHGPU_F32 ? 4 : 8;
         SceneHeader* h = reinterpret_cast<SceneHeader*>(ctx->pinned);
@@ -788,7 +791,7 @@ int bvhgpu_scene_import(bvhgpu_ctx* ctx, const void* src, size_t nbytes, int mem
             if (need > nbytes) return fail(ctx, BVHGPU_INVALID_ARG, "scene blob truncated");
         }
         const size_t tb = hd.trav_bytes, ab = hd.aabb_bytes, sb = hd.slot_bytes, gb = hd.tri_bytes;
-        t->flattened = false;   // until the new arrays are in place
+        t->flattened = false; t->lazy_flat = false;   // until the new arrays are in place
         t->trav.reserve(tb + 16);
         t->aabbs.reserve(ab + 16);
         const hipMemcpyKind kd = mem == BVHGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;

@@ -206,7 +206,7 @@ void bcast_arrays(bvhgpu_comm* c, bvhgpu_tree** trees, int root, int dtype, size
         if (i == local_root) continue;
         BVH_HIP(hipSetDevice(c->ctxs[i]->device));
         t->pending_build = false; t->pending_recv = false;
-        t->built = false; t->flattened = false; t->has_wide = false; t->exact_only = exact_only;
+        t->built = false; t->flattened = false; t->lazy_flat = false; t->has_wide = false; t->exact_only = exact_only;
         t->dtype = dtype; t->n = n; t->n_trav = n_trav; t->n_nodes = 0; t->n_flat = 0; t->unfolded = unfolded;
         t->gen++;
         t->trav.reserve(tb + 16);
@@ -220,6 +220,7 @@ void bcast_arrays(bvhgpu_comm* c, bvhgpu_tree** trees, int root, int dtype, size
     const void *s_trav = nullptr, *s_aabb = nullptr, *s_slot = nullptr, *s_tris = nullptr;
     if (have_root) {
         bvhgpu_tree* r = trees[local_root];
+        if (root_valid) { BVH_HIP(hipSetDevice(c->ctxs[local_root]->device)); ensure_flat_arrays(r); }   // (a lazy flatten: the arrays that travel are written now, on the root's stream)
         if (root_valid) { s_trav = r->trav.p; s_aabb = r->aabbs.p; s_slot = r->slot_entry.p; s_tris = r->tris.p; }
         else {
             bvhgpu_ctx* rc = c->ctxs[local_root];

@@ -46,7 +46,7 @@ struct bvhgpu_ctx {
     bool own_stream = false;
     std::string err;
     int n_cu = 256;
-    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0, 0, -1, 1, 1};  // bvhgpu_set_tuning defaults
+    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0, 0, -1, 1, 1, 1, 0};  // bvhgpu_set_tuning defaults
     // timing
     bool timing = false;
     hipEvent_t ev[8] = {};
@@ -68,7 +68,9 @@ struct bvhgpu_tree {
     size_t n_flat = 0;    // 3n-2 (1 if n==1)
     size_t n_trav = 0;    // 2n-2 (1 if n==1)
     bool built = false;     // has nodes / shape_node (false for imported scenes)
-    bool flattened = false; // has trav (+ flat if built)
+    bool flattened = false; // has trav (+ flat if built) — or owes them: see lazy_flat
+    bool lazy_flat = false; // the flatten of this generation wrote the wide walk's arrays only (BVHGPU_TUNE_FLATTEN_LAZY): flat / trav /
+                            // slot_entry are written by ensure_flat_arrays() the first time something reads them
     bool unfolded = false;  // trav mirrors an uploaded FlatBvh 1:1 (nav and leaf entries kept apart)
     bool ctr_ready = false; // build counters / root keys were reset by the previous build
     bool pending_build = false;  // build_enqueue ran, build_finalize has not (asynchronous entry points)
@@ -197,8 +199,12 @@ template <typename T> void build_finalize(bvhgpu_tree* t);
 // flatten.hip
 // pub_*: also publish + reset the builder's counters (build_enqueue's last launch); see k_flatten
 // bstat (with pub_*): device-side status word = pub_ctr[flags_idx] | (pub_ctr[level_idx] != 0 ? BSTAT_UNFINISHED : 0), level_idx == flags_idx: no level tier
+// wide_only: write the wide walk's arrays only and leave flat / trav / slot_entry to ensure_flat_arrays (ignored where the tree has no wide nodes)
 template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr = nullptr, uint32_t* pub_host = nullptr, uint32_t pub_words = 0,
-                                        uint32_t* bstat = nullptr, uint32_t flags_idx = 0, uint32_t level_idx = 0);
+                                        uint32_t* bstat = nullptr, uint32_t flags_idx = 0, uint32_t level_idx = 0, bool wide_only = false);
+// the FlatNode array, the folded binary array and the binary walk's LDS slot table of a tree whose flatten was lazy: enqueued on the
+// tree's stream now (a no-op for every other tree).  Everything that reads t->flat / t->trav / t->slot_entry calls this first.
+void ensure_flat_arrays(bvhgpu_tree* t);
 constexpr uint32_t BSTAT_NONFINITE = 1u, BSTAT_EMPTY_SPLIT = 2u;   // = build.hip BUILD_FLAG_*
 constexpr uint32_t BSTAT_UNFINISHED = 0x100u;
 constexpr int BUILD_CTR_TOPMASK = 5;   // u32 slot of the build counters: bit h = the level tier wrote the BvhNode of heap number h (h < 16)                      // the optimistic schedule left nodes in the level queue

@@ -113,7 +113,11 @@ __device__ __forceinline__ void flatten_wide_node(const typename Traits<T>::Node
     }
 }
 
-template <typename T>
+// PARTS: bit 0 = the FlatNode array (reference layout), the folded binary array and the binary walk's LDS slot table; bit 1 = the wide
+// nodes (+ an f64 tree's guide nodes) and their LDS slot table.  3 = everything in one pass; with BVHGPU_TUNE_FLATTEN_LAZY the flatten
+// behind a build runs part 2 — what the wide walk reads — and part 1 follows when something asks for those arrays (ensure_flat_arrays).
+constexpr int FLATTEN_FLAT = 1, FLATTEN_WIDE = 2;
+template <typename T, int PARTS>
 __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node* __restrict__ nodes,
                                                  const uint32_t* __restrict__ node_start,
                                                  const uint32_t* __restrict__ node_count, const T* __restrict__ aabbs,
@@ -142,12 +146,13 @@ __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node*
     // wide nodes: the walk only ever enters nodes an even number of levels below the root (it steps from a node to its
     // grandchildren, items start 2 or 4 levels down), so odd levels get none — as far as the level is known: heap numbers
     // saturate 16 levels down, below that every inner node gets one
-    if (wide && nd.shape == NONE && nd.l < n_nodes && nd.r < n_nodes) {
+    if ((PARTS & FLATTEN_WIDE) && wide && nd.shape == NONE && nd.l < n_nodes && nd.r < n_nodes) {
         const uint32_t h = node_slot[i];
         const bool odd_level = h != SLOT_NONE && h >= 1u && (((31 - __clz((int)h)) & 1) != 0);
         if (!odd_level) flatten_wide_node<T>(nodes, nd, i, node_slot, wide, wslot_node, n_nodes, n_shapes, guide);
         if (guide_info && i == 0) guide_info[0] = (float)guide_scene_extent<T>(nd.l_min, nd.l_max, nd.r_min, nd.r_max);   // (read by the ray conversion of the guide walk)
     }
+    if (!(PARTS & FLATTEN_FLAT)) return;
     if (n_nodes == 1) {
         // single-shape tree: the root is a leaf and emits one leaf entry (flat_bvh.rs:129-141); its
         // traversal entry tests the shape's own AABB (flat_bvh.rs:411-418)
@@ -305,20 +310,11 @@ template <typename T> void wide_from_trav(bvhgpu_tree* t) {
 template void wide_from_trav<float>(bvhgpu_tree*);
 template void wide_from_trav<double>(bvhgpu_tree*);
 
-template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr, uint32_t* pub_host, uint32_t pub_words, uint32_t* bstat,
-                                        uint32_t flags_idx, uint32_t level_idx) {
+template <typename T, int PARTS> static void launch_flatten(bvhgpu_tree* t, bool with_wide, bool with_guide, uint32_t* pub_ctr, uint32_t* pub_host,
+                                                             uint32_t pub_words, uint32_t* bstat, uint32_t flags_idx, uint32_t level_idx) {
     using Tr = Traits<T>;
-    if (t->n == 0) { t->flattened = true; return; }
-    t->flat.reserve(t->n_flat * sizeof(typename Tr::Flat));
-    t->trav.reserve(t->n_trav * sizeof(TravNode<T>));
     const uint32_t nn = (uint32_t)t->n_nodes;
-    hipStream_t st = t->ctx->stream;
-    // the wide nodes come out of the same pass (their LDS slot table was cleared by the build's first kernel)
-    const bool with_wide = t->n >= 2 && t->n < WIDE_MAX_SHAPES && t->wslot_node.p != nullptr;
-    if (with_wide) t->wide.reserve((size_t)nn * sizeof(WideNode<T>));
-    const bool with_guide = with_wide && sizeof(T) == 8;
-    if (with_guide) { t->wide_guide.reserve((size_t)nn * sizeof(WideNode<float>)); t->guide_info.reserve(16); }
-    hipLaunchKernelGGL(k_flatten<T>, dim3((nn + 255) / 256), dim3(256), 0, st,
+    hipLaunchKernelGGL((k_flatten<T, PARTS>), dim3((nn + 255) / 256), dim3(256), 0, t->ctx->stream,
                        t->nodes.as<typename Tr::Node>(), t->node_start.as<uint32_t>(), t->node_count.as<uint32_t>(),
                        t->aabbs.as<T>(), t->node_slot.as<uint16_t>(), t->slot_entry.as<uint32_t>(),
                        t->flat.as<typename Tr::Flat>(),
@@ -326,12 +322,49 @@ template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr, uint3
                        (uint32_t)t->n, pub_ctr, pub_host, pub_words, bstat, flags_idx, level_idx,
                        with_guide ? t->wide_guide.as<WideNode<float>>() : nullptr, with_guide ? t->guide_info.as<float>() : nullptr);
     BVH_HIP(hipGetLastError());
+}
+
+template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr, uint32_t* pub_host, uint32_t pub_words, uint32_t* bstat,
+                                        uint32_t flags_idx, uint32_t level_idx, bool wide_only) {
+    using Tr = Traits<T>;
+    t->lazy_flat = false;
+    if (t->n == 0) { t->flattened = true; return; }
+    // the wide nodes come out of the same pass (their LDS slot table was cleared by the build's first kernel)
+    const bool with_wide = t->n >= 2 && t->n < WIDE_MAX_SHAPES && t->wslot_node.p != nullptr;
+    const uint32_t nn = (uint32_t)t->n_nodes;
+    if (with_wide) t->wide.reserve((size_t)nn * sizeof(WideNode<T>));
+    const bool with_guide = with_wide && sizeof(T) == 8;
+    if (with_guide) { t->wide_guide.reserve((size_t)nn * sizeof(WideNode<float>)); t->guide_info.reserve(16); }
+    if (wide_only && with_wide) {   // (a tree without wide nodes is walked by the binary kernels: nothing to postpone)
+        launch_flatten<T, FLATTEN_WIDE>(t, true, with_guide, pub_ctr, pub_host, pub_words, bstat, flags_idx, level_idx);
+        t->lazy_flat = true;
+    } else {
+        t->flat.reserve(t->n_flat * sizeof(typename Tr::Flat));
+        t->trav.reserve(t->n_trav * sizeof(TravNode<T>));
+        launch_flatten<T, FLATTEN_FLAT | FLATTEN_WIDE>(t, with_wide, with_guide, pub_ctr, pub_host, pub_words, bstat, flags_idx, level_idx);
+    }
     t->has_wide = with_wide;
     t->has_guide = with_guide;
     t->flattened = true;
 }
 
-template void flatten_tree<float>(bvhgpu_tree*, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t);
-template void flatten_tree<double>(bvhgpu_tree*, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t);
+// part 1 of a lazy flatten, on the tree's stream (behind the build and the wide-only pass if they are still in flight: on an unfinished
+// tree build_finalize flattens again, completely).  The slot table k_prep cleared is filled here.
+void ensure_flat_arrays(bvhgpu_tree* t) {
+    if (!t->lazy_flat) return;
+    t->lazy_flat = false;
+    if (t->dtype == BVHGPU_F32) {
+        t->flat.reserve(t->n_flat * sizeof(Traits<float>::Flat));
+        t->trav.reserve(t->n_trav * sizeof(TravNode<float>));
+        launch_flatten<float, FLATTEN_FLAT>(t, false, false, nullptr, nullptr, 0, nullptr, 0, 0);
+    } else {
+        t->flat.reserve(t->n_flat * sizeof(Traits<double>::Flat));
+        t->trav.reserve(t->n_trav * sizeof(TravNode<double>));
+        launch_flatten<double, FLATTEN_FLAT>(t, false, false, nullptr, nullptr, 0, nullptr, 0, 0);
+    }
+}
+
+template void flatten_tree<float>(bvhgpu_tree*, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t, bool);
+template void flatten_tree<double>(bvhgpu_tree*, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t, uint32_t, bool);
 
 }  // namespace bvhgpu

@@ -130,7 +130,7 @@ template <typename T> void refit_tree(bvhgpu_tree* t, const T* aabbs_dev) {
     if (n == 1) {   // the root is the leaf: only the shape's AABB is stored (and tested by traversal)
         if (aabbs_dev != t->aabbs.as<T>()) BVH_HIP(hipMemcpyAsync(t->aabbs.p, aabbs_dev, 6 * sizeof(T), hipMemcpyDeviceToDevice, st));
         if (t->ctx->timing) { BVH_HIP(hipEventRecord(t->ctx->ev[1], st)); t->ctx->ev_set |= 1u; }
-        if (t->flattened) flatten_tree<T>(t);
+        if (t->flattened) flatten_tree<T>(t, nullptr, nullptr, 0, nullptr, 0, 0, t->ctx->tune[BVHGPU_TUNE_FLATTEN_LAZY] != 0);
         return;
     }
     uint32_t n_pad = 1;
@@ -152,7 +152,7 @@ template <typename T> void refit_tree(bvhgpu_tree* t, const T* aabbs_dev) {
     BVH_HIP(hipGetLastError());
     if (t->ctx->timing) { BVH_HIP(hipEventRecord(t->ctx->ev[1], st)); t->ctx->ev_set |= 1u; }
     t->exact_only = false;   // every child box is now the exact join of what is below it (also where the build left empty bounds)
-    if (t->flattened) flatten_tree<T>(t);   // the flat / traversal arrays carry the boxes too
+    if (t->flattened) flatten_tree<T>(t, nullptr, nullptr, 0, nullptr, 0, 0, t->ctx->tune[BVHGPU_TUNE_FLATTEN_LAZY] != 0);   // the flat / traversal arrays carry the boxes too
 }
 
 template void refit_tree<float>(bvhgpu_tree*, const float*);

@@ -1628,6 +1628,7 @@ static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
                         uint32_t split_at) {
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
+    ensure_flat_arrays(t);   // (a lazy flatten wrote the wide walk's arrays only: the binary array and its LDS slot table follow now)
     const uint32_t n_trav = (uint32_t)t->n_trav;
     const TravNode<T>* nodes = t->trav.as<TravNode<T>>();
     if (!use_lds) {   // one ray per lane per launch
@@ -2266,6 +2267,7 @@ void nearest_batch(bvhgpu_tree* t, const T* points_dev, size_t n, int kind, uint
     if (!n) return;
     hipStream_t st = t->ctx->stream;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    ensure_flat_arrays(t);
     const TravNode<T>* nodes = t->trav.as<TravNode<T>>();
     const uint32_t n_trav = (uint32_t)t->n_trav;
     const bool unfolded = t->unfolded || t->n == 1;   // a single-shape tree has one (leaf) entry and no navigator

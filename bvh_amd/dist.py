@@ -152,7 +152,14 @@ def broadcast_step(comm: "Communicator", rank: int, tree, aabbs, rays, dtype: st
     for attempt in range(3):
         if rank == root:
             if attempt == 0 and aabbs is not None:
-                tree.rebuild_async(aabbs)
+                # the arrays that travel (folded binary array + its slot table) are wanted at once: one complete flatten pass instead of
+                # the lazy pair (wide walk's arrays now, the rest on first use — which would be the very next call)
+                lazy = tree.ctx.get_tuning(_lib.TUNE_FLATTEN_LAZY)
+                tree.ctx.set_tuning(_lib.TUNE_FLATTEN_LAZY, 0)
+                try:
+                    tree.rebuild_async(aabbs)
+                finally:
+                    tree.ctx.set_tuning(_lib.TUNE_FLATTEN_LAZY, lazy)
             comm.bcast(tree, root, dtype, n_shapes)
             if attempt > 0:                      # the root's batch was completed by the wait that raised
                 return tree, stats, rebroadcasts

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BVHGPU_ABI_VERSION 5 /* 5: bvhgpu_rccl_info.  4: BVHGPU_TUNE_COUNT 15 (slot 14 = WIDE_F64_GUIDE), bvhgpu_hits_walk_info.  3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 14 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT, 13 = WIDE_REC8), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
+#define BVHGPU_ABI_VERSION 6 /* 6: BVHGPU_TUNE_COUNT 17 (slots 15 = FLATTEN_LAZY, 16 = BUILD_LEVEL_PERSIST).  5: bvhgpu_rccl_info.  4: BVHGPU_TUNE_COUNT 15 (slot 14 = WIDE_F64_GUIDE), bvhgpu_hits_walk_info.  3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 14 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT, 13 = WIDE_REC8), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
 #define BVHGPU_NONE 0xFFFFFFFFu /* u32::MAX marker (flat_bvh.rs:51-53, :124, :137) */
 
 typedef enum {
@@ -374,7 +374,15 @@ typedef enum {
                                               candidates in f64 — the hit lists are the same, the walk runs at the f32 rate; a batch with a ray outside
                                               the range the argument covers (|origin| > 3 x scene, |1/d| x scene outside 2^+-100, non-finite) is replayed
                                               with the f64 walk and the result object stays with it; 0 = always the f64 walk */
-    BVHGPU_TUNE_COUNT = 15
+    BVHGPU_TUNE_FLATTEN_LAZY = 15,         /* bvhgpu_rebuild_flat_async / bvhgpu_build_flat_*: 1 (default) = the flatten behind a build writes what the wide walk
+                                              reads (wide nodes, their LDS slot table, an f64 tree's guide nodes); the reference-layout FlatNode array and the
+                                              folded binary array are written by a second pass the first time something asks for them (bvhgpu_flat_nodes,
+                                              a binary / STATS / t-slice / ordered walk, nearest_to, scene export, a broadcast) — same arrays, byte for byte;
+                                              0 = every flatten writes everything at once */
+    BVHGPU_TUNE_BUILD_LEVEL_PERSIST = 16,  /* builder, level tier with one launch per level: 1 = tree levels 3 and deeper of the tier run as ONE persistent
+                                              launch, every XCD owning one level-3 subtree and synchronising its own workgroups (no chip-wide barrier);
+                                              0 = a launch per level throughout; -1 (default) = by scene (on where the eight subtrees exist) */
+    BVHGPU_TUNE_COUNT = 17
 } bvhgpu_tune;
 int bvhgpu_set_tuning(bvhgpu_ctx *ctx, int knob, int value);
 int bvhgpu_get_tuning(const bvhgpu_ctx *ctx, int knob, int *value);

@@ -3,7 +3,7 @@
 #![allow(non_camel_case_types, dead_code)]
 use core::ffi::{c_char, c_int, c_uint, c_void};
 
-pub const BVHGPU_ABI_VERSION: c_int = 5;
+pub const BVHGPU_ABI_VERSION: c_int = 6;
 pub const BVHGPU_NONE: u32 = u32::MAX; // flat_bvh.rs:51-53
 
 // bvhgpu_status
