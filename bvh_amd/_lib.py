@@ -129,6 +129,7 @@ SYMBOLS = [
     ("bvhgpu_hits_fetch_closest", _i, [_vp, _vp, _vp, _i]),
     ("bvhgpu_hits_info", _i, [_vp, C.POINTER(_sz), C.POINTER(C.c_uint64), C.POINTER(TraverseStats)]),
     ("bvhgpu_hits_walk_info", _i, [_vp, C.POINTER(C.c_uint)]),
+    ("bvhgpu_hits_walk_kernel", _i, [_vp, C.c_char_p, _sz]),
     ("bvhgpu_hits_fetch", _i, [_vp, _vp, _vp, _vp, _i]),
     ("bvhgpu_hits_device", _i, [_vp, _pp, _pp, _pp]),
     ("bvhgpu_hits_destroy", None, [_vp]),

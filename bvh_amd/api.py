@@ -339,6 +339,32 @@ class _Hits:
         return dict(hits=int(st.hits), visited=int(st.visited), leaf_visits=int(st.leaf_visits),
                     device_steps=int(st.device_steps), wave_steps=int(st.wave_steps), total=int(total.value))
 
+    def walk_kernel(self) -> str:
+        """bvhgpu_hits_walk_kernel: the kernel the completed batch was walked by, spelled as rocprofv3 prints it"""
+        buf = C.create_string_buffer(160)
+        check(_lib.load().bvhgpu_hits_walk_kernel(self.h, buf, 160), self.ctx._h)
+        return buf.value.decode()
+
+    def walk_flags(self) -> int:
+        f = C.c_uint(0)
+        check(_lib.load().bvhgpu_hits_walk_info(self.h, C.byref(f)), self.ctx._h)
+        return int(f.value)
+
+    def fetch_closest(self, n_rays: int, dtype=np.float32):
+        """CLOSEST batches: (Intersection{distance,u,v}[n,3], shape[n]) of the completed batch, copied to the host"""
+        isect = np.zeros((n_rays, 3), dtype=dtype)
+        shape = np.zeros(n_rays, dtype=np.uint32)
+        check(_lib.load().bvhgpu_hits_fetch_closest(self.h, ptr(isect), ptr(shape), HOST), self.ctx._h)
+        return isect, shape
+
+    def fetch_triangles(self, dtype=np.float32):
+        """TRIANGLES batches: Intersection{distance,u,v} of every candidate, CSR order"""
+        total = C.c_uint64()
+        check(_lib.load().bvhgpu_hits_info(self.h, None, C.byref(total), None), self.ctx._h)
+        isect = np.zeros((total.value, 3), dtype=dtype)
+        check(_lib.load().bvhgpu_hits_fetch_triangles(self.h, ptr(isect), HOST), self.ctx._h)
+        return isect
+
     def fetch(self, n_rays: int):
         """(offsets, indices) of the completed batch, copied to the host."""
         lib = _lib.load()

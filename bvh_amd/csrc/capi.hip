@@ -931,6 +931,12 @@ int bvhgpu_hits_walk_info(const bvhgpu_hits* h, unsigned* flags) {
     return BVHGPU_OK;
 }
 
+int bvhgpu_hits_walk_kernel(const bvhgpu_hits* h, char* name, size_t cap) {
+    if (!h || !name || cap == 0) return BVHGPU_INVALID_ARG;
+    std::snprintf(name, cap, "%s", h->walk_kernel.c_str());
+    return BVHGPU_OK;
+}
+
 int bvhgpu_hits_fetch(bvhgpu_hits* h, uint32_t* offsets, uint32_t* indices, void* tslice, int mem) {
     if (!h || !h->ctx) return BVHGPU_INVALID_ARG;
     bvhgpu_ctx* ctx = h->ctx;

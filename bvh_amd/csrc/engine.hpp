@@ -157,6 +157,7 @@ struct bvhgpu_hits {
     size_t idx_cap = 0;      // capacity of indices[] in entries (>= pool_cap; staged output sizes it by the hit total)
     bvhgpu::DevBuf raybuf;   // staged output of the wide walk: 2^shift shape indices per ray (traverse.hip WalkOut::raybuf)
     bool pend_staged = false;
+    std::string walk_kernel;  // the kernel the last batch was handed to, as rocprofv3 spells it (bvhgpu_hits_walk_kernel)
     bool pend_rec8 = false;   // the batch in flight writes pair records (8 bytes per hit: traverse.hip report_pair)
     bool pend_guide = false, no_guide = false; // guide walk in the batch in flight / the batch is being replayed in f64 (a ray was out of the guide's range)
     uint32_t guide_backoff = 0, guide_skip = 0; // f64 index batches that skip the guide after such a replay: 1, 2, 4 … 64 on consecutive failures / still to skip

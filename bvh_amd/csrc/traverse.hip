@@ -17,6 +17,7 @@
 // k_traverse_lds (persistent workgroups, top of the tree resident in LDS, ray refill; large batches).  Over the BvhNode
 // array: k_traverse_ordered (child-ordered iterator, LDS stack) and k_traverse_heap (best-first iterator, BinaryHeap);
 // k_nearest answers nearest_to point queries.
+#include <cstdio>
 #include <type_traits>
 
 #include "engine.hpp"
@@ -1622,6 +1623,11 @@ __global__ void k_publish_counters(unsigned long long* __restrict__ ctr, unsigne
     __threadfence_system();
 }
 
+// Name of the walk kernel a batch was handed to, spelled as rocprofv3 prints it (bvhgpu_hits_walk_kernel: bench.py looks its counters
+// up under this name instead of rebuilding template strings by hand).  Set by the launch helpers, copied into the result object.
+static thread_local char g_walk_kernel[128] = "";
+template <typename T> static const char* type_name() { return sizeof(T) == 4 ? "float" : "double"; }
+
 // ------------------------------------------------------------------------------------------------
 template <typename T, int MODE, bool STATS>
 static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, const WalkOut<T>& w, bool use_lds,
@@ -1631,6 +1637,8 @@ static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
     ensure_flat_arrays(t);   // (a lazy flatten wrote the wide walk's arrays only: the binary array and its LDS slot table follow now)
     const uint32_t n_trav = (uint32_t)t->n_trav;
     const TravNode<T>* nodes = t->trav.as<TravNode<T>>();
+    std::snprintf(g_walk_kernel, sizeof g_walk_kernel, "bvhgpu::%s<%s, %d, %s>", use_lds ? "k_traverse_lds" : "k_traverse", type_name<T>(), MODE,
+                  STATS ? "true" : "false");
     if (!use_lds) {   // one ray per lane per launch
         hipLaunchKernelGGL((k_traverse<T, MODE, STATS>), dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, nodes,
                            n_trav, rays_dev, (uint32_t)n_rays, w);
@@ -1732,6 +1740,7 @@ static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
     constexpr int MAXT = sizeof(T) == 8 ? 512 : 1024;
     constexpr int MINW = sizeof(T) == 8 ? BVH_WIDE_MIN_WAVES_F64 : BVH_WIDE_MIN_WAVES_F32;
     auto kern = &k_traverse_wide<T, MODE, ITEMS_LOG4, MAXT, MINW, GUIDE>;
+    std::snprintf(g_walk_kernel, sizeof g_walk_kernel, "bvhgpu::k_traverse_wide<%s, %d, %d, %d, %d, %d>", type_name<T>(), MODE, ITEMS_LOG4, MAXT, MINW, GUIDE);
     static thread_local size_t lds_attr[16] = {};   // per device: dynamic-LDS limit already set for this instantiation
     size_t& have = lds_attr[ctx->device & 15];
     if (have < g.lds_bytes) {
@@ -1856,7 +1865,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         else if (M != MODE_CLOSEST && items_log4 == 1) launch_wide<T, M, (M == MODE_CLOSEST ? 0 : 1)>(t, rays_dev, n_rays, w, h, ovf_flag, false);
         else launch_wide<T, M, 0>(t, rays_dev, n_rays, w, h, ovf_flag, false);
     };
-#define DISPATCH_WALK()                                                                              \
+#define DISPATCH_WALK_INNER()                                                                        \
     do {                                                                                             \
         if (ordered) {                                                                               \
             switch (mode) {                                                                          \
@@ -1885,6 +1894,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
                      else launch_walk<T, MODE_CLOSEST, false>(t, rays_dev, n_rays, w, use_lds, split_at); break;         \
         }                                                                                            \
     } while (0)
+#define DISPATCH_WALK() do { g_walk_kernel[0] = 0; DISPATCH_WALK_INNER(); h->walk_kernel = g_walk_kernel; } while (0)
 
     if (!h->ctr_clean) BVH_HIP(hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), st));   // (only this batch's set has to be clean)
     h->ctr_clean = false;

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BVHGPU_ABI_VERSION 6 /* 6: BVHGPU_TUNE_COUNT 17 (slots 15 = FLATTEN_LAZY, 16 = BUILD_LEVEL_PERSIST).  5: bvhgpu_rccl_info.  4: BVHGPU_TUNE_COUNT 15 (slot 14 = WIDE_F64_GUIDE), bvhgpu_hits_walk_info.  3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 14 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT, 13 = WIDE_REC8), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
+#define BVHGPU_ABI_VERSION 6 /* 6: BVHGPU_TUNE_COUNT 17 (slots 15 = FLATTEN_LAZY, 16 = BUILD_LEVEL_PERSIST), bvhgpu_hits_walk_kernel.  5: bvhgpu_rccl_info.  4: BVHGPU_TUNE_COUNT 15 (slot 14 = WIDE_F64_GUIDE), bvhgpu_hits_walk_info.  3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 14 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT, 13 = WIDE_REC8), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
 #define BVHGPU_NONE 0xFFFFFFFFu /* u32::MAX marker (flat_bvh.rs:51-53, :124, :137) */
 
 typedef enum {
@@ -315,6 +315,9 @@ int bvhgpu_hits_info(const bvhgpu_hits *hits, size_t *n_rays, uint64_t *total, b
 #define BVHGPU_WALK_REC8 4u       /* ... with pool records of 8 bytes per hit (BVHGPU_TUNE_WIDE_REC8) */
 #define BVHGPU_WALK_F64_GUIDE 8u  /* ... over the f32 guide boxes of an f64 tree, leaf candidates confirmed in f64 (BVHGPU_TUNE_WIDE_F64_GUIDE) */
 int bvhgpu_hits_walk_info(const bvhgpu_hits *hits, unsigned *flags);
+/* ... and the name of the walk kernel it was handed to, NUL-terminated, spelled the way rocprofv3 prints kernel names (e.g.
+ * "bvhgpu::k_traverse_wide<float, 0, 2, 1024, 8, 0>"): what a profile of the same call must be looked up under (diagnostic, ABI 6) */
+int bvhgpu_hits_walk_kernel(const bvhgpu_hits *hits, char *name, size_t cap);
 /* copy out; indices / tslice may be NULL.  tslice: 2 scalars of the tree's dtype per hit (flag T_SLICE). */
 int bvhgpu_hits_fetch(bvhgpu_hits *hits, uint32_t *offsets, uint32_t *indices, void *tslice, int mem);
 /* TRIANGLES: 3 scalars {distance,u,v} per hit, CSR order (distance = +inf: no intersection, ray_impl.rs:150-151). */

@@ -135,6 +135,7 @@ void orc_aligned_boxes(float *aabbs /* 21*6 */);
     /* Bvh::build_par: same result, OpenMP tasks with rayon_executor's 64 cut-off (:527-543). */ \
     int orc_build_par_##S(const T *aabbs, size_t n, NODE *nodes, uint32_t *shape_node);          \
     int orc_build_threads_##S(const T *aabbs, size_t n, NODE *nodes, uint32_t *shape_node, int threads); \
+    int orc_build_fast_##S(const T *aabbs, size_t n, NODE *nodes, uint32_t *shape_node, int threads); \
     /* Bvh::flatten (flat_bvh.rs:60-143,240-251,312-319). returns entries written. */            \
     size_t orc_flatten_##S(const NODE *nodes, size_t n_nodes, FLAT *out);                        \
     /* FlatBvh::traverse over a ray batch (flat_bvh.rs:396-431). CSR out; returns total hits.    \

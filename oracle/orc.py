@@ -216,8 +216,10 @@ class Tree:
     shape_node: np.ndarray
 
 
-def build(aabbs, parallel: bool = False, threads: int = 0) -> Tree:
-    """threads > 0: task-parallel build (the rayon_executor restatement) on a team of that size"""
+def build(aabbs, parallel: bool = False, threads: int = 0, schedule: str = "tasks") -> Tree:
+    """threads > 0: a parallel build on a team of that size — schedule "tasks": the rayon_executor restatement (OpenMP task
+    recursion, bvh_impl.rs:527-543); "fast": the big nodes split by the whole team, then one parallel for over the subtrees
+    (oracle_impl.inc build_fast: the same arithmetic per node, byte-equal arrays, scales with the cores)"""
     s = _sfx(aabbs.dtype)
     ft, nt, _, _ = _types(s)
     a = np.ascontiguousarray(aabbs, dtype=ft).reshape(-1, 6)
@@ -225,7 +227,8 @@ def build(aabbs, parallel: bool = False, threads: int = 0) -> Tree:
     nodes = np.zeros(max(2 * n - 1, 0), dtype=nt)
     shape_node = np.zeros(n, dtype=np.uint32)
     if threads > 0:
-        rc = getattr(lib(), f"orc_build_threads_{s}")(_p(a), C.c_size_t(n), _p(nodes), _p(shape_node), C.c_int(threads))
+        fn = getattr(lib(), f"orc_build_fast_{s}" if schedule == "fast" else f"orc_build_threads_{s}")
+        rc = fn(_p(a), C.c_size_t(n), _p(nodes), _p(shape_node), C.c_int(threads))
     else:
         fn = getattr(lib(), f"orc_build_par_{s}" if parallel else f"orc_build_{s}")
         rc = fn(_p(a), C.c_size_t(n), _p(nodes), _p(shape_node))

@@ -149,6 +149,7 @@ extern "C" {
     pub fn bvhgpu_tree_set_triangles_f64(t: *mut bvhgpu_tree, verts: *const f64, n: usize, mem: c_int) -> c_int;
     pub fn bvhgpu_hits_info(h: *const bvhgpu_hits, n_rays: *mut usize, total: *mut u64, stats: *mut bvhgpu_traverse_stats) -> c_int;
     pub fn bvhgpu_hits_walk_info(h: *const bvhgpu_hits, flags: *mut c_uint) -> c_int;
+    pub fn bvhgpu_hits_walk_kernel(h: *const bvhgpu_hits, name: *mut c_char, cap: usize) -> c_int;
     pub fn bvhgpu_hits_fetch(h: *mut bvhgpu_hits, offsets: *mut u32, indices: *mut u32, tslice: *mut c_void, mem: c_int) -> c_int;
     pub fn bvhgpu_hits_fetch_triangles(h: *mut bvhgpu_hits, isect: *mut c_void, mem: c_int) -> c_int;
     pub fn bvhgpu_hits_fetch_closest(h: *mut bvhgpu_hits, isect: *mut c_void, shape: *mut u32, mem: c_int) -> c_int;

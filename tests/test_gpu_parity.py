@@ -235,6 +235,69 @@ def test_parity_mid_tier_boundaries(eng, orc, n, dtype):
     _full_parity(eng, orc, aabbs, orc.make_rays(o, d, dtype), 1e-5 if dtype == np.float32 else 1e-12)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lazy_flatten_same_arrays_whoever_asks_first(eng, orc, dtype):
+    """BVHGPU_TUNE_FLATTEN_LAZY (default on): the flatten behind a build writes what the wide walk reads; the FlatNode array
+    (flat_bvh.rs:60-143), the folded binary array and its LDS slot table follow when something reads them.  Whatever asks
+    first — bvhgpu_flat_nodes, a STATS / t-slice (binary) walk, nearest_to, the scene blob, a refit — sees the arrays an eager
+    flatten writes, and a wide walk that never asks gives the same CSR."""
+    from bvh_amd import Bvh, Context, FlatBvh, testbase as tb
+    from bvh_amd._lib import TUNE_FLATTEN_LAZY
+    _, aabbs = tb.create_n_cubes(1700)
+    aabbs = aabbs.astype(dtype)
+    ot = orc.build(aabbs)
+    oflat = orc.flatten(ot.nodes)
+    rays = orc.create_rays(0, 40_000, tb.default_bounds(), dtype)
+    ooff, oidx, ots, ost = orc.traverse_flat(oflat, aabbs, rays, want_t=True, threads=orc.max_threads())
+    pts = np.random.default_rng(3).uniform(-900, 900, size=(500, 3)).astype(dtype)
+    firsts = ["flat_nodes", "stats_walk", "wide_walk_then_flat", "scene_blob", "nearest", "async_step"]
+    for lazy in (1, 0):
+        for first in firsts:
+            ctx = Context(0)
+            ctx.set_tuning(TUNE_FLATTEN_LAZY, lazy)
+            bvh = Bvh.from_aabbs(aabbs, ctx)
+            flat = bvh.flatten()
+            if first == "flat_nodes":
+                assert flat.nodes.tobytes() == oflat.tobytes()
+            elif first == "stats_walk":
+                off, idx, ts, st = flat.traverse_batch(_rb(eng, rays), want_t=True, stats=True)
+                assert np.array_equal(off, ooff) and np.array_equal(idx, oidx) and st["visited"] == ost["visited"]
+            elif first == "wide_walk_then_flat":
+                off, idx, _, _ = flat.traverse_batch(_rb(eng, rays))
+                assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+            elif first == "scene_blob":
+                blob = np.zeros(flat.scene_nbytes(), dtype=np.uint8)
+                flat.scene_export(blob)
+                peer = FlatBvh.scene_import(blob, len(blob), ctx)
+                off, idx, _, st = peer.traverse_batch(_rb(eng, rays), stats=True)
+                assert np.array_equal(off, ooff) and np.array_equal(idx, oidx) and st["visited"] == ost["visited"]
+            elif first == "nearest":
+                sh, dist = flat.nearest_batch(pts)
+                osh, odist = orc.nearest(oflat, aabbs, pts)
+                assert np.array_equal(sh, osh) and dist.tobytes() == odist.tobytes()
+            else:   # the asynchronous triple of bench.py's step, twice, then every reader in turn
+                import torch
+                from bvh_amd import RayBatch
+                dev_a = torch.from_numpy(aabbs).cuda()
+                dev_r = torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda()
+                rb = RayBatch.from_device(dev_r, len(rays), dtype)
+                for _ in range(2):
+                    bvh.rebuild_async(dev_a)
+                    st = bvh.traverse_async(rb).wait()
+                    assert st["hits"] == ost["hits"]
+            # afterwards everything agrees, in any order
+            assert flat.nodes.tobytes() == oflat.tobytes(), (lazy, first)
+            off, idx, _, st = flat.traverse_batch(_rb(eng, rays), stats=True)
+            assert np.array_equal(off, ooff) and np.array_equal(idx, oidx) and st["leaf_visits"] == ost["leaf_visits"]
+            off, idx, _, _ = flat.traverse_batch(_rb(eng, rays))
+            assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+            # a refit to the same boxes re-flattens (lazily again): same arrays
+            bvh.refit(aabbs)
+            off, idx, _, _ = flat.traverse_batch(_rb(eng, rays))
+            assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+            assert flat.nodes.tobytes() == oflat.tobytes(), (lazy, first, "after refit")
+
+
 def test_rebuild_and_determinism(eng, orc):
     from bvh_amd import testbase as tb
     _, a1 = tb.create_n_cubes(500)
