@@ -33,7 +33,8 @@ The JSON line (rank 0) follows the task contract, plus:
   cpu_baseline — the oracle (C restatement of the reference, kind "port"), rebuilt on this box with -O3 -march=native,
                  timed on this box's host cores; rank 0, N = 1 only
   pipelined    — the same steps kept in flight on two streams by ONE host thread through the asynchronous C ABI
-  back_to_back — the same steps on ONE stream, the host one step behind (what the per-step wait of `value` costs)
+  step_excludes — what the timed step leaves out, each measured as the same step with it inside: ray generation, the FlatNode
+                 array written eagerly, host-resident inputs and outputs
 """
 from __future__ import annotations
 
@@ -60,10 +61,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", choices=["cubes120k", "standin-primary", "standin-incoherent"], default="cubes120k")
+    ap.add_argument("--workload", choices=["cubes120k", "cubes12m", "standin-primary", "standin-incoherent"], default="cubes120k")
     ap.add_argument("--cubes", type=int, default=10_000, help="cubes120k: create_n_cubes(n), 12 triangles each")
     ap.add_argument("--rays", type=int, default=None, help="rays per GPU per step (weak) / in total (strong); default per workload")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--harness", choices=["closest", "triangles"], default=None,
+                    help="make the headline step the reference's WHOLE bench iteration (intersect_bh, testbase.rs:819-837): ray generation on the device "
+                         "+ build + flatten + traverse + intersects_triangle on every candidate (N = 1; the default line carries these as extra_configs)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
                     help="weak: --rays per GPU; strong: --rays in total, sharded over the GPUs (default for standin-incoherent)")
     ap.add_argument("--scene-dist", choices=["auto", "bcast", "replicate", "bcast-torch"], default="auto",
@@ -80,6 +84,7 @@ def parse():
                     help="N > 1: seconds after which the extra_configs section is given up and the line measured so far is printed (a rank that "
                          "fails alone would leave the others in a barrier for ever)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-excluded", action="store_true", help="skip the step_excludes section (ray generation / host I/O / eager FlatNode array beside `value`)")
     ap.add_argument("--extra-steps", type=int, default=20)
     ap.add_argument("--parity-max-rays", type=int, default=200_000_000,
                     help="rays of a batch diffed against the oracle (default: every ray of every config, 100 M included)")
@@ -174,11 +179,33 @@ class Watchdog:
         return False
 
 
+def timed_out_line(line, pending, what, after, rccl):
+    """What the watchdog makes of the line measured so far when a section with a collective did not come back (a silent
+    fall-back must be impossible to misread).  `pending`: the exchange plan in flight — {"res": the result dict whose scene_dist_plans the
+    line shows, "plan", "stage", "workload"} — or None (the hang was elsewhere).  The plan that timed out is NAMED in scene_dist_plans with
+    "timed_out": true, never just absent; `rccl` says how far the communicator got.  Returns the JSON text (None if the line could not be
+    serialised: the main thread may be publishing into it while this runs — retried)."""
+    if pending is not None:
+        plans = pending["res"].setdefault("scene_dist_plans", {})
+        plans[pending["plan"]] = {"timed_out": True, "after_s": after, "stage": pending["stage"], "workload": pending["workload"]}
+        if line.get("scene_dist_plans") is None and line.get("workload_name") == pending["workload"]:
+            line["scene_dist_plans"] = plans
+    line["collective_watchdog"] = (f"{what} did not finish within {after:.0f} s: this line is what had been measured until then (the replicate plan has "
+                                   "no data-path collective); scene_dist_plans names the plan that timed out")
+    line["rccl"] = rccl
+    for _ in range(20):
+        try:
+            return json.dumps(line)
+        except RuntimeError:      # "dictionary changed size during iteration"
+            time.sleep(0.01)
+    return None
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 class Workload:
     """scene + ray stream of one BASELINE config, resident in HBM; also what the CPU checker needs to redo it"""
 
-    def __init__(self, name, args, dtype_name, rank, n_gpus, dev, ctx, scaling=None, rays=None):
+    def __init__(self, name, args, dtype_name, rank, n_gpus, dev, ctx, scaling=None, rays=None, harness=None):
         import torch
         from bvh_amd import RayBatch, dist as bdist, scene, testbase as tb
         from bvh_amd._lib import RAY_F32, RAY_F64
@@ -187,14 +214,23 @@ class Workload:
         self.np_dtype = np.float32 if dtype_name == "f32" else np.float64
         self.coherent = False
         self.cam = None
-        if name == "cubes120k":
+        # harness: the step is the reference's WHOLE bench iteration (intersect_bh, testbase.rs:819-837): the rays are generated on the
+        # device inside the step and Ray::intersects_triangle runs on every candidate ("triangles": every Intersection kept, CSR order;
+        # "closest": the nearest one per ray kept)
+        self.harness = harness
+        self.tag = name + (f"+{harness}" if harness else "")
+        self.ctx = ctx
+        if name in ("cubes120k", "cubes12m"):
             self.bounds = tb.default_bounds()
-            _, self.aabbs_np = tb.create_n_cubes(args.cubes, self.bounds)
-            self.config_id, per = 1 if dtype_name == "f32" else 4, rays or 1_000_000
+            n_cubes = args.cubes if name == "cubes120k" else 1_000_000
+            self.tris_np, self.aabbs_np = tb.create_n_cubes(n_cubes, self.bounds)
+            if not harness:
+                self.tris_np = None     # (12 M triangles: 432 MB of vertices nobody reads)
+            self.config_id, per = (1 if dtype_name == "f32" else 4) if name == "cubes120k" else None, rays or (1_000_000 if name == "cubes120k" else 10_000_000)
             self.scaling = scaling or "weak"
-            self.label = f"create_n_cubes({args.cubes}) = {len(self.aabbs_np)} random-cube triangles"
+            self.label = f"create_n_cubes({n_cubes}) = {len(self.aabbs_np)} random-cube triangles"
         else:
-            _, self.aabbs_np, self.bounds = scene.parse_obj(scene.make_atrium_obj(args.standin_detail))
+            self.tris_np, self.aabbs_np, self.bounds = scene.parse_obj(scene.make_atrium_obj(args.standin_detail))
             self.label = (f"procedural atrium STAND-IN for media/sponza.obj (absent from the reference checkout), "
                           f"{len(self.aabbs_np)} triangles through the OBJ loader")
             if name == "standin-primary":
@@ -217,10 +253,16 @@ class Workload:
         self.ray_size = ray_size
         self.aabbs = torch.from_numpy(self.aabbs_np.astype(self.np_dtype)).to(dev)
         self.rays_buf = torch.empty(max(self.R, 1) * ray_size, dtype=torch.uint8, device=dev)
+        self.tris = torch.from_numpy(np.ascontiguousarray(self.tris_np, dtype=self.np_dtype).reshape(-1, 9)).to(dev) if harness else None
+        self.rays = self.regen()
+
+    def regen(self):
+        """the batch's rays written into its HBM buffer by the device generators, on the context's stream, no host wait: Ray::new per ray
+        (ray_impl.rs:70-80) behind create_ray (testbase.rs:687-691) or the primary-ray camera"""
+        from bvh_amd import RayBatch
         if self.cam is not None:
-            self.rays = RayBatch.primary(self.cam, self.W, self.H, self.first, self.R, self.rays_buf, self.np_dtype, ctx)
-        else:
-            self.rays = RayBatch.generate(self.first, self.R, self.bounds, self.rays_buf, self.np_dtype, ctx)
+            return RayBatch.primary(self.cam, self.W, self.H, self.first, self.R, self.rays_buf, self.np_dtype, self.ctx)
+        return RayBatch.generate(self.first, self.R, self.bounds, self.rays_buf, self.np_dtype, self.ctx)
 
     def oracle_rays(self, orc, first, n):
         """the same rays from the oracle's restatement of the generators (f64: the f32 points widened BEFORE Ray::new, like the device)"""
@@ -230,9 +272,13 @@ class Workload:
 
     def describe(self):
         kind = "coherent primary rays (4000x2500 pinhole)" if self.coherent else "create_ray rays (seed-0 stream)"
-        return (f"configs[{self.config_id}]: {self.label}, {self.dtype_name}/3D; {self.total_rays} {kind} "
-                f"{'in total, sharded over the GPUs' if self.scaling == 'strong' else 'per GPU'}; "
-                "step = Bvh::build_par + flatten + FlatBvh::traverse (CSR hit lists in HBM)")
+        step = "step = Bvh::build_par + flatten + FlatBvh::traverse (CSR hit lists in HBM)"
+        if self.harness:
+            step = ("step = the reference's whole bench iteration (intersect_bh, testbase.rs:819-837) behind a rebuild: ray generation on the device "
+                    "(Ray::new) + Bvh::build_par + flatten + FlatBvh::traverse + Ray::intersects_triangle on every candidate — "
+                    + ("every Intersection kept (CSR order, in HBM)" if self.harness == "triangles" else "the nearest Intersection per ray kept (in HBM)"))
+        return ((f"configs[{self.config_id}]: " if self.config_id is not None else "beyond BASELINE (HBM regime): ") + f"{self.label}, {self.dtype_name}/3D; {self.total_rays} {kind} "
+                f"{'in total, sharded over the GPUs' if self.scaling == 'strong' else 'per GPU'}; " + step)
 
 
 def newest_bound(kernel_prefix, workload="cubes120k", dtype="f32", rays=1_000_000):
@@ -278,9 +324,12 @@ def run_workload(wl, args, env, steps, warmup, detailed, force_plan=None):
     import torch
     import torch.distributed as dist
     from bvh_amd import Bvh, FlatBvh, dist as bdist
-    from bvh_amd._lib import REBROADCAST, TRAVERSE_COHERENT, TRAVERSE_RAYS_READY, BvhGpuError
+    from bvh_amd._lib import REBROADCAST, TRAVERSE_CLOSEST, TRAVERSE_COHERENT, TRAVERSE_RAYS_READY, TRAVERSE_TRIANGLES, BvhGpuError
     rank, n_gpus, dev, ctx, comm = env["rank"], env["n_gpus"], env["dev"], env["ctx"], env["comm"]
     R, aabbs, rays = wl.R, wl.aabbs, wl.rays
+    if wl.harness and n_gpus != 1:
+        raise SystemExit("--harness is an N = 1 measurement (the triangle vertices are not part of the broadcast plan's step)")
+    mode_flags = (TRAVERSE_COHERENT if wl.coherent else 0) | {None: 0, "closest": TRAVERSE_CLOSEST, "triangles": TRAVERSE_TRIANGLES}[wl.harness]
 
     if n_gpus == 1:
         plans = ["single"]
@@ -294,6 +343,8 @@ def run_workload(wl, args, env, steps, warmup, detailed, force_plan=None):
     bvh = Bvh.from_aabbs(aabbs, ctx) if own_tree else None
     if own_tree:
         bvh.flatten_in_place()
+        if wl.harness:
+            bvh.set_triangles(wl.tris)     # vertices of the shapes, resident in HBM like the AABBs (a rebuild of as many shapes keeps them)
     blob, peer = None, None
     if "bcast-torch" in plans:
         nbytes = bdist.broadcast_nbytes(bvh.scene_nbytes() if rank == 0 else 0, dev, 0)
@@ -327,6 +378,10 @@ def run_workload(wl, args, env, steps, warmup, detailed, force_plan=None):
             return tree.traverse_batch(rays, fetch=False, coherent=wl.coherent)[3]   # FlatBvh::traverse, CSR stays in HBM
         # single / replicate: FlatBvh::build (flat_bvh.rs:328-331) and FlatBvh::traverse enqueued back to back, ONE host round trip
         # per step: the wait validates the build, completes the batch and is the end of the step (nothing of the next step is in flight)
+        if wl.harness:      # intersect_bh: the rays are made inside the step (k_gen_rays / k_gen_primary on the same stream), then walked + intersected
+            wl.regen()
+            bvh.rebuild_async(aabbs)
+            return bvh.traverse_async(rays, flags=mode_flags).wait()
         bvh.rebuild_async(aabbs)
         return bvh.traverse_async(rays, flags=flags).wait()
 
@@ -358,7 +413,8 @@ def run_workload(wl, args, env, steps, warmup, detailed, force_plan=None):
     # Settle the GPU's clocks before the W warmup steps: a 0.34 ms step timed over K = 20 steps right after start-up reads 2 % low
     # (0.3417 against 0.334–0.337 ms over K >= 100).  Untimed, the same step, a fixed count on every rank (no collective decides it).
     # (plans with an exchange step — a collective per step, possibly the slow torch transport — and big batches settle in 20 steps)
-    for _ in range(args.settle_steps if (wl.R <= 2_000_000 and state["plan"] in ("single", "replicate")) else min(args.settle_steps, 20)):
+    settle = args.settle_steps if (wl.R <= 2_000_000 and state["plan"] in ("single", "replicate")) else min(args.settle_steps, 20)
+    for _ in range(settle):
         step()
     for _ in range(warmup):
         step()
@@ -372,17 +428,26 @@ def run_workload(wl, args, env, steps, warmup, detailed, force_plan=None):
     builder = plan not in ("bcast", "bcast-torch") or rank == 0
     tree = bvh if builder else state["peer"]
     ph = dict(build_ms=[], flatten_ms=[], traverse_kernel_ms=[], traverse_total_ms=[])
-    stats_walk = 0
+    stats_walk, walk_kernel = 0, ""
     for _ in range(max(5, min(steps, 20))):
         if builder:
             bvh.rebuild(aabbs)
             bvh.flatten_in_place()
-        stats_walk = tree.traverse_batch(rays, fetch=False, coherent=wl.coherent)[3].get("walk", 0)
+        hh = tree.traverse_async(rays, flags=mode_flags)     # (the synchronous entry points cover index batches only without a fetch)
+        hh.wait()
+        stats_walk, walk_kernel = hh.walk_flags(), hh.walk_kernel()
         t = ctx.last_timings()
         for k in ph:
             ph[k].append(t[k])
     ctx.enable_timing(False)
     phases = {k: float(np.mean(v)) for k, v in ph.items()}
+    if wl.harness:    # the generator's share of the step, timed alone (its launch is one of the step's)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            wl.regen()
+        torch.cuda.synchronize(dev)
+        phases["ray_gen_ms"] = (time.perf_counter() - t0) / 20 * 1e3
     # exact visit counters (reference-equivalent loop iterations, from the binary walk) for the algorithmic byte count
     stats = tree.traverse_batch(rays, stats=True, fetch=False, coherent=wl.coherent)[3]
     V, VL, H = stats["visited"], stats["leaf_visits"], stats["hits"]
@@ -392,8 +457,8 @@ def run_workload(wl, args, env, steps, warmup, detailed, force_plan=None):
         dist.all_reduce(ht, op=dist.ReduceOp.SUM)
         hits_all = int(ht.item())
     out = {
-        "workload": wl.name, "config": wl.config_id, "dtype": wl.dtype_name, "value": round(value, 3), "unit": "Mrays/s",
-        "ms_per_step": round(ms_per_step, 4), "steps": steps, "scaling": wl.scaling, "triangles": wl.n_tri,
+        "workload": wl.tag, "harness": wl.harness, "config": wl.config_id, "dtype": wl.dtype_name, "value": round(value, 3), "unit": "Mrays/s",
+        "ms_per_step": round(ms_per_step, 4), "steps": steps, "warmup": warmup, "settle_steps": settle, "scaling": wl.scaling, "triangles": wl.n_tri,
         "rays_this_rank": R, "rays_total": wl.total_rays, "scene_dist": plan,
         "phases_ms": {k: round(v, 4) for k, v in phases.items()},
         "hits_all_ranks": int(hits_all), "visited_per_ray": round(V / max(R, 1), 2),
@@ -409,25 +474,32 @@ def run_workload(wl, args, env, steps, warmup, detailed, force_plan=None):
     flat_sz = 36 if wl.dtype_name == "f32" else 64
     # per ray  Ray in + V*FlatNode + V_leaf*shape AABB + CSR out 4*(H+1)
     algo_bytes = R * wl.ray_size + V * flat_sz + VL * 6 * elem + 4 * (H + R)
+    if wl.harness == "triangles":   # + the triangle stage: 9 vertices read, Intersection{distance,u,v} written per candidate
+        algo_bytes += H * (9 + 3) * elem
+    elif wl.harness == "closest":   # + 9 vertices read per candidate; one Intersection + shape per ray instead of the CSR
+        algo_bytes += H * 9 * elem + R * (3 * elem + 4) - 4 * (H + R)
     kern_s = phases["traverse_kernel_ms"] * 1e-3
-    ctype = "float" if wl.dtype_name == "f32" else "double"
-    if R >= 16384:   # the wide walk; rays are cut into 16 items below ~2 M rays (traverse.hip `few_rays`), walked whole above
-        kern_name = f"bvhgpu::k_traverse_wide<{ctype}, 0, {2 if R < N_CU * 2048 * 4 else 0},"
-    else:
-        kern_name = f"bvhgpu::k_traverse<{ctype}, 0"
+    # the walk kernel's name as the library reports it for the timed batch shape (bvhgpu_hits_walk_kernel: spelled the way rocprofv3
+    # prints it, so the counters of profiles/*_bound.json are looked up under the name the launch really had)
+    kern_name = walk_kernel
     from bvh_amd._lib import WALK_F64_GUIDE
-    guide_ran = bool(stats_walk & WALK_F64_GUIDE)   # bvhgpu_hits_walk_info of the timed batch shape: which kernel walked it
-    if guide_ran:   # an f64 index batch walked by the f32 kernel over the tree's guide boxes (template flag GUIDE = 1)
-        items = 2 if R < N_CU * 2048 * 4 else 0
-        kern_name = f"bvhgpu::k_traverse_wide<float, 0, {items}, 1024, 8, 1>"
-    pmc, src = newest_bound(kern_name, wl.name, wl.dtype_name, R)
+    guide_ran = bool(stats_walk & WALK_F64_GUIDE)   # bvhgpu_hits_walk_info: an f64 index batch walked by the f32 kernel over the guide boxes
+    pmc, src = newest_bound(kern_name, wl.tag, wl.dtype_name, R)
     roof = {
-        "kernel": kern_name.rstrip("<,"), "kernel_ms": round(phases["traverse_kernel_ms"], 4),
+        "kernel": kern_name, "kernel_ms": round(phases["traverse_kernel_ms"], 4),
         "algorithmic_bytes_per_launch": int(algo_bytes),
         "algorithmic_gbs": round(algo_bytes / kern_s / 1e9, 1),
-        "algorithmic_note": "reference-algorithm bytes (SURVEY §8d) / kernel time; the working set is LDS- and cache-resident, so this "
-                            "exceeds what HBM delivers and is NOT the roofline fraction — `frac` is",
-        "slab_tests_per_s": round(V / kern_s, 1), "visited": int(V), "leaf_visits": int(VL), "hits": int(H),
+        # SURVEY §8d's own figure, stated so that nobody has to derive it: algorithmic bytes / kernel time / 8 TB/s.  Above 1 (or above
+        # `hbm_frac` by a wide margin) means the kernel does not do the §8d traffic at all: it reads the tree out of LDS and L2
+        "algorithmic_frac": round(algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS, 4),
+        "algorithmic_note": "reference-algorithm bytes (SURVEY §8d: Ray + V x FlatNode + V_leaf x shape AABB + CSR) / kernel time against the 8 TB/s "
+                            "HBM peak.  It is NOT a bandwidth: the walk tests four grandchildren per step out of an LDS- and L2-resident image, "
+                            "so the bytes the reference's loop would move never cross the HBM interface — `hbm_frac` (PMC) is what does, `frac` is "
+                            "the binding resource",
+        "slab_tests_per_s": round(V / kern_s, 1),
+        "slab_tests_note": "reference-equivalent: ray/AABB tests of the reference's loop on these rays (the binary STATS walk's visit count = the "
+                           "oracle's) per second of the wide walk's kernel time — not a count of the tests the wide kernel executes",
+        "visited": int(V), "leaf_visits": int(VL), "hits": int(H),
     }
     if wl.dtype_name == "f64":
         roof["f64_walk"] = ("guide: inner-node tests in f32 on boxes that contain the f64 ones, every leaf candidate decided by the f64 slab test "
@@ -444,6 +516,8 @@ def run_workload(wl, args, env, steps, warmup, detailed, force_plan=None):
             "bound": bound, "achieved": round(ach, 2), "peak": round(peak, 1), "unit": unit, "frac": round(fr[bound], 4),
             "traffic": pmc.get("hbm_bytes"), "hbm_frac": round(fr.get("hbm", 0), 4), "valu_frac": round(fr.get("valu", 0), 4),
             "lds_frac": round(fr.get("lds", 0), 4), "wait_frac": pmc.get("wait_frac"), "profile_kernel_us": pmc.get("avg_us"),
+            "algorithmic_void": ("working set cache-resident: the HBM-side traffic (PMC) is %.3f of the algorithmic bytes, so algorithmic_frac prices "
+                                 "bytes that never reach HBM" % (pmc["hbm_bytes"] / algo_bytes)) if pmc.get("hbm_bytes") and pmc["hbm_bytes"] < 0.5 * algo_bytes else None,
             "profile_rays_per_launch": pmc.get("scaled_from_rays", R),
             "source": f"{src}: separate rocprofv3 --pmc passes of this workload (per-launch means; FETCH_SIZE doubled per "
                       "MI355X_MICROARCH.md) over the live HIP-event kernel time; peaks: 8 TB/s HBM, 1024 SIMDs x 2.4 GHz / 2 cycles per "
@@ -491,7 +565,7 @@ def check_parity(wl, env, orc, n_check, chunk=1_000_000):
     tree = last["tree"]
     n = min(n_check, wl.R)
     a = wl.aabbs_np.astype(wl.np_dtype)
-    ot = orc.build(a, threads=min(16, orc.max_threads()))
+    ot = orc.build(a, threads=orc.max_threads(), schedule="fast")     # (byte-equal to the serial build: tests/test_oracle_golden.py)
     oflat = orc.flatten(ot.nodes)
     try:
         last["oracle_levels"] = float(orc.tree_stats(ot.nodes, a)["mean_leaf_depth"])   # = sum over the levels of live shapes / N
@@ -519,6 +593,140 @@ def check_parity(wl, env, orc, n_check, chunk=1_000_000):
             "csr_offsets_and_indices_equal": csr_equal, "visit_counters_equal": cnt_equal, "bvh_nodes_equal": nodes_equal,
             "hits": int(H), "against": "oracle (C restatement of bvh_node.rs / flat_bvh.rs, see oracle/bvh_oracle.h)",
             "oracle_chunks": n_chunks, "oracle_traverse_s": round(t_or, 4)}
+
+
+def check_parity_harness(wl, env, orc, n_check, chunk=1_000_000, cpu_sample=1_000_000):
+    """The harness step's result on this rank's WHOLE batch against the oracle's restatement of the same loop (testbase.rs:826-836 behind
+    FlatBvh::traverse): "closest" — (distance, u, v, shape) of every ray, bit for bit; "triangles" — CSR offsets / indices and the
+    Intersection of every candidate, bit for bit.  Also times the oracle's whole loop (orc.harness_loop = intersect_bh: ray generation,
+    one walk per ray into a growable list, intersects_triangle on every candidate) on `cpu_sample` rays for the CPU figure beside it."""
+    from bvh_amd import RayBatch
+    last = env["last"]
+    tree = last["tree"]
+    n = min(n_check, wl.R)
+    a = wl.aabbs_np.astype(wl.np_dtype)
+    tris = np.ascontiguousarray(wl.tris_np, dtype=wl.np_dtype).reshape(-1, 9)
+    t0 = time.perf_counter()
+    ot = orc.build(a, threads=orc.max_threads(), schedule="fast")
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    oflat = orc.flatten(ot.nodes)
+    t_flat = time.perf_counter() - t0
+    sub = RayBatch(n, wl.np_dtype, host=None, device=wl.rays_buf, device_ptr=wl.rays_buf.data_ptr())
+    if wl.harness == "closest":
+        g_isect, g_shape, _ = tree.closest_hits(sub, coherent=wl.coherent)
+    else:
+        g_off, g_idx, g_isect, _ = tree.intersect_triangles(sub, coherent=wl.coherent)
+    equal, H, n_chunks = True, 0, 0
+    for c0 in range(0, n, chunk):
+        m = min(chunk, n - c0)
+        rays_o = wl.oracle_rays(orc, wl.first + c0, m)
+        ooff, oidx, _, ost = orc.traverse_flat(oflat, a, rays_o, threads=orc.max_threads())
+        o_isect, o_closest, o_prim = orc.triangle_stage(tris, rays_o, ooff, oidx)
+        if wl.harness == "closest":
+            equal = equal and g_isect[c0:c0 + m].tobytes() == o_closest.tobytes() and bool(np.array_equal(g_shape[c0:c0 + m], o_prim))
+        else:
+            base, end = int(g_off[c0]), int(g_off[c0 + m])
+            equal = (equal and bool(np.array_equal(g_off[c0:c0 + m + 1] - np.uint32(base), ooff) and np.array_equal(g_idx[base:end], oidx))
+                     and g_isect[base:end].tobytes() == o_isect.tobytes())
+        H += ost["hits"]; n_chunks += 1
+    nodes_equal = bool(last["bvh"].nodes.tobytes() == ot.nodes.tobytes()) if last["builder"] and last["bvh"] is not None else None
+    out = {"checked_rays": int(n), "rays_this_rank": int(wl.R), "equal": bool(equal and nodes_equal is not False), "candidates": int(H),
+           "what": ("closest (distance, u, v, shape) of every ray" if wl.harness == "closest" else "CSR + Intersection{distance,u,v} of every candidate")
+                   + ", byte for byte", "bvh_nodes_equal": nodes_equal,
+           "against": "oracle: traverse_flat + triangle_stage (restatement of flat_bvh.rs:396-431 + testbase.rs:826-836 + ray_impl.rs:154-213)"}
+    cpu = None
+    if wl.dtype_name == "f32":   # the reference's harness is f32
+        ns = min(cpu_sample, wl.R)
+        best, best_th = 1e9, 0
+        cores = orc.max_threads()
+        for th in sorted({16, 32, 64, 128, cores} & set(range(1, cores + 1))):
+            t0 = time.perf_counter()
+            orc.harness_loop(oflat, a, tris, wl.first, ns, wl.bounds, wl.cam, getattr(wl, "W", 0), getattr(wl, "H", 0), threads=th)
+            dt = time.perf_counter() - t0
+            if dt < best:
+                best, best_th = dt, th
+        total = t_build + t_flat + best * (wl.R / ns)
+        cpu = {"value": round(wl.R / total / 1e6, 4), "unit": "Mrays/s", "cores": best_th, "kind": "port",
+               "sample": f"oracle (C restatement, portable -O2 build), the same step: build {t_build * 1e3:.1f} ms (scalable schedule, all cores) + flatten "
+                         f"{t_flat * 1e3:.1f} ms + intersect_bh on {ns} of the {wl.R} rays ({best * 1e3:.1f} ms on {best_th} threads: ray generation, one walk "
+                         "per ray into a growable list, intersects_triangle on every candidate), scaled to the batch",
+               "loop_ms_scaled": round(best * (wl.R / ns) * 1e3, 2), "build_ms": round(t_build * 1e3, 2)}
+    return out, cpu
+
+
+def measure_excluded(wl, args, env, ms_step):
+    """The three things the timed step of `value` does not contain, each as the SAME step with that thing put inside, K steps timed the
+    same way (device sync on both sides):
+      with_ray_gen      Ray::new for every ray of the batch (ray_impl.rs:70-80 via create_ray, testbase.rs:687-691: the reference's bench
+                        iteration starts with it) generated on the device inside the step — k_gen_rays on the step's stream
+      with_flat_array   the FlatNode array in the reference's layout (flat_bvh.rs:60-143) written by every step's flatten
+                        (BVHGPU_TUNE_FLATTEN_LAZY = 0) instead of on first use
+      host_io           shape AABBs and rays start in HOST memory, the CSR ends in host memory: what GpuBvh::build + traverse_batch of the
+                        Rust shim costs a caller whose data lives in Vecs (rust/bvh-mi355x/src/lib.rs) — upload, step, download"""
+    import torch
+    from bvh_amd import Bvh, RayBatch
+    from bvh_amd._lib import TRAVERSE_RAYS_READY, TUNE_FLATTEN_LAZY
+    dev, ctx = env["dev"], env["ctx"]
+    K = max(args.steps, 100)
+    bvh = Bvh.from_aabbs(wl.aabbs, ctx)
+    bvh.flatten_in_place()
+
+    def timed(fn, k):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / k * 1e3
+
+    def entry(ms, what):
+        return {"value": round(wl.R / (ms * 1e-3) / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(ms, 4),
+                "delta_ms_vs_value": round(ms - ms_step, 4), "what": what}
+
+    res = {"steps": K}
+
+    def step_gen():
+        bvh.rebuild_async(wl.aabbs)
+        RayBatch.generate(wl.first, wl.R, wl.bounds, wl.rays_buf, wl.np_dtype, ctx)   # the same buffer, rewritten every step
+        return bvh.traverse_async(wl.rays, flags=0).wait()
+    res["with_ray_gen"] = entry(timed(step_gen, K), "create_ray + Ray::new of all rays on the device inside every step (k_gen_rays), then the step of `value`")
+
+    ctx.set_tuning(TUNE_FLATTEN_LAZY, 0)
+    try:
+        def step_eager():
+            bvh.rebuild_async(wl.aabbs)
+            return bvh.traverse_async(wl.rays, flags=TRAVERSE_RAYS_READY).wait()
+        res["with_flat_array"] = entry(timed(step_eager, K), "every flatten also writes the reference-layout FlatNode array + the folded binary array "
+                                                             "(BVHGPU_TUNE_FLATTEN_LAZY = 0); `value` writes them on first use (bvhgpu_flat_nodes, a binary walk …)")
+    finally:
+        ctx.set_tuning(TUNE_FLATTEN_LAZY, 1)
+
+    # host I/O: pageable numpy arrays, like a Rust caller's Vecs
+    a_host = np.ascontiguousarray(wl.aabbs_np.astype(wl.np_dtype))
+    rays_host = torch.empty(wl.R * wl.ray_size, dtype=torch.uint8)
+    rays_host.copy_(wl.rays_buf[:wl.R * wl.ray_size])
+    from bvh_amd._lib import RAY_F32, RAY_F64
+    rb_host = RayBatch(wl.R, wl.np_dtype, host=rays_host.numpy().view(RAY_F32 if wl.dtype_name == "f32" else RAY_F64))
+    nbytes = {"aabbs_up": int(a_host.nbytes), "rays_up": int(wl.R * wl.ray_size)}
+
+    def step_host():
+        bvh.rebuild(a_host, flatten=True)
+        off, idx, _, _ = bvh.traverse_batch(rb_host, fetch=True)
+        return off, idx
+    off, idx = step_host()
+    nbytes["csr_down"] = int(off.nbytes + idx.nbytes)
+    kh = max(10, min(K, 30))
+    e = entry(timed(step_host, kh), "AABBs + rays uploaded from pageable host memory and the CSR fetched to host memory inside every step "
+                                   "(bvhgpu_rebuild_flat(HOST) + bvhgpu_traverse(HOST) + bvhgpu_hits_fetch(HOST): the Rust shim's GpuBvh::build + traverse_batch)")
+    e["steps"] = kh
+    e["bytes_per_step"] = nbytes
+    e["pcie_gbs"] = round(sum(nbytes.values()) / (e["ms_per_step"] * 1e-3) / 1e9, 2)
+    res["host_io"] = e
+    bvh.close()
+    return res
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -587,14 +795,25 @@ def main():
         raise SystemExit(f"--gpus {args.gpus}: the process group holds {ranks_seen} ranks")
 
     line = {}            # the JSON line as far as it has been measured: what the watchdog prints if an exchange section hangs
-    xstate = {"comm_err": None, "tried_comm": False}
+    xstate = {"comm_err": None, "tried_comm": False, "pending": None}
 
     def emit_and_exit(what, seconds=None):
-        line["collective_watchdog"] = (f"{what} did not finish within {seconds if seconds is not None else args.collective_timeout:.0f} s: this line is what had been measured until "
-                                       "then (the replicate plan has no data-path collective)")
-        if rank == 0 and line.get("value") is not None:
-            os.write(json_fd, (json.dumps(line) + "\n").encode())
-        os._exit(0 if line.get("value") is not None else 3)
+        """runs on the watchdog's helper thread: print the line as far as it has been measured and end the process — whatever happens on
+        the way (os._exit sits in a `finally`: an exception here must not bring back the hang the watchdog exists to prevent)"""
+        code = 3
+        try:
+            after = seconds if seconds is not None else args.collective_timeout
+            try:
+                rccl = env["comm"].info() if env["comm"] is not None else {"nranks": None, "formed": False, "error": xstate["comm_err"]}
+            except Exception as e:
+                rccl = {"nranks": None, "formed": env["comm"] is not None, "error": repr(e)}
+            text = timed_out_line(line, xstate.get("pending"), what, after, rccl)
+            if text is not None and line.get("value") is not None:
+                if rank == 0:
+                    os.write(json_fd, (text + "\n").encode())
+                code = 0
+        finally:
+            os._exit(code)
 
     def make_comm():
         """the RCCL communicator of the C ABI (torch.distributed only carries the 128-byte id) — made AFTER the replicate plan has been
@@ -625,17 +844,22 @@ def main():
             return run_workload(w, args, env, steps, warmup, detailed), None
         res = run_workload(w, args, env, steps, warmup, detailed, force_plan="replicate")
         keep = dict(env["last"])
+        pick = lambda r: {k: r[k] for k in ("value", "ms_per_step", "phases_ms", "hits_all_ranks") if k in r}
+        res["scene_dist_plans"] = {"replicate": pick(res)}
         if publish:
             publish(res)
+        guess = "bcast" if args.backend == "nccl" else "bcast-torch"
+        xstate["pending"] = {"res": res, "plan": guess, "stage": "forming the RCCL communicator", "workload": w.tag}
         with Watchdog(args.collective_timeout, lambda: emit_and_exit(f"the exchange plan of {w.name}")):
             if os.environ.get("BVH_BENCH_TEST_HANG_EXCHANGE"):   # tests: a collective that never returns (tests/test_gpu_dist.py)
                 time.sleep(10 ** 6)
             comm = make_comm()
             xplan = "bcast" if comm is not None else "bcast-torch"
+            xstate["pending"].update(plan=xplan, stage="the exchange plan's steps (communicator formed)")
             res_x = run_workload(w, args, env, steps, warmup, detailed, force_plan=xplan)
+        xstate["pending"] = None
         probe = {"replicate": res["ms_per_step"], xplan: res_x["ms_per_step"]}
-        both = {"replicate": {k: res[k] for k in ("value", "ms_per_step", "phases_ms", "hits_all_ranks")},
-                xplan: {k: res_x[k] for k in ("value", "ms_per_step", "phases_ms", "hits_all_ranks") if k in res_x}}
+        both = {"replicate": pick(res), xplan: pick(res_x)}
         if res_x["ms_per_step"] < res["ms_per_step"]:
             res = res_x
         else:
@@ -647,9 +871,12 @@ def main():
     def compose(res):
         out = {
             "metric": "Mrays/s (build+traverse)", "value": res["value"], "unit": "Mrays/s", "n_gpus": n_gpus,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+            "steps": args.steps, "warmup": args.warmup, "settle_steps": res.get("settle_steps"),
+            "settle_note": "untimed steps of the same kind run BEFORE the W warmup steps (clock ramp after start-up: the 0.33 ms step read 2-3 % "
+                           "low without them); --settle-steps 0 switches them off",
+            "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "workload_name": wl.name,
+            "workload_name": wl.tag, "harness": wl.harness,
             "config": {
                 "workload": wl.describe(), "triangles": wl.n_tri, "rays_per_gpu": wl.R, "rays_total": wl.total_rays,
                 "scene_dist": res["scene_dist"],
@@ -669,7 +896,7 @@ def main():
             out["rccl_comm_error"] = xstate["comm_err"]
         return out
 
-    wl = Workload(args.workload, args, args.dtype, rank, n_gpus, dev, ctx, scaling=args.scaling, rays=args.rays)
+    wl = Workload(args.workload, args, args.dtype, rank, n_gpus, dev, ctx, scaling=args.scaling, rays=args.rays, harness=args.harness)
     torch.cuda.synchronize(dev)
     res, _ = measure(wl, args.steps, args.warmup, True, publish=lambda r: line.update(compose(r)))
     main_env = dict(env["last"])
@@ -681,7 +908,11 @@ def main():
     parity_run = None
     if not args.no_parity and rank == 0:
         from oracle import orc
-        parity_run = check_parity(wl, env, orc, min(wl.R, args.parity_max_rays))
+        if wl.harness:
+            parity_run, cpu_h = check_parity_harness(wl, env, orc, min(wl.R, args.parity_max_rays))
+            out["cpu_harness"] = cpu_h
+        else:
+            parity_run = check_parity(wl, env, orc, min(wl.R, args.parity_max_rays))
         out["parity"] = parity_run
         if out.get("roofline_build") and env["last"].get("oracle_levels"):
             out["roofline_build"] = build_roofline(wl, main_env["phases"], env["last"]["oracle_levels"])
@@ -729,98 +960,106 @@ def main():
         for c, tr, h, _ in lanes:
             h.close(); tr.close(); c.close()
 
-    # ---- supplementary: the same steps on ONE stream with the host one step behind (N = 1) ----
-    # `value` waits for every step before it enqueues the next one, so its step contains a host round trip (completion seen → next
-    # launch reaches the GPU: ≈ 12 µs in the kernel trace, EXPERIMENTS.md "Where the step's 342 µs are").  Here the host enqueues step
-    # k + 1 behind step k on the same stream and only then waits for step k (two result objects used alternately): the GPU runs exactly
-    # the same kernels, serially, with no overlap between steps — the difference to `value` is the host's share of the step.
-    if n_gpus == 1 and args.pipeline_streams > 0:
-        c = Context(local_rank)
-        tr = Bvh.from_aabbs(wl.aabbs, c)
-        tr.flatten_in_place()
-        hs = [_Hits(c), _Hits(c)]
-        for k in range(6):
-            tr.rebuild_async(wl.aabbs); tr.traverse_async(wl.rays, hs[k % 2], flags=RAYS_READY); hs[k % 2].wait()
-        torch.cuda.synchronize(dev)
-        K = max(args.steps, 200)
-        hits_b = []
-        t0 = time.perf_counter()
-        for k in range(K):
-            tr.rebuild_async(wl.aabbs)
-            tr.traverse_async(wl.rays, hs[k % 2], flags=RAYS_READY)
-            if k:
-                hits_b.append(hs[(k - 1) % 2].wait()["hits"])
-        hits_b.append(hs[(K - 1) % 2].wait()["hits"])
-        torch.cuda.synchronize(dev)
-        dtb = time.perf_counter() - t0
-        out["back_to_back"] = {
-            "streams": 1, "host_threads": 1, "steps": K, "value": round(K * wl.R / dtb / 1e6, 3), "unit": "Mrays/s",
-            "ms_per_step": round(dtb * 1e3 / K, 4), "hits_every_step_equal": bool(len(set(hits_b)) == 1 and len(hits_b) == K),
-            "hits": hits_b[0] if hits_b else None,
-            "note": f"{K} steps enqueued back to back on ONE stream, the host waiting for step k after it has enqueued step k + 1 (two result "
-                    "objects): the same kernels in the same order with no overlap between steps; ms_per_step - this = the host round trip "
-                    "inside every step of `value` — never reported as `value`",
-        }
-        for h in hs:
-            h.close()
-        tr.close(); c.close()
+    # (A `back_to_back` figure — one stream, the host one step behind — was reported in round 4 and withdrawn: bvhgpu_hits_wait
+    #  synchronises the whole stream and a rebuild completes the batches pending on its tree, so that loop was the `value` loop again
+    #  (ADVICE r4).  What overlapping steps buy is the `pipelined` figure above; what the host costs inside a step is in the kernel
+    #  trace: ≈ 12 µs between the last kernel of a step and the first of the next, EXPERIMENTS.md "Where the step's 342 µs are".)
 
-    # ---- the other BASELINE configs, driver-observed in the same line ----
-    if not args.no_extra and args.workload == "cubes120k" and args.dtype == "f32":
+    # ---- what the timed step leaves out, measured beside it (N = 1) — never reported as `value` ----
+    if n_gpus == 1 and args.workload == "cubes120k" and not args.no_excluded:
+        try:
+            out["step_excludes"] = measure_excluded(wl, args, env, out["ms_per_step"])
+        except Exception as e:   # a supplementary figure must never take the headline down
+            out["step_excludes"] = {"error": repr(e)}
+
+    # ---- the other BASELINE configs, the reference's whole harness loop and a scene beyond the caches, driver-observed in the same line ----
+    if not args.no_extra and args.workload == "cubes120k" and args.dtype == "f32" and args.harness is None:
         extras = []
         out["extra_configs"] = extras
+        E = lambda name, dt="f32", scaling=None, rays=None, harness=None, **kw: dict(name=name, dt=dt, scaling=scaling, rays=rays, harness=harness, **kw)
         if n_gpus == 1:
-            plan = [("standin-primary", "f32", None, None), ("standin-incoherent", "f32", "weak", 12_500_000), ("cubes120k", "f64", None, None),
-                    ("standin-incoherent", "f32", "strong", 100_000_000)]   # configs[3] whole on ONE GPU: the N = 1 point of the strong curve
+            plan = [
+                # intersect_bh (testbase.rs:819-837) whole, behind a rebuild: ray generation + build + flatten + walk + triangle stage
+                E("cubes120k", harness="closest"), E("cubes120k", harness="triangles"), E("standin-primary", harness="closest"),
+                E("standin-primary"), E("standin-incoherent", scaling="weak", rays=12_500_000), E("cubes120k", dt="f64"),
+                E("standin-incoherent", scaling="strong", rays=100_000_000),   # configs[3] whole on ONE GPU: the N = 1 point of the strong curve
+                # the regime the north star's HBM language is about: a tree far beyond L2 + MALL (create_n_cubes(1 000 000) = 12 M triangles)
+                E("cubes12m", rays=10_000_000, parity_rays=1_000_000),
+            ]
+            only = os.environ.get("BVH_BENCH_EXTRAS")     # developer runs: comma-separated entry numbers of the list above
+            if only:
+                plan = [plan[int(k)] for k in only.split(",")]
         else:
-            plan = [("standin-incoherent", "f32", "strong", 100_000_000)]
+            plan = [E("standin-incoherent", scaling="strong", rays=100_000_000)]
         # N > 1: the section's barriers and all-reduces are only safe while every rank gets through it — a rank that fails alone (its
         # `except` below skips the collectives) would leave the others waiting for ever, and the headline with them
         import contextlib
         guard = (Watchdog(args.extras_timeout, lambda: emit_and_exit("the extra_configs section", args.extras_timeout)) if n_gpus > 1
                  else contextlib.nullcontext())
-        guard.__enter__()
-        for name, dt, scaling, nrays in plan:
-            try:
-                w2 = Workload(name, args, dt, rank, n_gpus, dev, ctx, scaling=scaling, rays=nrays)
-                if name == "standin-incoherent" and n_gpus == 1 and scaling == "weak":   # the shard rank 5 of 8 owns (tests/test_gpu_scene.py checks the same one)
-                    from bvh_amd import RayBatch
-                    w2.first = 62_500_000
-                    w2.rays = RayBatch.generate(w2.first, w2.R, w2.bounds, w2.rays_buf, w2.np_dtype, ctx)
-                r2, _ = measure(w2, args.extra_steps, 3, False)
-                if name == "standin-incoherent" and n_gpus == 1:
-                    r2["note"] = ("one GPU's share of configs[3]: rays [62.5 M, 75 M) of the 100 M-ray stream (rank 5 of 8)" if scaling == "weak" else
-                                  "configs[3] whole: all 100 M rays of the stream on one GPU in one batch — the N = 1 point of the strong-scaling "
-                                  "curve whose N > 1 points the same entry carries when bench.py runs with --gpus N")
-                if name == "standin-incoherent" and scaling == "strong" and nrays == 100_000_000 and args.standin_detail == 16:
-                    # the whole stream's hit count as one GPU produced it with oracle parity on all 100 M rays (BENCH_r03 extra_configs):
-                    # the shards of an N > 1 run must add up to exactly this
-                    r2["hits_n1_reference"] = 457_389_170
-                    r2["hits_match_n1_reference"] = bool(r2["hits_all_ranks"] == 457_389_170)
-                if dt == "f64":
-                    r2["note"] = ("tree, rays, builder and every test that decides a hit in f64; the walk's inner-node tests run on f32 boxes that contain "
-                                  "the f64 ones (BVHGPU_TUNE_WIDE_F64_GUIDE, DESIGN.md §4 \"f64 guide walk\"): same lists, checked against the f64 oracle below")
-                if rank == 0 and not args.no_parity:
-                    from oracle import orc
-                    r2["parity"] = check_parity(w2, env, orc, min(w2.R, args.parity_max_rays))
-                if dt == "f64":
-                    # the same step with EVERY slab test of the walk in double precision (BASELINE configs[4] names "double-precision slab
-                    # test"): k_traverse_wide<double, …>, its own timing, roofline (its own counter passes when profiles/ holds them) and parity
-                    from bvh_amd._lib import TUNE_WIDE_F64_GUIDE
-                    ctx.set_tuning(TUNE_WIDE_F64_GUIDE, 0)
-                    try:
-                        r3 = run_workload(w2, args, env, args.extra_steps, 3, detailed=False)
-                        if rank == 0 and not args.no_parity:
-                            r3["parity"] = check_parity(w2, env, orc, min(w2.R, args.parity_max_rays))
-                        r2["pure_f64_walk"] = {k: r3[k] for k in ("value", "unit", "ms_per_step", "steps", "phases_ms", "hits_all_ranks", "roofline", "parity") if k in r3}
-                    finally:
-                        ctx.set_tuning(TUNE_WIDE_F64_GUIDE, 1)
-                extras.append(r2)
-                del w2
-                torch.cuda.empty_cache()
-            except Exception as e:   # an extra config must never take the headline line down
-                extras.append({"workload": name, "dtype": dt, "error": repr(e)})
-        guard.__exit__(None, None, None)
+        with guard:
+            for e in plan:
+                name, dt, scaling, nrays = e["name"], e["dt"], e["scaling"], e["rays"]
+                try:
+                    w2 = Workload(name, args, dt, rank, n_gpus, dev, ctx, scaling=scaling, rays=nrays, harness=e["harness"])
+                    if name == "standin-incoherent" and n_gpus == 1 and scaling == "weak":   # the shard rank 5 of 8 owns (tests/test_gpu_scene.py checks the same one)
+                        w2.first = 62_500_000
+                        w2.rays = w2.regen()
+                    provisional = []
+
+                    def publish_extra(r):      # N > 1: the replicate result is on the line before the exchange plan is tried
+                        provisional.append(r)
+                        extras.append(r)
+                    r2, _ = measure(w2, args.extra_steps, 3, False, publish=publish_extra)
+                    for r in provisional:       # (replaced by the finished entry below)
+                        if r in extras:
+                            extras.remove(r)
+                    if name == "standin-incoherent" and n_gpus == 1:
+                        r2["note"] = ("one GPU's share of configs[3]: rays [62.5 M, 75 M) of the 100 M-ray stream (rank 5 of 8)" if scaling == "weak" else
+                                      "configs[3] whole: all 100 M rays of the stream on one GPU in one batch — the N = 1 point of the strong-scaling "
+                                      "curve whose N > 1 points the same entry carries when bench.py runs with --gpus N")
+                    if name == "standin-incoherent" and scaling == "strong" and nrays == 100_000_000 and args.standin_detail == 16:
+                        # the whole stream's hit count as one GPU produced it with oracle parity on all 100 M rays (BENCH_r03 extra_configs):
+                        # the shards of an N > 1 run must add up to exactly this — under EVERY plan that was measured
+                        r2["hits_n1_reference"] = 457_389_170
+                        r2["hits_match_n1_reference"] = bool(r2["hits_all_ranks"] == 457_389_170)
+                        for pl in (r2.get("scene_dist_plans") or {}).values():
+                            if "hits_all_ranks" in pl:
+                                pl["hits_match_n1_reference"] = bool(pl["hits_all_ranks"] == 457_389_170)
+                    if name == "cubes12m":
+                        r2["note"] = ("NOT a BASELINE config: the scene where SURVEY §8d's HBM roofline applies — 12 M triangles (node + shape arrays ≈ 1.9 GB, far "
+                                      "beyond L2 + MALL), 10 M create_ray rays; roofline.hbm_frac is this walk's own PMC pass when profiles/ holds one; parity on "
+                                      f"the first {e['parity_rays']} rays of the batch (the oracle's 12 M-triangle tree is built once for it)")
+                    if dt == "f64":
+                        r2["note"] = ("tree, rays, builder and every test that decides a hit in f64; the walk's inner-node tests run on f32 boxes that contain "
+                                      "the f64 ones (BVHGPU_TUNE_WIDE_F64_GUIDE, DESIGN.md §4 \"f64 guide walk\"): same lists, checked against the f64 oracle below")
+                    if rank == 0 and not args.no_parity:
+                        from oracle import orc
+                        n_par = min(w2.R, args.parity_max_rays, e.get("parity_rays") or w2.R)
+                        if w2.harness:
+                            r2["parity"], r2["cpu_harness"] = check_parity_harness(w2, env, orc, n_par)
+                            if r2["cpu_harness"]:
+                                r2["speedup_vs_cpu_harness"] = round(r2["value"] / r2["cpu_harness"]["value"], 2)
+                        else:
+                            r2["parity"] = check_parity(w2, env, orc, n_par)
+                    if dt == "f64":
+                        # the same step with EVERY slab test of the walk in double precision (BASELINE configs[4] names "double-precision slab
+                        # test"): k_traverse_wide<double, …>, its own timing, roofline (its own counter passes when profiles/ holds them) and parity
+                        from bvh_amd._lib import TUNE_WIDE_F64_GUIDE
+                        ctx.set_tuning(TUNE_WIDE_F64_GUIDE, 0)
+                        try:
+                            r3 = run_workload(w2, args, env, args.extra_steps, 3, detailed=False)
+                            if rank == 0 and not args.no_parity:
+                                r3["parity"] = check_parity(w2, env, orc, min(w2.R, args.parity_max_rays))
+                            r2["pure_f64_walk"] = {k: r3[k] for k in ("value", "unit", "ms_per_step", "steps", "phases_ms", "hits_all_ranks", "roofline", "parity") if k in r3}
+                        finally:
+                            ctx.set_tuning(TUNE_WIDE_F64_GUIDE, 1)
+                    extras.append(r2)
+                    del w2
+                    env["last"] = {}
+                    torch.cuda.empty_cache()
+                except Exception as ex:   # an extra config must never take the headline line down
+                    import traceback
+                    extras.append({"workload": name, "dtype": dt, "harness": e["harness"], "error": repr(ex), "where": traceback.format_exc(limit=3)[-400:]})
         out["extra_configs"] = extras
 
     # ---- CPU baseline: the oracle (C port of the reference algorithm) on this box's host cores ----
@@ -831,7 +1070,7 @@ def main():
         ns = min(args.cpu_sample_rays, wl.R)
         rr = wl.oracle_rays(orc, wl.first, ns)
         n1 = max(ns // 16, 1000)
-        tb_par, par_threads, tb_ser, tf, tt_all, trav_threads, tt_1, tt_csr = 1e9, 0, 1e9, 1e9, 1e9, cores, 1e9, 1e9
+        tb_par, par_threads, tb_task, task_threads, tb_ser, tf, tt_all, trav_threads, tt_1, tt_csr = 1e9, 0, 1e9, 0, 1e9, 1e9, 1e9, cores, 1e9, 1e9
         builds_timed = []
         # the portable -O2 build that travelled with the repository, then the -O3 -march=native build made on THIS box
         # (SURVEY §8d); every phase keeps its best time over the two (neither flag set wins everywhere)
@@ -840,10 +1079,19 @@ def main():
                 break
             builds_timed.append(which)
             orc.build(a)                                    # warm the allocator and the page cache
-            for th in sorted({4, 8, 16, 32, 64, cores} & set(range(1, cores + 1))):   # libgomp's task queue stops scaling early
-                t0 = time.perf_counter(); ot = orc.build(a, threads=th); dt = time.perf_counter() - t0
-                if dt < tb_par:
-                    tb_par, par_threads = dt, th
+            # Bvh::build_par on the host cores.  "fast": the schedule that scales like rayon's work stealing (big nodes split by the whole
+            # team, then one parallel for over the subtrees; byte-equal arrays) — the figure the baseline uses.  "tasks": the literal
+            # restatement of rayon_executor's join recursion as OpenMP tasks, which libgomp's single task queue caps at ~4 threads — kept
+            # beside it so that nobody has to guess what round 4's 20 ms were.
+            for th in sorted({8, 16, 32, 64, 96, 128, cores} & set(range(1, cores + 1))):
+                for _ in range(3):
+                    t0 = time.perf_counter(); ot = orc.build(a, threads=th, schedule="fast"); dt = time.perf_counter() - t0
+                    if dt < tb_par:
+                        tb_par, par_threads = dt, th
+            for th in sorted({4, 8, 16} & set(range(1, cores + 1))):
+                t0 = time.perf_counter(); orc.build(a, threads=th); dt = time.perf_counter() - t0
+                if dt < tb_task:
+                    tb_task, task_threads = dt, th
             for _ in range(2):
                 t0 = time.perf_counter(); ot = orc.build(a, parallel=False); tb_ser = min(tb_ser, time.perf_counter() - t0)
             t0 = time.perf_counter(); of = orc.flatten(ot.nodes); tf = min(tf, time.perf_counter() - t0)
@@ -868,12 +1116,15 @@ def main():
             "kind": "port",
             "sample": f"oracle = C restatement of the reference, NOT the Rust crate (no cargo here); gcc -ffp-contract=off + OpenMP, best per phase of "
                       f"{' and '.join(builds_timed)}{'' if native else ' (the native rebuild failed)'}; full {wl.n_tri}-triangle build "
-                      f"(best of task-parallel {tb_par * 1e3:.1f} ms on {par_threads} threads with rayon_executor's cut-off bvh_impl.rs:534 / serial "
-                      f"{tb_ser * 1e3:.1f} ms) + serial flatten {tf * 1e3:.1f} ms + traversal of {ns} of the {wl.R} rays as the reference's harness does it "
+                      f"{tb_par * 1e3:.1f} ms on {par_threads} threads (scalable schedule: big nodes split by the whole team, then a parallel for over the subtrees — "
+                      f"byte-equal to the serial build; the literal OpenMP-task restatement of rayon_executor, bvh_impl.rs:527-543, takes {tb_task * 1e3:.1f} ms on its best "
+                      f"{task_threads} threads, the serial build {tb_ser * 1e3:.1f} ms; README.md:155 quotes 8.9 ms for the crate's rayon build on a 12-core 3900X) "
+                      f"+ serial flatten {tf * 1e3:.1f} ms + traversal of {ns} of the {wl.R} rays as the reference's harness does it "
                       f"(testbase.rs:826-836: one walk per ray, hits pushed into a per-ray growable list), rays-parallel on {trav_threads} threads (best team size: "
                       f"{tt_all * 1e3:.1f} ms; the two-walk CSR form of the parity leg: {tt_csr * 1e3:.1f} ms), scaled to {wl.R} rays; single-thread "
                       f"traversal {tt_1 / n1 * 1e9:.0f} ns/ray (README.md:175 quotes 866 ns/ray for the Rust crate on a Ryzen 9 3900X)",
-            "build_ms": round(tbuild * 1e3, 2), "flatten_ms": round(tf * 1e3, 2),
+            "build_ms": round(tbuild * 1e3, 2), "build_threads": par_threads if tb_par <= tb_ser else 1, "build_schedule": "team-split top + parallel for over subtrees",
+            "build_ms_task_recursion": round(tb_task * 1e3, 2), "build_ms_serial": round(tb_ser * 1e3, 2), "flatten_ms": round(tf * 1e3, 2),
             "traverse_ms_all_cores": round(tt_all * (wl.R / ns) * 1e3, 2), "traverse_csr_two_pass_ms": round(tt_csr * (wl.R / ns) * 1e3, 2),
             "traverse_ns_per_ray_1thread": round(tt_1 / n1 * 1e9, 1), "native_build": bool(native),
         }

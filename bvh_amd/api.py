@@ -441,7 +441,8 @@ class _TreeBase:
         wk = C.c_uint()
         check(lib.bvhgpu_hits_walk_info(self._hits.h, C.byref(wk)), self.ctx._h)
         sd = dict(hits=int(st.hits), visited=int(st.visited), leaf_visits=int(st.leaf_visits),
-                  device_steps=int(st.device_steps), wave_steps=int(st.wave_steps), walk=int(wk.value))   # walk: _lib.WALK_* bits (diagnostic)
+                  device_steps=int(st.device_steps), wave_steps=int(st.wave_steps), walk=int(wk.value),   # walk: _lib.WALK_* bits (diagnostic)
+                  kernel=self._hits.walk_kernel())                                                          # ... and the kernel's name
         if not fetch:
             return None, None, None, sd
         ft = np.float32 if self.sfx == "f32" else np.float64

@@ -1540,7 +1540,8 @@ __global__ __launch_bounds__(256) void k_hits_scatter_pair(const uint4* __restri
 
 // Staged hits (WalkOut::raybuf) → CSR: one thread per ray copies the ray's first min(count, 2^shift) shapes from its own 2^shift-word
 // slot to indices[offsets[ray] ..]: reads of whole 16-byte quads of the slot, writes that neighbouring threads make contiguous.  The later
-// hits of a ray (k >= 2^shift) are pool records and go through k_hits_scatter_wide as before.  Together they replace the
+// hits of a ray (k >= 2^shift) are pool records — pair records through k_hits_scatter_pair / k_hits_scatter8 (BVHGPU_TUNE_WIDE_REC8, the
+// default), else 12-byte records through k_hits_scatter_wide.  Together they replace the
 // 12-byte-record round trip (write, read, scatter) that cost configs[2] 0.42 ms for 58.8 M hits.  (Fusing this copy into
 // k_scan_final — the thread that computes a ray's offset copies its shapes — was measured and dropped: four rays per thread
 // break the contiguity of the writes, 0.31 ms against 0.13 + 0.03.)
@@ -1797,7 +1798,9 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     // then the guide is tried again; a batch that stays in range resets the back-off (the fall-back used to be for ever).
     const bool guide_ok = sizeof(T) == 8 && use_wide && mode == MODE_INDICES && t->has_guide && !early_items && ctx->tune[BVHGPU_TUNE_WIDE_F64_GUIDE] != 0;
     const bool replaying_out_of_range = h->no_guide;      // traverse_check sent this very batch back
-    if (guide_ok && !replaying_out_of_range && h->guide_skip > 0) h->guide_skip--;
+    // (one back-off slot per BATCH: a replay of the same batch — pool / index growth, a stack overflow's switch to the binary walk — takes none)
+    const bool first_enqueue = h->pend_attempts == 0 && !h->force_binary && !replaying_out_of_range;
+    if (guide_ok && first_enqueue && h->guide_skip > 0) h->guide_skip--;
     const bool use_guide = guide_ok && !replaying_out_of_range && h->guide_skip == 0;
     if (replaying_out_of_range) {
         h->no_guide = false;
@@ -1914,7 +1917,12 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     h->offsets.reserve((n_rays + 1) * 4);
     const uint32_t nb = (uint32_t)((n_rays + SCAN_BLOCK - 1) / SCAN_BLOCK);
     if (h->blocksums.reserve((nb + 1) * sizeof(unsigned long long))) h->bs_clean = false;
-    if (h->pool_cap == 0) h->pool_cap = std::max<size_t>(n_rays, (size_t)1 << 16);
+    if (h->pool_cap == 0) {
+        h->pool_cap = std::max<size_t>(n_rays, (size_t)1 << 16);
+        // pair records take 16 bytes whether they hold one hit or two: a first pool sized in 12-byte slots would hold 0.75 records per ray and
+        // a batch of single-hit rays would overflow it where the 12-byte records fitted — size it so that every ray has a record
+        if (use_wide && items_log4 == 0 && mode == MODE_INDICES && ctx->tune[BVHGPU_TUNE_WIDE_REC8] != 0) h->pool_cap = (h->pool_cap * 16 + sizeof(HitRec) - 1) / sizeof(HitRec);
+    }
     if (n_rays == 0) {
         BVH_HIP(hipMemsetAsync(h->offsets.p, 0, 4, st));
         h->pend_tree = nullptr;

@@ -373,10 +373,10 @@ typedef enum {
     BVHGPU_TUNE_WIDE_REC8 = 13,            /* variant 3, whole rays, indices only: pool records of 8 bytes per hit (16-byte records {ray, k, shape, shape} for two
                                               consecutive hits of a ray) instead of 12; 1 (default) on, 0 off */
     BVHGPU_TUNE_WIDE_F64_GUIDE = 14,       /* variant 3, f64 trees, indices only: 1 (default) = walk the tree's f32 guide boxes (the f64 boxes grown by 2^-18 of the
-                                              scene's largest |coordinate| and rounded outward) with f32 copies of the rays and test only the leaf
+                                              scene's largest |coordinate| and rounded outward) with the rays converted to f32 where the walk loads them, and test only the leaf
                                               candidates in f64 — the hit lists are the same, the walk runs at the f32 rate; a batch with a ray outside
                                               the range the argument covers (|origin| > 3 x scene, |1/d| x scene outside 2^+-100, non-finite) is replayed
-                                              with the f64 walk and the result object stays with it; 0 = always the f64 walk */
+                                              with the f64 walk and the result object skips the guide for 1, 2, 4 … 64 batches on consecutive failures before it tries again; 0 = always the f64 walk */
     BVHGPU_TUNE_FLATTEN_LAZY = 15,         /* bvhgpu_rebuild_flat_async / bvhgpu_build_flat_*: 1 (default) = the flatten behind a build writes what the wide walk
                                               reads (wide nodes, their LDS slot table, an f64 tree's guide nodes); the reference-layout FlatNode array and the
                                               folded binary array are written by a second pass the first time something asks for them (bvhgpu_flat_nodes,

@@ -199,6 +199,54 @@ void orc_primary_rays_f64(const float cam[14], uint32_t width, uint32_t height, 
     }
 }
 
+/* intersect_bh — testbase.rs:819-837, the loop every "intersect" bench of the reference times, WHOLE:
+ *     let ray = create_ray(&mut seed, bounds);          (:825; with `cam`: the engine's primary-ray definition above instead)
+ *     let hits = bh.traverse(&ray, triangles);          (:828; FlatBvh::traverse, one walk into a growable Vec)
+ *     for triangle in &hits { ray.intersects_triangle(&triangle.a, &triangle.b, &triangle.c); }     (:831-833)
+ * for rays [first, first + n) of the stream, rays-parallel (splitmix64's state after k draws is k*GAMMA: every ray starts in O(1)).
+ * bench.py's cpu_baseline of the harness entries times this.  Returns the number of candidates; *checksum (nullable) = sum of the
+ * candidates' shape indices + the number of finite distances, so that nothing can be optimised away. */
+uint64_t orc_harness_loop_f32(const orc_flat_f32 *flat, size_t n_flat, const float *shape_aabbs, const float *tris, uint64_t first,
+                              size_t n_rays, const float bounds[6], const float *cam, uint32_t width, uint32_t height, int threads,
+                              uint64_t *checksum) {
+    uint64_t total = 0, sum = 0;
+    if (threads < 1) threads = 1;
+    (void)threads;
+    const long long nr = (long long)n_rays;
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(threads) reduction(+ : total, sum)
+    for (long long i = 0; i < nr; i++) {
+        orc_ray_f32 ray;
+        if (cam) orc_primary_rays(cam, width, height, first + (uint64_t)i, 1, &ray);
+        else orc_create_rays(first + (uint64_t)i, 1, bounds, &ray);
+        uint32_t *vec = NULL;      /* Vec::new() */
+        size_t len = 0, cap = 0;
+        size_t index = 0;
+        while (index < n_flat) {   /* flat_bvh.rs:408-428 */
+            const orc_flat_f32 *nd = &flat[index];
+            if (nd->entry == ORC_NONE) {
+                if (ray_hit_f32(&ray, shape_aabbs + 6 * (size_t)nd->shape)) {
+                    if (len == cap) { cap = cap ? 2 * cap : 4; vec = (uint32_t *)realloc(vec, cap * sizeof *vec); }
+                    vec[len++] = nd->shape;
+                }
+                index = nd->exit;
+            } else {
+                float box[6] = { nd->min[0], nd->min[1], nd->min[2], nd->max[0], nd->max[1], nd->max[2] };
+                index = ray_hit_f32(&ray, box) ? nd->entry : nd->exit;
+            }
+        }
+        for (size_t k = 0; k < len; k++) {
+            const float *t = tris + 9 * (size_t)vec[k];
+            float uv[2];
+            const float d = orc_ray_triangle_f32(&ray, t, t + 3, t + 6, uv);
+            sum += vec[k] + (d < INFINITY ? 1u : 0u);
+        }
+        total += len;
+        free(vec);
+    }
+    if (checksum) *checksum = sum;
+    return total;
+}
+
 /* generate_aligned_boxes + UnitBox::aabb — testbase.rs:109-116, 84-89 */
 void orc_aligned_boxes(float *aabbs) {
     int i = 0;

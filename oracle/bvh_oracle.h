@@ -104,6 +104,11 @@ void orc_primary_rays(const float cam[14], uint32_t width, uint32_t height, uint
 void orc_create_rays_f64(uint64_t first, size_t n, const float bounds[6], orc_ray_f64 *rays);
 void orc_primary_rays_f64(const float cam[14], uint32_t width, uint32_t height, uint64_t first, size_t n, orc_ray_f64 *rays);
 /* generate_aligned_boxes (testbase.rs:109-116) → 21 AABBs (UnitBox::aabb :84-89). */
+/* intersect_bh (testbase.rs:819-837) whole: create_ray → FlatBvh::traverse → intersects_triangle on every candidate; cam == NULL: the
+ * create_ray stream, else primary rays of that camera.  Returns the candidate count. */
+uint64_t orc_harness_loop_f32(const orc_flat_f32 *flat, size_t n_flat, const float *shape_aabbs, const float *tris, uint64_t first,
+                              size_t n_rays, const float bounds[6], const float *cam, uint32_t width, uint32_t height, int threads,
+                              uint64_t *checksum);
 void orc_aligned_boxes(float *aabbs /* 21*6 */);
 
 /* ---------- per-type API ---------- */

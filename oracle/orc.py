@@ -282,6 +282,22 @@ def traverse_flat_once(flat, shape_aabbs, rays, threads: int = 1):
     return int(total), int(ck.value)
 
 
+def harness_loop(flat, shape_aabbs, tris, first: int, n_rays: int, bounds=DEFAULT_BOUNDS, cam=None, width: int = 0, height: int = 0,
+                 threads: int = 1):
+    """intersect_bh (testbase.rs:819-837) whole, f32: create_ray (or a primary ray of `cam`) → FlatBvh::traverse into a growable list →
+    Ray::intersects_triangle on every candidate; rays [first, first + n) of the stream, rays-parallel.  returns (candidates, checksum)"""
+    sa = np.ascontiguousarray(shape_aabbs, dtype=np.float32).reshape(-1, 6)
+    t = np.ascontiguousarray(tris, dtype=np.float32).reshape(-1, 9)
+    b = np.ascontiguousarray(bounds, dtype=np.float32).reshape(6)
+    c = None if cam is None else np.ascontiguousarray(cam, dtype=np.float32).reshape(14)
+    ck = C.c_uint64(0)
+    fn = lib().orc_harness_loop_f32
+    fn.restype = C.c_uint64
+    total = fn(_p(np.ascontiguousarray(flat)), C.c_size_t(len(flat)), _p(sa), _p(t), C.c_uint64(first), C.c_size_t(n_rays), _p(b), _p(c),
+               C.c_uint32(width), C.c_uint32(height), C.c_int(threads), C.byref(ck))
+    return int(total), int(ck.value)
+
+
 def traverse_tree(nodes, shape_aabbs, rays):
     s = "f32" if nodes.dtype == NODE_F32 else "f64"
     ft = _types(s)[0]

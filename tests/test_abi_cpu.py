@@ -439,3 +439,37 @@ def test_bench_watchdog_prints_what_was_measured():
     lines = p.stdout.strip().splitlines()
     assert len(lines) == 1 and "NOT REACHED" not in p.stdout
     assert json.loads(lines[0]) == {"value": 123.0, "scene_dist": "replicate", "collective_watchdog": "timed out"}
+
+
+def test_bench_timed_out_exchange_plan_is_named_on_the_line():
+    """when the watchdog abandons the exchange plan (the RCCL broadcast nobody has run on more than one GPU), the line it
+    prints must say so where a reader looks for the plans — scene_dist_plans carries the plan that did not come back with
+    "timed_out": true, the stage it was in and the workload, beside the replicate result; `rccl` says how far the communicator got.  The same
+    for an exchange that hangs inside the extra_configs section (configs[3] strong): the entry's own scene_dist_plans names it."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod_wd", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    # headline: replicate measured and published, the exchange plan pending in the communicator
+    res = {"value": 20000.0, "ms_per_step": 0.4, "scene_dist_plans": {"replicate": {"value": 20000.0, "ms_per_step": 0.4, "hits_all_ranks": 80000}}}
+    line = {"value": res["value"], "n_gpus": 8, "workload_name": "cubes120k", "scene_dist_plans": res["scene_dist_plans"], "rccl": None}
+    pending = {"res": res, "plan": "bcast", "stage": "forming the RCCL communicator", "workload": "cubes120k"}
+    text = b.timed_out_line(line, pending, "the exchange plan of cubes120k", 60.0, {"nranks": None, "formed": False, "error": None})
+    out = json.loads(text)
+    assert out["scene_dist_plans"]["bcast"] == {"timed_out": True, "after_s": 60.0, "stage": "forming the RCCL communicator", "workload": "cubes120k"}
+    assert out["scene_dist_plans"]["replicate"]["value"] == 20000.0 and out["value"] == 20000.0
+    assert out["rccl"] == {"nranks": None, "formed": False, "error": None} and "did not finish within 60 s" in out["collective_watchdog"]
+    # extras: the headline finished with both plans; configs[3] strong hangs in its exchange steps after its replicate result was published
+    res3 = {"workload": "standin-incoherent", "value": 30000.0, "scene_dist_plans": {"replicate": {"value": 30000.0, "hits_all_ranks": 457389170}}}
+    line = {"value": 21000.0, "n_gpus": 8, "workload_name": "cubes120k",
+            "scene_dist_plans": {"replicate": {"value": 20000.0}, "bcast": {"value": 21000.0}}, "extra_configs": [res3]}
+    pending = {"res": res3, "plan": "bcast", "stage": "the exchange plan's steps (communicator formed)", "workload": "standin-incoherent"}
+    out = json.loads(b.timed_out_line(line, pending, "the exchange plan of standin-incoherent", 60.0, {"nranks": 8, "version": "2.26.6"}))
+    e = out["extra_configs"][0]
+    assert e["scene_dist_plans"]["bcast"]["timed_out"] is True and e["scene_dist_plans"]["replicate"]["hits_all_ranks"] == 457389170
+    assert set(out["scene_dist_plans"]) == {"replicate", "bcast"} and "timed_out" not in out["scene_dist_plans"]["bcast"]
+    assert out["rccl"]["nranks"] == 8
+    # a hang outside any exchange plan (pending None): the note and rccl only
+    out = json.loads(b.timed_out_line({"value": 1.0}, None, "the extra_configs section", 300.0, None))
+    assert "did not finish within 300 s" in out["collective_watchdog"] and "scene_dist_plans" not in out

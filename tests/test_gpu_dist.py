@@ -133,6 +133,10 @@ def test_bench_exchange_plan_cannot_take_the_line_down():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["scene_dist"] == "replicate" and out["value"] > 0
     assert "did not finish within 8 s" in out["collective_watchdog"]
+    # the plan that did not come back is NAMED where a reader looks for the plans, beside the replicate result
+    plans = out["scene_dist_plans"]
+    assert plans["replicate"]["value"] == out["value"] and plans["bcast-torch"]["timed_out"] is True and plans["bcast-torch"]["after_s"] == 8
+    assert out["rccl"]["formed"] is False
     assert out["roofline"]["kernel"] and out["launch"]["ranks_seen"] == 2
     # without the simulated hang both plans are on the line, the faster one is the headline
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)

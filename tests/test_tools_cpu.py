@@ -4,6 +4,7 @@ import glob
 import json
 import os
 import py_compile
+import re
 import subprocess
 import sys
 
@@ -77,3 +78,50 @@ def test_design_numbers_reads_the_committed_bench_line():
     j = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
     assert f"{j['value']:.0f} Mrays/s" in p.stdout and "CSR assembly" in p.stdout and "Pure f64 walk" in p.stdout and "CPU baseline" in p.stdout
     assert p.stdout.count("parity equal: true") + p.stdout.count("`equal: true`") >= 1 + len(j.get("extra_configs", []))
+
+
+def _newest_default_line():
+    def key(f):
+        m = re.match(r"r(\d+)_v(\d+)_bench_default\.json", os.path.basename(f))
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_v*_bench_default.json")), key=key)
+    assert lines, "no committed default bench line under profiles/"
+    return lines[-1], json.loads(open(lines[-1]).read().strip().splitlines()[-1])
+
+
+def test_committed_bench_line_follows_from_the_committed_profiles():
+    """VERDICT r4 #8 — the evidence chain, checked on every CPU run.  The newest committed line of a default bench run
+    (profiles/r<N>_v<M>_bench_default.json) must be reproducible from the profile files it cites:
+      (a) roofline.kernel names a kernel that is a row of the cited round's kernel_stats.md (a template-argument change in traverse.hip
+          can no longer silently drop the roofline),
+      (b) roofline.frac recomputes from the cited bound.json's counters and the line's own kernel time, within 3 %,
+      (c) the kernels of one step, at their profiled average durations, fit into the line's ms_per_step."""
+    path, j = _newest_default_line()
+    roof = j["roofline"]
+    assert roof.get("frac") is not None and roof.get("source"), f"{path}: the headline carries no PMC-derived roofline"
+    bound_file = roof["source"].split(":")[0]
+    assert os.path.exists(os.path.join(ROOT, bound_file)), bound_file
+    stats_file = bound_file.replace("_bound.json", "_kernel_stats.md")
+    rows = {}
+    for ln in open(os.path.join(ROOT, stats_file)):
+        m = re.match(r"\| `([^`]+)` \| (\d+) \| [\d.]+ \| ([\d.]+) \|", ln)
+        if m:
+            rows[m.group(1)] = (int(m.group(2)), float(m.group(3)))
+    # (a)
+    hit = [k for k in rows if k.startswith(roof["kernel"])]
+    assert len(hit) == 1, (roof["kernel"], sorted(rows)[:5])
+    # (b)
+    bj = json.load(open(os.path.join(ROOT, bound_file)))
+    c = next(k for k in bj["kernels"] if k["kernel"] == hit[0])
+    secs = roof["kernel_ms"] * 1e-3
+    scale = j["config"]["rays_per_gpu"] / bj["rays_per_launch"]      # (per-launch counters are per ray to first order: bench.py newest_bound)
+    peaks = {"hbm": (c.get("hbm_bytes"), 8e12), "valu": (c.get("SQ_INSTS_VALU"), 1024 * 2.4e9 / 2),
+             "lds": ((c.get("SQ_INSTS_LDS") or 0) * 4 + (c.get("SQ_LDS_BANK_CONFLICT") or 0), 256 * 2.4e9)}
+    count, peak = peaks[roof["bound"]]
+    frac = count * scale / secs / peak
+    assert abs(frac - roof["frac"]) <= 0.03 * roof["frac"], (frac, roof["frac"])
+    # (c): the walk runs once per step; every kernel that ran at least once per step is priced at calls-per-step x its average
+    steps = rows[hit[0]][0]
+    per_step_us = sum(avg * round(calls / steps) for calls, avg in rows.values() if calls >= 0.9 * steps)
+    assert per_step_us <= j["ms_per_step"] * 1e3 * 1.03, (per_step_us, j["ms_per_step"])
+    assert per_step_us >= 0.7 * j["ms_per_step"] * 1e3, "the profile and the line do not describe the same step"
