@@ -37,6 +37,8 @@ constexpr int CTR_TOPMASK = BUILD_CTR_TOPMASK;   // u32: bit h set when the leve
                                  // once bits 1..15 are there, the walk's item filter can run beside the rest of the build (traverse.hip k_wide_items)
 constexpr uint32_t BUILD_FLAG_NONFINITE = 1u;    // a shape AABB holds NaN / ±inf, or the root centroid extent overflows: the
                                                  // reference panics there (bvh_node.rs:214-217, `to_usize().unwrap()`); nothing is built
+constexpr uint32_t BUILD_FLAG_PERSIST_GAVE_UP = BSTAT_UNFINISHED;   // k_level_xcd: a group barrier timed out (its workgroups were not all resident in time) or the
+                                                 // subtree is deeper than the counter slots: the tree is unfinished, the host builds it again level by level
 constexpr uint32_t BUILD_FLAG_EMPTY_SPLIT = 2u;  // some node had no winning SAH candidate (NaN / inf costs): its children carry
                                                  // Aabb::empty() bounds (bvh_node.rs:225-230), so a child box is NOT the join of its
                                                  // grandchildren and traversal must test every ancestor (no wide walk)
@@ -74,6 +76,9 @@ constexpr int STAT_REP = BVH_STAT_REP;   // global replicas of an item's statist
                               // the root do not serialise on 78 addresses (k_bin of level 0: 13.4 -> see profiles); the
                               // selection merges the replicas
 constexpr int CTR_LEVEL0 = 16;   // u32 pairs (n_items, n_tiles) per level slot
+constexpr int CTR_XDIR = CTR_LEVEL0 + 2 * MAXLV;   // 8 x {kind, slot, start, count}: the tree's level-3 nodes (heap numbers 8 .. 15) as the level pass that
+                                                   // created them left them: the subtree every workgroup group of k_level_xcd owns
+static_assert((CTR_XDIR + 8 * 4) * 4 <= 1024, "the directory lives inside the counter page");
 constexpr size_t ROOTKEY_OFF = 1024;  // byte offset of k_prep's per-workgroup partial bounds (12 keys each) inside the ctr buffer
 constexpr int PREP_MAX_WG = 1024;     // k_prep's grid never exceeds this
 
@@ -127,7 +132,9 @@ template <typename T> struct BuildArgs {
     typename Traits<T>::Key* rootkeys;   // [gridDim of k_prep][12]: every workgroup's bounds (joined by k_root / k_level<ROOT>)
     uint32_t prep_wgs;                   // gridDim of k_prep
     uint32_t n;
+    unsigned long long* xbar;            // k_level_xcd: per workgroup group two 128-byte lines {arrivals | live << 32} and {round | live << 32}; zeroed by k_prep
 };
+constexpr int XBAR_WORDS = 8 * 32;       // unsigned long long words: 8 groups x 2 lines of 16
 
 // is key slot j of a bucket a "min" slot?  layout: aabb.min[3] aabb.max[3] cen.min[3] cen.max[3]
 __device__ __forceinline__ bool key_is_min(int j) { return j < 3 || (j >= 6 && j < 9); }
@@ -157,6 +164,8 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T>
     }
     if (a.lv.tile_map[0] && blockIdx.x == 0 && threadIdx.x < WAVE)   // ... and the root's statistic replicas (k_level<ROOT> adds to them)
         for (int r = 0; r < STAT_REP; r++) init_stats<T>(&a.lv.stats[0][r], (int)threadIdx.x);
+    if (a.xbar && blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < (uint32_t)XBAR_WORDS; i += blockDim.x) a.xbar[i] = 0ull;
     if (blockIdx.x == 0) {   // the LDS slot tables of the previous tree (filled again by flatten)
         for (uint32_t i = threadIdx.x; i < a.n_slots; i += blockDim.x) a.slot_entry[i] = NONE;
         for (uint32_t i = threadIdx.x; i < WIDE_SLOTS; i += blockDim.x) a.wslot_node[i] = NONE;
@@ -703,6 +712,24 @@ template <typename T> __global__ __launch_bounds__(256) void k_split(BuildArgs<T
 //   the children's work items (level tier: LevelArgs arrays; workgroup / wave tier: their queues, as before).
 // ROOT: level 0 has no parent — the root item (k_root) is binned in place.
 // ------------------------------------------------------------------------------------------------
+// Accesses to data another workgroup of the SAME launch wrote (k_level_xcd: one level's result is the next level's input without a
+// kernel boundary between them).  DEV: device-scope relaxed atomics = loads / stores with sc1 — a store is written through, a load does not
+// hit a line the L1 or a foreign XCD's L2 kept (tools/ubench/twostage.hip: no stale read in 19 M across the chip) — so the result does not
+// depend on where the dispatcher put a workgroup.  !DEV: the plain access of the launch-per-level schedule.
+template <bool DEV, typename U> __device__ __forceinline__ U ldx(const U* p) {
+    if constexpr (DEV) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
+}
+template <bool DEV, typename U, typename V> __device__ __forceinline__ void stx(U* p, V v) {
+    if constexpr (DEV) __hip_atomic_store(p, (U)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = (U)v;
+}
+template <bool DEV> __device__ __forceinline__ uint4 ldx4(const uint4* p) {
+    if constexpr (DEV) { const uint32_t* q = reinterpret_cast<const uint32_t*>(p); return make_uint4(ldx<true>(q), ldx<true>(q + 1), ldx<true>(q + 2), ldx<true>(q + 3)); }
+    else return *p;
+}
+template <bool DEV> __device__ __forceinline__ void stx4(uint4* p, uint4 v) {
+    if constexpr (DEV) { uint32_t* q = reinterpret_cast<uint32_t*>(p); stx<true>(q, v.x); stx<true>(q + 1, v.y); stx<true>(q + 2, v.z); stx<true>(q + 3, v.w); }
+    else *p = v;
+}
 __device__ __forceinline__ float lane_bcast_rt(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ double lane_bcast_rt(double v, int l) {
     const long long b = __double_as_longlong(v);
@@ -852,10 +879,16 @@ constexpr int LEVEL_PT = TILE / 256;   // shapes per thread
 // workgroups start up to 4 µs apart.
 constexpr int LEVEL_THREADS = BVH_LEVEL_THREADS;
 constexpr bool LEVEL_DEDICATED = LEVEL_THREADS > 256;
-template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) void k_level(BuildArgs<T> a, int L) {
+// One pass of the tier over tile ids [g0, g1) by workgroups wg_rank, wg_rank + wg_count, … — the whole grid over all tiles for k_level, one
+// workgroup group over its subtree's tiles for k_level_xcd (DEV: see ldx / stx; the arrays the NEXT pass accumulates into are then reset
+// over that range and the statistics slots [s0, s1) only).  live (DEV, LDS): += children this workgroup sent on to the next pass.
+template <typename T, bool ROOT, bool DEV>
+__device__ __forceinline__ void level_pass(const BuildArgs<T>& a, const int L, const uint32_t wg_rank, const uint32_t wg_count, const uint32_t g0,
+                                           const uint32_t g1, const uint32_t s0, const uint32_t s1, uint32_t* live) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
     static_assert(TILE % 256 == 0 && LEVEL_PT >= 1 && LEVEL_PT <= 4, "a tile is a whole number of 256-thread rounds");
+    static_assert(!(ROOT && DEV), "the root is binned by a launch of its own");
     const LevelArgs<T>& v = a.lv;
     const int bP = (L + 2) % 3, bC = L % 3, bN = (L + 1) % 3;
     const uint32_t* src = ROOT ? a.idx[0] : a.idx[(L + 1) & 1];   // the parents' order (level L-1; the root's slice is where k_prep wrote it)
@@ -870,7 +903,7 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
     LEVEL_STAMP(0);
     // (the first tile's record is requested before the housekeeping stores: its round trip hides behind them)
     uint4 tm_first = make_uint4(NONE, 0u, 0u, 0u);
-    if (!ROOT && blockIdx.x < v.n_tiles) tm_first = v.tile_map[bP][blockIdx.x];
+    if (!ROOT && g0 + wg_rank < g1) tm_first = ldx4<DEV>(&v.tile_map[bP][g0 + wg_rank]);
     // ROOT: the scene bounds (k_prep left one row of 12 keys per workgroup) → the root item, in every workgroup; tile g of
     // the root is simply positions [g TILE, (g+1) TILE)
     __shared__ Key s_rootk[STAT_KEYS];
@@ -907,16 +940,19 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
 
     // ---- reset what the NEXT level accumulates into
     {
-        const uint32_t gt = blockIdx.x * (uint32_t)LEVEL_THREADS + threadIdx.x, gs = gridDim.x * (uint32_t)LEVEL_THREADS;
-        for (uint32_t i = gt; i < v.n_tiles; i += gs) v.tile_map[bN][i] = make_uint4(NONE, 0u, 0u, 0u);
-        for (uint32_t i = gt; i < v.n_tiles * (uint32_t)NUM_BUCKETS; i += gs) v.tile_cnt[bN][i] = 0u;
-        constexpr uint32_t NK = NUM_BUCKETS * STAT_KEYS;
-        const uint32_t ns = v.n_slots * (uint32_t)STAT_REP;
-        for (uint32_t i = gt; i < ns * NK; i += gs) {
-            const uint32_t e = i / NK, j = i % NK;
-            v.stats[bN][e].k[j] = key_is_min((int)(j % STAT_KEYS)) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF;
+        const uint32_t gt = wg_rank * (uint32_t)LEVEL_THREADS + threadIdx.x, gs = wg_count * (uint32_t)LEVEL_THREADS;
+        for (uint32_t i = g0 + gt; i < g1; i += gs) {
+            if constexpr (DEV) stx<true>(&v.tile_map[bN][i].x, NONE);   // (readers look at .x first)
+            else v.tile_map[bN][i] = make_uint4(NONE, 0u, 0u, 0u);
         }
-        for (uint32_t i = gt; i < ns * (uint32_t)NUM_BUCKETS; i += gs) v.stats[bN][i / NUM_BUCKETS].cnt[i % NUM_BUCKETS] = 0u;
+        for (uint32_t i = g0 * (uint32_t)NUM_BUCKETS + gt; i < g1 * (uint32_t)NUM_BUCKETS; i += gs) stx<DEV>(&v.tile_cnt[bN][i], 0u);
+        constexpr uint32_t NK = NUM_BUCKETS * STAT_KEYS;
+        const uint32_t e0 = s0 * (uint32_t)STAT_REP, e1 = s1 * (uint32_t)STAT_REP;
+        for (uint32_t i = e0 * NK + gt; i < e1 * NK; i += gs) {
+            const uint32_t e = i / NK, j = i % NK;
+            stx<DEV>(&v.stats[bN][e].k[j], key_is_min((int)(j % STAT_KEYS)) ? Tr::KEY_POS_INF : Tr::KEY_NEG_INF);
+        }
+        for (uint32_t i = e0 * (uint32_t)NUM_BUCKETS + gt; i < e1 * (uint32_t)NUM_BUCKETS; i += gs) stx<DEV>(&v.stats[bN][i / NUM_BUCKETS].cnt[i % NUM_BUCKETS], 0u);
     }
 
     __shared__ Key sk[2][BIN_REP][NUM_BUCKETS * STAT_KEYS];
@@ -929,9 +965,9 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
     __shared__ Key s_sah[72];
     const int rp = (int)(stid & (BIN_REP - 1)), rt = (int)(stid & (LEVEL_TC_REP - 1));
 
-    for (uint32_t g = blockIdx.x; g < v.n_tiles; g += gridDim.x) {
+    for (uint32_t g = g0 + wg_rank; g < g1; g += wg_count) {
         // one load tells the tile's workgroup all it needs to start: the item's slot (statistics, record), slice and size
-        const uint4 tm = g == blockIdx.x ? tm_first : (ROOT ? make_uint4(g < (a.n + TILE - 1) / TILE ? 0u : NONE, 0u, a.n, 0u) : v.tile_map[bP][g]);
+        const uint4 tm = g == g0 + wg_rank ? tm_first : (ROOT ? make_uint4(g < (a.n + TILE - 1) / TILE ? 0u : NONE, 0u, a.n, 0u) : ldx4<DEV>(&v.tile_map[bP][g]));
         const uint32_t slotP = tm.x;
         if (slotP == NONE) continue;   // workgroup-uniform
         LEVEL_STAMP(1);
@@ -953,12 +989,12 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
             for (int h = 0; h < 2; h++) {
                 const int j = lane + 64 * h;
 #pragma unroll
-                for (int r = 0; r < STAT_REP; r++) rk[h][r] = j < NUM_BUCKETS * STAT_KEYS ? rep[r].k[j] : (Key)0;
+                for (int r = 0; r < STAT_REP; r++) rk[h][r] = j < NUM_BUCKETS * STAT_KEYS ? ldx<DEV>(&rep[r].k[j]) : (Key)0;
             }
 #pragma unroll
-            for (int r = 0; r < STAT_REP; r++) rc[r] = lane < NUM_BUCKETS ? rep[r].cnt[lane] : 0u;
+            for (int r = 0; r < STAT_REP; r++) rc[r] = lane < NUM_BUCKETS ? ldx<DEV>(&rep[r].cnt[lane]) : 0u;
 #pragma unroll
-            for (int k = 0; k < 6; k++) { PA[k] = P->A[k]; PC[k] = P->C[k]; }
+            for (int k = 0; k < 6; k++) { PA[k] = ldx<DEV>(&P->A[k]); PC[k] = ldx<DEV>(&P->C[k]); }
         }
         // ---- loads that depend on the tile only: the shapes' indices and buckets at L-1 ...
         uint32_t sh[LEVEL_PT];
@@ -968,8 +1004,8 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
         for (int u = 0; u < LEVEL_PT; u++) {
             const uint32_t p = p0 + (uint32_t)u * 256u + stid;
             const bool valid = shaper && p < pend;
-            sh[u] = valid ? src[p] : NONE;
-            bo[u] = !valid ? 7 : (ROOT ? 0 : (int)bk_src[p]);
+            sh[u] = valid ? ldx<DEV>(&src[p]) : NONE;
+            bo[u] = !valid ? 7 : (ROOT ? 0 : (int)ldx<DEV>(&bk_src[p]));
         }
         // ... and the bucket counts of P's tiles (consumed further down) → offset of (this tile, bucket b) inside P's slice =
         // shapes of P in buckets < b + shapes of bucket b in P's earlier tiles
@@ -983,7 +1019,7 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
             for (int i = 0; i < TCV; i++) {
                 const uint32_t j = ctid + (uint32_t)NCT * (uint32_t)i;
 #pragma unroll
-                for (int b = 0; b < NUM_BUCKETS; b++) tcv[i][b] = (w > 0 && j < ntl) ? tc[(size_t)j * NUM_BUCKETS + b] : 0u;
+                for (int b = 0; b < NUM_BUCKETS; b++) tcv[i][b] = (w > 0 && j < ntl) ? ldx<DEV>(&tc[(size_t)j * NUM_BUCKETS + b]) : 0u;
             }
         }
         if (ROOT) {
@@ -1073,7 +1109,7 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
             for (uint32_t j = ctid + (uint32_t)NCT * TCV; j < ntl; j += NCT) {   // (items of more than 384 tiles: huge scenes' top levels)
 #pragma unroll
                 for (int b = 0; b < NUM_BUCKETS; b++) {
-                    const uint32_t x = tc[(size_t)j * NUM_BUCKETS + b];
+                    const uint32_t x = ldx<DEV>(&tc[(size_t)j * NUM_BUCKETS + b]);
                     all[b] += x;
                     before[b] += j < tl ? x : 0u;
                 }
@@ -1125,7 +1161,7 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
                 off = run0[b] + rank[u];
                 for (int uu = 0; uu < u; uu++) off += wcnt[0][uu][b] + wcnt[1][uu][b] + wcnt[2][uu][b] + wcnt[3][uu][b];   // earlier rounds
                 for (int ww = 0; ww < sw; ww++) off += wcnt[ww][u][b];                                                     // earlier waves of this round
-                dst[start + off] = sh[u];
+                stx<DEV>(&dst[start + off], sh[u]);
             }
             const int side = off >= nl ? 1 : 0;
             const LevelChild<T>& c = ch[side];
@@ -1137,7 +1173,7 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
                 int nb;
                 if (c.degen) nb = (q - c.start) < c.half ? 0 : 1;          // halves in the child's order (:117)
                 else nb = bucket_of(cen[c.ax], c.cmin, c.ext);             // :210-217
-                bk_dst[q] = (uint8_t)nb;
+                stx<DEV>(&bk_dst[q], (uint8_t)nb);
                 Key* kk = &sk[side][rp][nb * STAT_KEYS];                   // Bucket::add_aabb (utils.rs:81-85)
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
@@ -1192,7 +1228,7 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
         LEVEL_STAMP(5);
         // ---- tile 0 of P: P's BvhNode (bvh_node.rs:145-151) and the children's work items
         if (!ROOT && tl == 0 && w == 0) {
-            const uint32_t ni = P->ni, heap = P->heap;
+            const uint32_t ni = ldx<DEV>(&P->ni), heap = ldx<DEV>(&P->heap);
             const uint32_t li = ni + 1;                 // :140
             const uint32_t ri = li + (2 * nl - 1);      // :138,142
             if (sel.no_winner && lane == 0) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_EMPTY_SPLIT);
@@ -1203,7 +1239,7 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
                     nd->l_min[k] = sel.AL[k]; nd->l_max[k] = sel.AL[3 + k];
                     nd->r_min[k] = sel.AR[k]; nd->r_max[k] = sel.AR[3 + k];
                 }
-                nd->parent = P->parent; nd->l = li; nd->r = ri; nd->shape = NONE;
+                nd->parent = ldx<DEV>(&P->parent); nd->l = li; nd->r = ri; nd->shape = NONE;
                 a.node_start[ni] = start;
                 a.node_count[ni] = count;
                 a.node_slot[ni] = (uint16_t)heap;
@@ -1223,18 +1259,85 @@ template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) voi
                 const uint32_t cq = __shfl(qslot, side);
                 Item<T>* it = c.kind == 0u ? &a.small[cq] : (c.kind == 1u ? &a.mid2[cq] : &v.item[L & 1][c.slot]);
                 if (lane == 0) {
-                    it->ni = side ? ri : li; it->parent = ni; it->start = c.start; it->count = c.count;
-                    it->tile_base = c.tile0; it->parity = (uint32_t)(L & 1); it->heap = heap_child(heap, (uint32_t)side); it->_r1 = 0;
+                    stx<DEV>(&it->ni, side ? ri : li); stx<DEV>(&it->parent, ni); stx<DEV>(&it->start, c.start); stx<DEV>(&it->count, c.count);
+                    stx<DEV>(&it->tile_base, c.tile0); stx<DEV>(&it->parity, (uint32_t)(L & 1)); stx<DEV>(&it->heap, heap_child(heap, (uint32_t)side)); stx<DEV>(&it->_r1, 0u);
+                    // the tree's level-3 nodes (heap numbers 8 .. 15): the subtrees the groups of k_level_xcd own
+                    const uint32_t hc = heap_child(heap, (uint32_t)side);
+                    if (hc >= 8u && hc < 16u) {
+                        uint32_t* xd = &a.ctr[CTR_XDIR + 4 * (hc - 8u)];
+                        xd[0] = c.kind; xd[1] = c.slot; xd[2] = c.start; xd[3] = c.count;
+                    }
+                    if (DEV && c.kind == 3u) atomicAdd(live, 1u);   // (LDS)
                 }
-                if (lane < 6) { it->A[lane] = side ? sel.AR[lane] : sel.AL[lane]; it->C[lane] = side ? sel.CR[lane] : sel.CL[lane]; }
+                if (lane < 6) { stx<DEV>(&it->A[lane], side ? sel.AR[lane] : sel.AL[lane]); stx<DEV>(&it->C[lane], side ? sel.CR[lane] : sel.CL[lane]); }
                 if (c.kind == 3u) {
                     const uint32_t cnt_t = (c.count + TILE - 1) / TILE;
-                    for (uint32_t j = lane; j < cnt_t; j += WAVE) v.tile_map[bC][c.tile0 + j] = make_uint4(c.slot, c.start, c.count, 0u);
+                    for (uint32_t j = lane; j < cnt_t; j += WAVE) stx4<DEV>(&v.tile_map[bC][c.tile0 + j], make_uint4(c.slot, c.start, c.count, 0u));
                 }
             }
         }
         LEVEL_STAMP(6);
         __syncthreads();
+    }
+}
+
+template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) void k_level(BuildArgs<T> a, int L) {
+    level_pass<T, ROOT, false>(a, L, blockIdx.x, gridDim.x, 0u, a.lv.n_tiles, 0u, a.lv.n_slots, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The tier's passes from tree level 4 on as ONE persistent launch (BVHGPU_TUNE_BUILD_LEVEL_PERSIST).  The launch-per-level
+// schedule pays ≈ 2.5 µs of dispatch gap + ≈ 2 µs of cold misses per level; a barrier over ALL workgroups costs as much (2.3 – 2.5 µs in two
+// stages, tools/ubench/twostage.hip), but the eight subtrees below tree level 3 never exchange anything: workgroup group q = blockIdx.x % 8
+// (the dispatcher puts those on one XCD: 2 048 of 2 048 blocks — a matter of speed only, see ldx / stx) owns the subtree of heap number
+// 8 + q and synchronises with ITSELF after every pass (1.9 µs for 32 workgroups, eight groups side by side), running on until its subtree has
+// left the tier, however deep.  A pass is level_pass<DEV> over the subtree's tile ids [T(start), T(start + count)), T(p) = p / TILE + p /
+// slot_div (monotone in p: the ranges of the eight subtrees do not overlap, LevelArgs).  Barrier: one 64-bit word per group, {arrivals |
+// children sent on << 32}; the last arriver publishes {round | children << 32} on a line of its own, the others poll that with sc1 loads.
+// The release is s_waitcnt vmcnt(0) behind write-through stores: no fence (an agent-scope fence writes the whole L2 back: 6.5 µs).
+// A poll that does not come back (the group's workgroups are not all resident: another stream's walk holds the CUs) raises
+// BUILD_FLAG_PERSIST_GAVE_UP and the host builds the tree again with a launch per level (build_finalize).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t XCD_SPIN_MAX = 3000000u;
+template <typename T> __global__ __launch_bounds__(LEVEL_THREADS) void k_level_xcd(BuildArgs<T> a, int L0) {
+    __shared__ uint32_t s_live, s_go;
+    __shared__ unsigned long long s_word;
+    const uint32_t grp = blockIdx.x & 7u, rank = blockIdx.x >> 3, nx = gridDim.x >> 3;
+    const uint32_t* xd = &a.ctr[CTR_XDIR + 4 * grp];        // (written by the pass that split tree level 2: an earlier launch)
+    const uint32_t kind = xd[0], start = xd[2], count = xd[3];
+    if (kind != 3u || (a.ctr[CTR_FLAGS] & BUILD_FLAG_NONFINITE)) return;   // the whole group: its subtree never reached this tier (or there is no tree)
+    const uint32_t sd = a.lv.slot_div, end = start + count;
+    const uint32_t g0 = start / (uint32_t)TILE + start / sd, g1 = end / (uint32_t)TILE + end / sd;
+    const uint32_t s0 = start / sd, s1 = end / sd;
+    unsigned long long* arrive = a.xbar + (size_t)grp * 32, *go = arrive + 16;
+    uint32_t live_seen = 0;
+    for (int L = L0, round = 0; ; L++, round++) {
+        if (threadIdx.x == 0) s_live = 0u;
+        __syncthreads();
+        level_pass<T, false, true>(a, L, rank, nx, g0, g1, s0, s1, &s_live);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store and atomic of this pass has been performed
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long old = __hip_atomic_fetch_add(arrive, 1ull | ((unsigned long long)s_live << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long word;
+            uint32_t ok = 1u;
+            if ((uint32_t)old + 1u == (uint32_t)(round + 1) * nx) {      // the last one of the group
+                word = (unsigned long long)(uint32_t)(round + 1) | ((old >> 32) + (unsigned long long)s_live) << 32;
+                __hip_atomic_store(go, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                uint32_t spins = 0;
+                while ((uint32_t)(word = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (uint32_t)(round + 1) && ++spins < XCD_SPIN_MAX)
+                    __builtin_amdgcn_s_sleep(1);
+                if (spins >= XCD_SPIN_MAX) ok = 0u;
+            }
+            s_word = word; s_go = ok;
+        }
+        __syncthreads();
+        if (!s_go) { if (threadIdx.x == 0) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_PERSIST_GAVE_UP); return; }
+        const uint32_t live_total = (uint32_t)(s_word >> 32);
+        if (live_total == live_seen) return;                 // nothing of this subtree stays in the tier: done
+        live_seen = live_total;
+        if (L + 1 >= MAXLV - 4) { if (threadIdx.x == 0) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_PERSIST_GAVE_UP); return; }   // (deeper than the counter slots)
     }
 }
 #ifdef BVH_LEVEL_PROFILE
@@ -1966,6 +2069,7 @@ template <typename T> static BuildArgs<T> make_args(bvhgpu_tree* t, const T* src
     a.ctr = t->ctr.as<uint32_t>();
     a.rootkeys = reinterpret_cast<Key*>(reinterpret_cast<char*>(t->ctr.p) + ROOTKEY_OFF);
     a.n = (uint32_t)t->n;
+    a.xbar = t->xbar.as<unsigned long long>();   // (NULL unless the persistent level tier is in use)
     a.prep_wgs = 0;
     const bool small_scene = t->n <= MID_SCENE_SPLIT;
     a.mid_max = (uint32_t)(small_scene ? MidSmallScene<T>::MAXN : MidLargeScene<T>::MAXN);
@@ -2031,13 +2135,15 @@ template <typename T> static void run_lower_tiers(bvhgpu_tree* t, const BuildArg
     hipLaunchKernelGGL(k_small<T>, dim3(g.small_grid), dim3(256), 0, st, a, small_done);
 }
 
-template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after) {
+// redo: build_finalize builds the SAME generation again (the persistent level tier gave up): no new generation, the tree's own AABB copy
+template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after, bool redo) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
     t->built = false; t->flattened = false; t->lazy_flat = false; t->pending_build = false; t->exact_only = false; t->pending_recv = false;
-    t->gen++;   // results enqueued from here on belong to this build (bvhgpu_hits_wait compares generations)
+    t->pend_persist = false;
+    if (!redo) t->gen++;   // results enqueued from here on belong to this build (bvhgpu_hits_wait compares generations)
     if (n != t->n) t->has_tris = false;   // one triangle per shape: a different shape count invalidates the vertex array
     t->n = n; t->n_nodes = n ? 2 * n - 1 : 0;
     t->n_flat = n >= 2 ? 3 * n - 2 : n;
@@ -2061,6 +2167,11 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     t->idx[1].reserve(n * 4);
     t->bk.reserve(2 * n);   // (the one-launch-per-level tier keeps the buckets of two consecutive levels)
     if (level_fused<T>(t) && n > (size_t)MID_MAX) t->lvbuf.reserve(LevelLayout<T>(n, MID_MAX).bytes);
+    // Persistent level tier (k_level_xcd): where the eight level-3 subtrees are big enough to be worth a workgroup group each.  A tree on
+    // which it once gave up (its workgroups were not resident together: another stream kept the CUs) stays with a launch per level.
+    const int persist_knob = ctx->tune[BVHGPU_TUNE_BUILD_LEVEL_PERSIST];
+    const bool persist = persist_knob != 0 && !t->persist_broken && level_fused<T>(t) && n >= 32 * (MID_MAX + 1);
+    if (persist) t->xbar.reserve(XBAR_WORDS * sizeof(unsigned long long));
     for (int i = 0; i < 2; i++) {
         t->big[i].reserve(g.max_big * sizeof(Item<T>));
         t->stats[i].reserve(g.max_big * STAT_REP * sizeof(ItemStats<T>));
@@ -2098,9 +2209,18 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
         for (size_t m = n; m > (size_t)MID_MAX; m = (m + 1) / 2) fixed++;
         if (t->hint_levels > 0 && t->hint_n == n) fixed = t->hint_levels;
         if (fixed > MAXLV - 4) fixed = MAXLV - 4;
+        if (persist) {
+            // tree levels 0 .. 2 are split (and level 3 binned) by launches over the whole chip; everything below by ONE persistent launch,
+            // a workgroup group per level-3 subtree, however deep the subtrees turn out to be (no blind pass count, no host loop)
+            for (; level < 3; level++) run_level<T>(t, a, g, level);
+            const int nx = persist_knob >= 8 ? std::min(persist_knob, 64) : 32;
+            hipLaunchKernelGGL(k_level_xcd<T>, dim3(8 * nx), dim3(LEVEL_THREADS), 0, st, a, 4);
+            t->pend_persist = true;
+            fixed = level;
+        }
         for (; level < fixed; level++) {
             run_level<T>(t, a, g, level);
-            if (level == 3 && ctx->tune[BVHGPU_TUNE_WIDE_EARLY_ITEMS] != 0) {   // (only when the early item filter is switched on: an event record costs the level chain a gap)
+            if (level == 3 && ctx->tune[BVHGPU_TUNE_WIDE_EARLY_ITEMS] != 0 && !t->pend_persist) {   // (only when the early item filter is switched on: an event record costs the level chain a gap)
                 // tree levels 0..3 are split: their BvhNode records (and with them the boxes of the 16 subtrees the wide
                                 // walk cuts its rays into) are final — a batch enqueued behind this build may filter its rays from here on
                 if (!t->ev_top) BVH_HIP(hipEventCreateWithFlags(&t->ev_top, hipEventDisableTiming));
@@ -2117,7 +2237,7 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     t->bstat.reserve(64);
     if (flatten_after && n >= 1)
         flatten_tree<T>(t, a.ctr, reinterpret_cast<uint32_t*>(t->pin), (uint32_t)(ROOTKEY_OFF / 4), t->bstat.as<uint32_t>(), (uint32_t)CTR_FLAGS,
-                        n > (size_t)MID_MAX ? (uint32_t)(CTR_LEVEL0 + 2 * lvl_slot(level)) : (uint32_t)CTR_FLAGS,
+                        (n > (size_t)MID_MAX && !t->pend_persist) ? (uint32_t)(CTR_LEVEL0 + 2 * lvl_slot(level)) : (uint32_t)CTR_FLAGS,   // (persistent tier: its give-up flag IS the unfinished bit)
                         ctx->tune[BVHGPU_TUNE_FLATTEN_LAZY] != 0);
     else hipLaunchKernelGGL(k_publish_build<T>, dim3(1), dim3(256), 0, st, a, reinterpret_cast<uint32_t*>(t->pin));
     t->ctr_ready = true;
@@ -2139,8 +2259,17 @@ template <typename T> void build_finalize(bvhgpu_tree* t) {
         t->failed_gen = t->gen; t->failed_what = "NONFINITE";   // (batches already enqueued on this generation walked nothing: their waits say so)
         throw HipFail{hipErrorInvalidValue, "NONFINITE", __LINE__};
     }
-    int level = t->pend_level;
-    if (n > (size_t)MID_MAX && pin[CTR_LEVEL0 + 2 * lvl_slot(level)] != 0) {
+    if (t->pend_persist && (pin[CTR_FLAGS] & BUILD_FLAG_PERSIST_GAVE_UP)) {
+        // the persistent level tier left the tree unfinished: the same generation again with a launch per level (this tree stays with that)
+        t->persist_broken = true;
+        const bool fl = t->pend_flatten;
+        build_enqueue<T>(t, static_cast<const T*>(nullptr), n, fl, true);
+        build_finalize<T>(t);
+        t->redone_gen = t->gen;   // whoever traversed the optimistic result of this generation must do it again
+        return;
+    }
+    int level = t->pend_persist ? MAXLV - 3 : t->pend_level;
+    if (n > (size_t)MID_MAX && !t->pend_persist && pin[CTR_LEVEL0 + 2 * lvl_slot(level)] != 0) {
         // slow path: the level queue is not empty yet (unbalanced tree) — one more level per host round trip.  The counters
         // were zeroed behind the readback: put them back first.
         const BuildGrid<T> g(t, MID_MAX);
@@ -2173,13 +2302,13 @@ template <typename T> void build_finalize(bvhgpu_tree* t) {
     int used = level;
     while (used > 0 && used - 1 < MAXLV - 2 && pin[CTR_LEVEL0 + 2 * (used - 1)] == 0) used--;
     t->levels = used;
-    t->hint_levels = used > 0 ? used : 0; t->hint_n = n;   // the next rebuild's optimistic schedule
+    if (!t->pend_persist) { t->hint_levels = used > 0 ? used : 0; t->hint_n = n; }   // the next rebuild's optimistic schedule
     t->exact_only = (pin[CTR_FLAGS] & BUILD_FLAG_EMPTY_SPLIT) != 0;
     t->built = true;
 }
 
 template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after) {
-    build_enqueue<T>(t, aabbs_dev, n, flatten_after);
+    build_enqueue<T>(t, aabbs_dev, n, flatten_after, false);
     build_finalize<T>(t);
 }
 
@@ -2193,8 +2322,8 @@ void debug_mid_prof(unsigned long long* out, bool reset) {
 
 template void build_tree<float>(bvhgpu_tree*, const float*, size_t, bool);
 template void build_tree<double>(bvhgpu_tree*, const double*, size_t, bool);
-template void build_enqueue<float>(bvhgpu_tree*, const float*, size_t, bool);
-template void build_enqueue<double>(bvhgpu_tree*, const double*, size_t, bool);
+template void build_enqueue<float>(bvhgpu_tree*, const float*, size_t, bool, bool);
+template void build_enqueue<double>(bvhgpu_tree*, const double*, size_t, bool, bool);
 template void build_finalize<float>(bvhgpu_tree*);
 template void build_finalize<double>(bvhgpu_tree*);
 

@@ -69,7 +69,7 @@ void copy_out(bvhgpu_ctx* ctx, void* dst, const void* src_dev, size_t bytes, int
 
 void free_tree_buffers(bvhgpu_tree* t) {
     t->aabbs.release(); t->nodes.release(); t->node_start.release(); t->node_count.release();
-    t->shape_node.release(); t->flat.release(); t->trav.release(); t->slot_entry.release(); t->node_slot.release(); t->tris.release();
+    t->xbar.release(); t->shape_node.release(); t->flat.release(); t->trav.release(); t->slot_entry.release(); t->node_slot.release(); t->tris.release();
     t->idx[0].release(); t->idx[1].release(); t->bk.release(); t->lvbuf.release();
     t->big[0].release(); t->big[1].release(); t->mid2.release(); t->small.release();
     t->stats[0].release(); t->stats[1].release();

@@ -94,6 +94,8 @@ struct bvhgpu_tree {
     bool exact_only = false;     // some split had no SAH winner (empty child bounds): a child box is not the join of its
                                  // grandchildren, so traversal must test every ancestor (binary walk only)
     int pend_level = 0;
+    bool pend_persist = false;   // the build in flight ran the level tier's lower passes as one persistent launch (build.hip k_level_xcd)
+    bool persist_broken = false; // ... which once gave up on this tree (its workgroups were not resident together): a launch per level from then on
     int levels = 0;
     int hint_levels = 0;         // level-synchronous passes the previous build of hint_n shapes needed
     size_t hint_n = 0;
@@ -122,6 +124,7 @@ struct bvhgpu_tree {
     bvhgpu::DevBuf idx[2];      // n * u32 ping-pong permutation
     bvhgpu::DevBuf bk;          // 2 n * u8 bucket per position (two consecutive levels)
     bvhgpu::DevBuf lvbuf;       // level tier, one launch per level: rotating tile maps / tile counts / statistics (build.hip LevelLayout)
+    bvhgpu::DevBuf xbar;        // persistent level tier: barrier words of its eight workgroup groups (2 KB)
     bvhgpu::DevBuf big[2];      // Item queues of the level-synchronous tier
     bvhgpu::DevBuf mid2;        // Item queue of the workgroup tier (65..1024 shapes)
     bvhgpu::DevBuf small;       // Item queue of the wave-subtree tier
@@ -195,7 +198,7 @@ namespace bvhgpu {
 
 // build.hip
 template <typename T> void build_tree(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after);
-template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after);
+template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, size_t n, bool flatten_after, bool redo = false);
 template <typename T> void build_finalize(bvhgpu_tree* t);
 // flatten.hip
 // pub_*: also publish + reset the builder's counters (build_enqueue's last launch); see k_flatten

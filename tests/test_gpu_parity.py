@@ -221,6 +221,62 @@ def test_level_tier_schedules_same_tree(eng, orc, launches, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("groups_of", [1, 16, 64])
+def test_persistent_level_tier_same_tree(eng, orc, groups_of, dtype):
+    """BVHGPU_TUNE_BUILD_LEVEL_PERSIST: the level tier's passes below tree level 3 as ONE persistent launch, a workgroup group per
+    level-3 subtree synchronising with itself (build.hip k_level_xcd; 1 = 32 workgroups per group, else that many).  The BvhNode array
+    (bvh_node.rs:81-279) and the shape → node map must be the oracle's, bit for bit: balanced scenes, sizes around the tier's threshold
+    (32 x 769 shapes), an unbalanced chain (one subtree holds nearly everything and runs on for dozens of passes), colliding centroids
+    (the halving branch inside the persistent passes), rebuilds of the same tree object, and the wide walk's CSR on the result."""
+    from bvh_amd import Bvh, Context, testbase as tb
+    from bvh_amd._lib import TUNE_BUILD_LEVEL_PERSIST
+    ctx = Context(0)
+    ctx.set_tuning(TUNE_BUILD_LEVEL_PERSIST, groups_of)
+    rng = np.random.default_rng(11)
+    scenes = []
+    _, cubes = tb.create_n_cubes(10000)
+    scenes.append(cubes.astype(dtype))                                  # configs[1]'s scene
+    scenes.append(cubes[:30000].astype(dtype))
+    for m in (24607, 24608, 24609, 50001):                              # around 32 x (768 + 1)
+        lo = rng.uniform(-500, 500, size=(m, 3))
+        scenes.append(np.concatenate([lo, lo + rng.uniform(0, 3, size=(m, 3))], axis=1).astype(dtype))
+    n = 40000
+    x = np.float32(1.0003) ** np.arange(n, dtype=np.float32)
+    lo = np.stack([x, np.zeros(n, np.float32), np.zeros(n, np.float32)], axis=1)
+    scenes.append(np.concatenate([lo, lo + np.float32(0.5)], axis=1).astype(dtype))        # unbalanced: long chains below level 3
+    same = np.tile(np.array([[1, 2, 3, 4, 5, 6]], dtype), (30000, 1))                       # every centroid equal: halving all the way down
+    scenes.append(same)
+    scenes.append(np.concatenate([same[:12000], cubes[:24000].astype(dtype)]))              # a degenerate cluster inside a scene
+    clustered = np.concatenate([cubes[:3000].astype(dtype) * dtype(0.001), cubes[3000:60000].astype(dtype)])   # one level-3 subtree tiny
+    scenes.append(clustered)
+    bvh = None
+    for aabbs in scenes:
+        ot = orc.build(aabbs, threads=orc.max_threads(), schedule="fast")
+        for _ in range(2):                                              # (the second build of a scene reuses every buffer and counter)
+            bvh = Bvh.from_aabbs(aabbs, ctx) if bvh is None else bvh.rebuild(aabbs)
+            assert bvh.nodes.tobytes() == ot.nodes.tobytes(), (groups_of, len(aabbs))
+            assert np.array_equal(bvh.shape_nodes, ot.shape_node)
+    # the asynchronous step on such a tree, and the walk of what it built
+    rays = orc.create_rays(0, 50_000, tb.default_bounds(), dtype)
+    a = scenes[0]
+    ot = orc.build(a, threads=orc.max_threads(), schedule="fast")
+    oflat = orc.flatten(ot.nodes)
+    ooff, oidx, _, _ = orc.traverse_flat(oflat, a, rays, threads=orc.max_threads())
+    import torch
+    from bvh_amd import RayBatch
+    dev_a = torch.from_numpy(a).cuda()
+    dev_r = torch.from_numpy(rays.view(np.uint8).reshape(-1)).cuda()
+    rb = RayBatch.from_device(dev_r, len(rays), dtype)
+    for _ in range(3):
+        bvh.rebuild_async(dev_a)
+        h = bvh.traverse_async(rb)
+        h.wait()
+        off, idx = h.fetch(len(rays))
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+    assert bvh.flatten().nodes.tobytes() == oflat.tobytes()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("n", [4095, 4096, 4097, 8193, 30000])
 def test_parity_mid_tier_boundaries(eng, orc, n, dtype):
     """sizes around MID_MAX = 4096 (workgroup tier) with clustered data so sub-node sizes vary widely."""
