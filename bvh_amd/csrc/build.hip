@@ -37,7 +37,7 @@ constexpr int CTR_TOPMASK = BUILD_CTR_TOPMASK;   // u32: bit h set when the leve
                                  // once bits 1..15 are there, the walk's item filter can run beside the rest of the build (traverse.hip k_wide_items)
 constexpr uint32_t BUILD_FLAG_NONFINITE = 1u;    // a shape AABB holds NaN / ±inf, or the root centroid extent overflows: the
                                                  // reference panics there (bvh_node.rs:214-217, `to_usize().unwrap()`); nothing is built
-constexpr uint32_t BUILD_FLAG_PERSIST_GAVE_UP = BSTAT_UNFINISHED;   // k_level_xcd: a group barrier timed out (its workgroups were not all resident in time) or the
+constexpr uint32_t BUILD_FLAG_PERSIST_GAVE_UP = BSTAT_UNFINISHED;   // k_level<T, false, true>: a group barrier timed out (its workgroups were not all resident in time) or the
                                                  // subtree is deeper than the counter slots: the tree is unfinished, the host builds it again level by level
 constexpr uint32_t BUILD_FLAG_EMPTY_SPLIT = 2u;  // some node had no winning SAH candidate (NaN / inf costs): its children carry
                                                  // Aabb::empty() bounds (bvh_node.rs:225-230), so a child box is NOT the join of its
@@ -77,7 +77,7 @@ constexpr int STAT_REP = BVH_STAT_REP;   // global replicas of an item's statist
                               // selection merges the replicas
 constexpr int CTR_LEVEL0 = 16;   // u32 pairs (n_items, n_tiles) per level slot
 constexpr int CTR_XDIR = CTR_LEVEL0 + 2 * MAXLV;   // 8 x {kind, slot, start, count}: the tree's level-3 nodes (heap numbers 8 .. 15) as the level pass that
-                                                   // created them left them: the subtree every workgroup group of k_level_xcd owns
+                                                   // created them left them: the subtree every workgroup group of k_level<T, false, true> owns
 static_assert((CTR_XDIR + 8 * 4) * 4 <= 1024, "the directory lives inside the counter page");
 constexpr size_t ROOTKEY_OFF = 1024;  // byte offset of k_prep's per-workgroup partial bounds (12 keys each) inside the ctr buffer
 constexpr int PREP_MAX_WG = 1024;     // k_prep's grid never exceeds this
@@ -132,7 +132,7 @@ template <typename T> struct BuildArgs {
     typename Traits<T>::Key* rootkeys;   // [gridDim of k_prep][12]: every workgroup's bounds (joined by k_root / k_level<ROOT>)
     uint32_t prep_wgs;                   // gridDim of k_prep
     uint32_t n;
-    unsigned long long* xbar;            // k_level_xcd: per workgroup group two 128-byte lines {arrivals | live << 32} and {round | live << 32}; zeroed by k_prep
+    unsigned long long* xbar;            // k_level<T, false, true>: per workgroup group two 128-byte lines {arrivals | live << 32} and {round | live << 32}; zeroed by k_prep
 };
 constexpr int XBAR_WORDS = 8 * 32;       // unsigned long long words: 8 groups x 2 lines of 16
 
@@ -712,15 +712,18 @@ template <typename T> __global__ __launch_bounds__(256) void k_split(BuildArgs<T
 //   the children's work items (level tier: LevelArgs arrays; workgroup / wave tier: their queues, as before).
 // ROOT: level 0 has no parent — the root item (k_root) is binned in place.
 // ------------------------------------------------------------------------------------------------
-// Accesses to data another workgroup of the SAME launch wrote (k_level_xcd: one level's result is the next level's input without a
+// Accesses to data another workgroup of the SAME launch wrote (k_level<T, false, true>: one level's result is the next level's input without a
 // kernel boundary between them).  DEV: device-scope relaxed atomics = loads / stores with sc1 — a store is written through, a load does not
 // hit a line the L1 or a foreign XCD's L2 kept (tools/ubench/twostage.hip: no stale read in 19 M across the chip) — so the result does not
 // depend on where the dispatcher put a workgroup.  !DEV: the plain access of the launch-per-level schedule.
 template <bool DEV, typename U> __device__ __forceinline__ U ldx(const U* p) {
     if constexpr (DEV) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
 }
+#ifndef BVH_XCD_PLAIN_STORES
+#define BVH_XCD_PLAIN_STORES 0   // developer variant: 1 = plain stores in the persistent tier too (correct only while group q really sits on one XCD)
+#endif
 template <bool DEV, typename U, typename V> __device__ __forceinline__ void stx(U* p, V v) {
-    if constexpr (DEV) __hip_atomic_store(p, (U)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = (U)v;
+    if constexpr (DEV && !BVH_XCD_PLAIN_STORES) __hip_atomic_store(p, (U)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = (U)v;
 }
 template <bool DEV> __device__ __forceinline__ uint4 ldx4(const uint4* p) {
     if constexpr (DEV) { const uint32_t* q = reinterpret_cast<const uint32_t*>(p); return make_uint4(ldx<true>(q), ldx<true>(q + 1), ldx<true>(q + 2), ldx<true>(q + 3)); }
@@ -852,8 +855,9 @@ template <typename T> __device__ __forceinline__ void level_child_derive(LevelCh
 }
 
 #ifdef BVH_LEVEL_PROFILE   // developer build: wall-clock stamps (100 MHz) of k_level's phases at level BVH_LEVEL_PROFILE, per workgroup
-__device__ unsigned long long g_level_prof[8 * 1024];
-#define LEVEL_STAMP(i) do { if (L == BVH_LEVEL_PROFILE && threadIdx.x == 0 && blockIdx.x < 1024) g_level_prof[8 * blockIdx.x + (i)] = wall_clock64(); } while (0)
+__device__ unsigned long long g_level_prof[2 * 8 * 1024];   // rows 0 .. 1023: level BVH_LEVEL_PROFILE, rows 1024 .. 2047: the level after it
+#define LEVEL_STAMP(i) do { if ((L == BVH_LEVEL_PROFILE || L == BVH_LEVEL_PROFILE + 1) && threadIdx.x == 0 && blockIdx.x < 1024) \
+        g_level_prof[8 * (blockIdx.x + 1024 * (L - BVH_LEVEL_PROFILE)) + (i)] = wall_clock64(); } while (0)
 #else
 #define LEVEL_STAMP(i) do { } while (0)
 #endif
@@ -874,22 +878,56 @@ constexpr int LEVEL_PT = TILE / 256;   // shapes per thread
 #ifndef BVH_LEVEL_THREADS
 #define BVH_LEVEL_THREADS 256
 #endif
+#ifndef BVH_LEVEL_EARLY_DUTIES
+#define BVH_LEVEL_EARLY_DUTIES 1
+#endif
 // 256: wave 0 runs the selection and then carries shapes like the other three.  320: wave 0 ONLY selects (and writes the node /
 // the children's items), four more waves carry the shapes — measured slower (build 0.204 → 0.226 ms at 120 k): five-wave
 // workgroups start up to 4 µs apart.
 constexpr int LEVEL_THREADS = BVH_LEVEL_THREADS;
 constexpr bool LEVEL_DEDICATED = LEVEL_THREADS > 256;
-// One pass of the tier over tile ids [g0, g1) by workgroups wg_rank, wg_rank + wg_count, … — the whole grid over all tiles for k_level, one
-// workgroup group over its subtree's tiles for k_level_xcd (DEV: see ldx / stx; the arrays the NEXT pass accumulates into are then reset
-// over that range and the statistics slots [s0, s1) only).  live (DEV, LDS): += children this workgroup sent on to the next pass.
-template <typename T, bool ROOT, bool DEV>
-__device__ __forceinline__ void level_pass(const BuildArgs<T>& a, const int L, const uint32_t wg_rank, const uint32_t wg_count, const uint32_t g0,
-                                           const uint32_t g1, const uint32_t s0, const uint32_t s1, uint32_t* live) {
+// DEV = false: ONE pass of the tier over all tile ids by the whole grid (a launch per level).
+// DEV = true (k_level<T, false, true>, BVHGPU_TUNE_BUILD_LEVEL_PERSIST): the tier's passes from tree level L_first on as ONE
+// persistent launch.  The launch-per-level schedule pays ≈ 2.5 µs of dispatch gap + ≈ 2 µs of cold misses per level; a barrier over ALL
+// workgroups costs as much (2.3 – 2.5 µs in two stages, tools/ubench/twostage.hip), but the eight subtrees below tree level 3 never exchange
+// anything: workgroup group q = blockIdx.x % 8 (the dispatcher puts those on one XCD: 2 048 of 2 048 blocks — a matter of speed only, see
+// ldx / stx) owns the subtree of heap number 8 + q and synchronises with ITSELF after every pass (1.9 µs for 32 workgroups, eight groups
+// side by side), running on until its subtree has left the tier, however deep.  A pass covers the subtree's tile ids [T(start), T(start +
+// count)), T(p) = p / TILE + p / slot_div (monotone in p: the ranges of the eight subtrees do not overlap, LevelArgs) and resets the next
+// pass's accumulators over that range and the statistics slots [start / slot_div, end / slot_div) only.  Barrier: one 64-bit word per group,
+// {arrivals | children sent on << 32}; the last arriver publishes {round | children << 32} on a line of its own, the others poll that with
+// sc1 loads.  The release is s_waitcnt vmcnt(0) behind write-through stores: no fence (an agent-scope fence writes the whole L2 back:
+// 6.5 µs).  A poll that does not come back (the group's workgroups are not all resident: another stream's walk holds the CUs) raises
+// BUILD_FLAG_PERSIST_GAVE_UP and the host builds the tree again with a launch per level (build_finalize).
+// (One kernel body for both: `a` must stay the kernel's own by-value parameter — handed to a helper by reference it is copied to scratch,
+//  344 bytes, and every access to it becomes a scratch load: 182 VGPRs and +67 µs per build, measured.)
+constexpr uint32_t XCD_SPIN_MAX = 3000000u;
+template <typename T, bool ROOT, bool DEV = false> __global__ __launch_bounds__(LEVEL_THREADS) void k_level(BuildArgs<T> a, int L_first) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
     static_assert(TILE % 256 == 0 && LEVEL_PT >= 1 && LEVEL_PT <= 4, "a tile is a whole number of 256-thread rounds");
     static_assert(!(ROOT && DEV), "the root is binned by a launch of its own");
     const LevelArgs<T>& v = a.lv;
+    uint32_t wg_rank = blockIdx.x, wg_count = gridDim.x, g0 = 0u, g1 = v.n_tiles, s0 = 0u, s1 = v.n_slots;
+    __shared__ uint32_t s_live, s_go;
+    __shared__ unsigned long long s_word;
+    uint32_t live_seen = 0;
+    if constexpr (DEV) {
+        const uint32_t grp = blockIdx.x & 7u;
+        wg_rank = blockIdx.x >> 3; wg_count = gridDim.x >> 3;
+        const uint32_t* xd = &a.ctr[CTR_XDIR + 4 * grp];        // (written by the pass that split tree level 2: an earlier launch)
+        const uint32_t kind = xd[0], start = xd[2], count = xd[3];
+        if (kind != 3u || (a.ctr[CTR_FLAGS] & BUILD_FLAG_NONFINITE)) return;   // the whole group: its subtree never reached this tier (or there is no tree)
+        const uint32_t sd = v.slot_div, end = start + count;
+        g0 = start / (uint32_t)TILE + start / sd; g1 = end / (uint32_t)TILE + end / sd;
+        s0 = start / sd; s1 = end / sd;
+    }
+    uint32_t* const live = &s_live;
+  for (int L = L_first, round = 0; ; L++, round++) {
+    if constexpr (DEV) {
+        if (threadIdx.x == 0) s_live = 0u;
+        __syncthreads();
+    }
     const int bP = (L + 2) % 3, bC = L % 3, bN = (L + 1) % 3;
     const uint32_t* src = ROOT ? a.idx[0] : a.idx[(L + 1) & 1];   // the parents' order (level L-1; the root's slice is where k_prep wrote it)
     uint32_t* dst = a.idx[L & 1];                                   // the children's
@@ -983,6 +1021,7 @@ __device__ __forceinline__ void level_pass(const BuildArgs<T>& a, const int L, c
         Key rk[2][STAT_REP];
         uint32_t rc[STAT_REP];
         T PA[6], PC[6];
+        uint32_t P_ni = 0, P_heap = 0, P_parent = 0;   // (tile 0's duties: the same record, fetched with the bounds)
         if (!ROOT && w == 0) {
             const ItemStats<T>* rep = &v.stats[bP][(size_t)slotP * STAT_REP];
 #pragma unroll
@@ -995,6 +1034,7 @@ __device__ __forceinline__ void level_pass(const BuildArgs<T>& a, const int L, c
             for (int r = 0; r < STAT_REP; r++) rc[r] = lane < NUM_BUCKETS ? ldx<DEV>(&rep[r].cnt[lane]) : 0u;
 #pragma unroll
             for (int k = 0; k < 6; k++) { PA[k] = ldx<DEV>(&P->A[k]); PC[k] = ldx<DEV>(&P->C[k]); }
+            if (tl == 0) { P_ni = ldx<DEV>(&P->ni); P_heap = ldx<DEV>(&P->heap); P_parent = ldx<DEV>(&P->parent); }
         }
         // ---- loads that depend on the tile only: the shapes' indices and buckets at L-1 ...
         uint32_t sh[LEVEL_PT];
@@ -1022,6 +1062,59 @@ __device__ __forceinline__ void level_pass(const BuildArgs<T>& a, const int L, c
                 for (int b = 0; b < NUM_BUCKETS; b++) tcv[i][b] = (w > 0 && j < ntl) ? ldx<DEV>(&tc[(size_t)j * NUM_BUCKETS + b]) : 0u;
             }
         }
+        // ---- tile 0 of P: P's BvhNode (bvh_node.rs:145-151) and the children's work items.  Everything it needs is known once the selection
+        // is: wave 0 issues these stores right behind the selection (BVH_LEVEL_EARLY_DUTIES, default), where their latency hides behind the
+        // move of the shapes — at the end of the pass (the round-2 .. 4 place) the tile-0 workgroups were the stragglers every launch boundary
+        // and every group barrier waited for: mean end of a pass 7.6 µs, last end 9.7 µs (tools/level_prof.py, profiles/r5_level_timeline.log)
+        auto tile0_duties = [&](const uint32_t nl) {
+            const uint32_t ni = P_ni, heap = P_heap;
+            const uint32_t li = ni + 1;                 // :140
+            const uint32_t ri = li + (2 * nl - 1);      // :138,142 (nl: the lambda's argument)
+            if (sel.no_winner && lane == 0) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_EMPTY_SPLIT);
+            if (lane == 0) {
+                typename Tr::Node* nd = &a.nodes[ni];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    nd->l_min[k] = sel.AL[k]; nd->l_max[k] = sel.AL[3 + k];
+                    nd->r_min[k] = sel.AR[k]; nd->r_max[k] = sel.AR[3 + k];
+                }
+                nd->parent = P_parent; nd->l = li; nd->r = ri; nd->shape = NONE;
+                a.node_start[ni] = start;
+                a.node_count[ni] = count;
+                a.node_slot[ni] = (uint16_t)heap;
+                if (heap < 16u) atomicOr(&a.ctr[CTR_TOPMASK], 1u << heap);
+            }
+            // queue slots of the children that leave this tier: lanes 0 / 1 reserve them at the same time
+            const uint32_t mykind = ch[lane & 1].kind;
+            uint32_t qslot = 0;
+            if (lane < 2) {
+                if (mykind == 0u) qslot = atomicAdd(&a.ctr[CTR_SMALL], 1u);
+                else if (mykind == 1u) qslot = atomicAdd(&a.ctr[CTR_MID2], 1u);
+                else atomicAdd(&a.ctr[CTR_LEVEL0 + 2 * lvl_slot(L)], 1u);   // the host only asks whether the level is empty
+            }
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const LevelChild<T>& c = ch[side];
+                const uint32_t cq = __shfl(qslot, side);
+                Item<T>* it = c.kind == 0u ? &a.small[cq] : (c.kind == 1u ? &a.mid2[cq] : &v.item[L & 1][c.slot]);
+                if (lane == 0) {
+                    stx<DEV>(&it->ni, side ? ri : li); stx<DEV>(&it->parent, ni); stx<DEV>(&it->start, c.start); stx<DEV>(&it->count, c.count);
+                    stx<DEV>(&it->tile_base, c.tile0); stx<DEV>(&it->parity, (uint32_t)(L & 1)); stx<DEV>(&it->heap, heap_child(heap, (uint32_t)side)); stx<DEV>(&it->_r1, 0u);
+                    // the tree's level-3 nodes (heap numbers 8 .. 15): the subtrees the groups of k_level<T, false, true> own
+                    const uint32_t hc = heap_child(heap, (uint32_t)side);
+                    if (hc >= 8u && hc < 16u) {
+                        uint32_t* xd = &a.ctr[CTR_XDIR + 4 * (hc - 8u)];
+                        xd[0] = c.kind; xd[1] = c.slot; xd[2] = c.start; xd[3] = c.count;
+                    }
+                    if (DEV && c.kind == 3u) atomicAdd(live, 1u);   // (LDS)
+                }
+                if (lane < 6) { stx<DEV>(&it->A[lane], side ? sel.AR[lane] : sel.AL[lane]); stx<DEV>(&it->C[lane], side ? sel.CR[lane] : sel.CL[lane]); }
+                if (c.kind == 3u) {
+                    const uint32_t cnt_t = (c.count + TILE - 1) / TILE;
+                    for (uint32_t j = lane; j < cnt_t; j += WAVE) stx4<DEV>(&v.tile_map[bC][c.tile0 + j], make_uint4(c.slot, c.start, c.count, 0u));
+                }
+            }
+                };
         if (ROOT) {
             if (threadIdx.x == 0) {
                 T C[6];
@@ -1060,7 +1153,7 @@ __device__ __forceinline__ void level_pass(const BuildArgs<T>& a, const int L, c
             LEVEL_STAMP(7);
             sah_select_wave<T>(s_merged.k, s_merged.cnt, PA, degen, &sel, s_sah, lane);
 #ifdef BVH_LEVEL_PROFILE
-            if (L == BVH_LEVEL_PROFILE && threadIdx.x == 0 && blockIdx.x < 1024) g_level_prof[8 * blockIdx.x + 3] = wall_clock64();   // (slot 3: selection done)
+            LEVEL_STAMP(3);   // (slot 3: selection done)
 #endif
             if (lane < 2) {   // lane 0: left child, lane 1: right child
                 const uint32_t nl = sel.nl;
@@ -1068,6 +1161,12 @@ __device__ __forceinline__ void level_pass(const BuildArgs<T>& a, const int L, c
 #pragma unroll
                 for (int k = 0; k < 6; k++) CC[k] = lane ? sel.CR[k] : sel.CL[k];
                 level_child_derive<T>(&ch[lane], CC, lane ? start + nl : start, lane ? count - nl : nl, a.mid_max, v.slot_div);
+            }
+            if (BVH_LEVEL_EARLY_DUTIES && tl == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                tile0_duties(sel.nl);
             }
         } else {
             // the other waves prepare the LDS accumulators meanwhile
@@ -1226,103 +1325,23 @@ __device__ __forceinline__ void level_pass(const BuildArgs<T>& a, const int L, c
             atomicAdd(&v.tile_cnt[bC][(size_t)(ch[side].tile0 + kt) * NUM_BUCKETS + nb], cn);
         }
         LEVEL_STAMP(5);
-        // ---- tile 0 of P: P's BvhNode (bvh_node.rs:145-151) and the children's work items
-        if (!ROOT && tl == 0 && w == 0) {
-            const uint32_t ni = ldx<DEV>(&P->ni), heap = ldx<DEV>(&P->heap);
-            const uint32_t li = ni + 1;                 // :140
-            const uint32_t ri = li + (2 * nl - 1);      // :138,142
-            if (sel.no_winner && lane == 0) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_EMPTY_SPLIT);
-            if (lane == 0) {
-                typename Tr::Node* nd = &a.nodes[ni];
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    nd->l_min[k] = sel.AL[k]; nd->l_max[k] = sel.AL[3 + k];
-                    nd->r_min[k] = sel.AR[k]; nd->r_max[k] = sel.AR[3 + k];
-                }
-                nd->parent = ldx<DEV>(&P->parent); nd->l = li; nd->r = ri; nd->shape = NONE;
-                a.node_start[ni] = start;
-                a.node_count[ni] = count;
-                a.node_slot[ni] = (uint16_t)heap;
-                if (heap < 16u) atomicOr(&a.ctr[CTR_TOPMASK], 1u << heap);
-            }
-            // queue slots of the children that leave this tier: lanes 0 / 1 reserve them at the same time
-            const uint32_t mykind = ch[lane & 1].kind;
-            uint32_t qslot = 0;
-            if (lane < 2) {
-                if (mykind == 0u) qslot = atomicAdd(&a.ctr[CTR_SMALL], 1u);
-                else if (mykind == 1u) qslot = atomicAdd(&a.ctr[CTR_MID2], 1u);
-                else atomicAdd(&a.ctr[CTR_LEVEL0 + 2 * lvl_slot(L)], 1u);   // the host only asks whether the level is empty
-            }
-#pragma unroll
-            for (int side = 0; side < 2; side++) {
-                const LevelChild<T>& c = ch[side];
-                const uint32_t cq = __shfl(qslot, side);
-                Item<T>* it = c.kind == 0u ? &a.small[cq] : (c.kind == 1u ? &a.mid2[cq] : &v.item[L & 1][c.slot]);
-                if (lane == 0) {
-                    stx<DEV>(&it->ni, side ? ri : li); stx<DEV>(&it->parent, ni); stx<DEV>(&it->start, c.start); stx<DEV>(&it->count, c.count);
-                    stx<DEV>(&it->tile_base, c.tile0); stx<DEV>(&it->parity, (uint32_t)(L & 1)); stx<DEV>(&it->heap, heap_child(heap, (uint32_t)side)); stx<DEV>(&it->_r1, 0u);
-                    // the tree's level-3 nodes (heap numbers 8 .. 15): the subtrees the groups of k_level_xcd own
-                    const uint32_t hc = heap_child(heap, (uint32_t)side);
-                    if (hc >= 8u && hc < 16u) {
-                        uint32_t* xd = &a.ctr[CTR_XDIR + 4 * (hc - 8u)];
-                        xd[0] = c.kind; xd[1] = c.slot; xd[2] = c.start; xd[3] = c.count;
-                    }
-                    if (DEV && c.kind == 3u) atomicAdd(live, 1u);   // (LDS)
-                }
-                if (lane < 6) { stx<DEV>(&it->A[lane], side ? sel.AR[lane] : sel.AL[lane]); stx<DEV>(&it->C[lane], side ? sel.CR[lane] : sel.CL[lane]); }
-                if (c.kind == 3u) {
-                    const uint32_t cnt_t = (c.count + TILE - 1) / TILE;
-                    for (uint32_t j = lane; j < cnt_t; j += WAVE) stx4<DEV>(&v.tile_map[bC][c.tile0 + j], make_uint4(c.slot, c.start, c.count, 0u));
-                }
-            }
-        }
+        if (!BVH_LEVEL_EARLY_DUTIES && !ROOT && tl == 0 && w == 0) tile0_duties(nl);
         LEVEL_STAMP(6);
         __syncthreads();
     }
-}
-
-template <typename T, bool ROOT> __global__ __launch_bounds__(LEVEL_THREADS) void k_level(BuildArgs<T> a, int L) {
-    level_pass<T, ROOT, false>(a, L, blockIdx.x, gridDim.x, 0u, a.lv.n_tiles, 0u, a.lv.n_slots, nullptr);
-}
-
-// ------------------------------------------------------------------------------------------------
-// The tier's passes from tree level 4 on as ONE persistent launch (BVHGPU_TUNE_BUILD_LEVEL_PERSIST).  The launch-per-level
-// schedule pays ≈ 2.5 µs of dispatch gap + ≈ 2 µs of cold misses per level; a barrier over ALL workgroups costs as much (2.3 – 2.5 µs in two
-// stages, tools/ubench/twostage.hip), but the eight subtrees below tree level 3 never exchange anything: workgroup group q = blockIdx.x % 8
-// (the dispatcher puts those on one XCD: 2 048 of 2 048 blocks — a matter of speed only, see ldx / stx) owns the subtree of heap number
-// 8 + q and synchronises with ITSELF after every pass (1.9 µs for 32 workgroups, eight groups side by side), running on until its subtree has
-// left the tier, however deep.  A pass is level_pass<DEV> over the subtree's tile ids [T(start), T(start + count)), T(p) = p / TILE + p /
-// slot_div (monotone in p: the ranges of the eight subtrees do not overlap, LevelArgs).  Barrier: one 64-bit word per group, {arrivals |
-// children sent on << 32}; the last arriver publishes {round | children << 32} on a line of its own, the others poll that with sc1 loads.
-// The release is s_waitcnt vmcnt(0) behind write-through stores: no fence (an agent-scope fence writes the whole L2 back: 6.5 µs).
-// A poll that does not come back (the group's workgroups are not all resident: another stream's walk holds the CUs) raises
-// BUILD_FLAG_PERSIST_GAVE_UP and the host builds the tree again with a launch per level (build_finalize).
-// ------------------------------------------------------------------------------------------------
-constexpr uint32_t XCD_SPIN_MAX = 3000000u;
-template <typename T> __global__ __launch_bounds__(LEVEL_THREADS) void k_level_xcd(BuildArgs<T> a, int L0) {
-    __shared__ uint32_t s_live, s_go;
-    __shared__ unsigned long long s_word;
-    const uint32_t grp = blockIdx.x & 7u, rank = blockIdx.x >> 3, nx = gridDim.x >> 3;
-    const uint32_t* xd = &a.ctr[CTR_XDIR + 4 * grp];        // (written by the pass that split tree level 2: an earlier launch)
-    const uint32_t kind = xd[0], start = xd[2], count = xd[3];
-    if (kind != 3u || (a.ctr[CTR_FLAGS] & BUILD_FLAG_NONFINITE)) return;   // the whole group: its subtree never reached this tier (or there is no tree)
-    const uint32_t sd = a.lv.slot_div, end = start + count;
-    const uint32_t g0 = start / (uint32_t)TILE + start / sd, g1 = end / (uint32_t)TILE + end / sd;
-    const uint32_t s0 = start / sd, s1 = end / sd;
-    unsigned long long* arrive = a.xbar + (size_t)grp * 32, *go = arrive + 16;
-    uint32_t live_seen = 0;
-    for (int L = L0, round = 0; ; L++, round++) {
-        if (threadIdx.x == 0) s_live = 0u;
-        __syncthreads();
-        level_pass<T, false, true>(a, L, rank, nx, g0, g1, s0, s1, &s_live);
+    if constexpr (!DEV) {
+        break;
+    } else {
+        // ---- the group's barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store and atomic of this pass has been performed
         __syncthreads();
         if (threadIdx.x == 0) {
+            unsigned long long* arrive = a.xbar + (size_t)(blockIdx.x & 7u) * 32, *go = arrive + 16;
             const unsigned long long old = __hip_atomic_fetch_add(arrive, 1ull | ((unsigned long long)s_live << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             unsigned long long word;
             uint32_t ok = 1u;
-            if ((uint32_t)old + 1u == (uint32_t)(round + 1) * nx) {      // the last one of the group
-                word = (unsigned long long)(uint32_t)(round + 1) | ((old >> 32) + (unsigned long long)s_live) << 32;
+            if ((uint32_t)old + 1u == (uint32_t)(round + 1) * wg_count) {      // the last one of the group
+                word = (unsigned long long)(uint32_t)(round + 1) | (((old >> 32) + (unsigned long long)s_live) << 32);
                 __hip_atomic_store(go, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 uint32_t spins = 0;
@@ -1339,6 +1358,7 @@ template <typename T> __global__ __launch_bounds__(LEVEL_THREADS) void k_level_x
         live_seen = live_total;
         if (L + 1 >= MAXLV - 4) { if (threadIdx.x == 0) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_PERSIST_GAVE_UP); return; }   // (deeper than the counter slots)
     }
+  }
 }
 #ifdef BVH_LEVEL_PROFILE
 void debug_level_prof(unsigned long long* out, size_t n) {
@@ -2167,7 +2187,7 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     t->idx[1].reserve(n * 4);
     t->bk.reserve(2 * n);   // (the one-launch-per-level tier keeps the buckets of two consecutive levels)
     if (level_fused<T>(t) && n > (size_t)MID_MAX) t->lvbuf.reserve(LevelLayout<T>(n, MID_MAX).bytes);
-    // Persistent level tier (k_level_xcd): where the eight level-3 subtrees are big enough to be worth a workgroup group each.  A tree on
+    // Persistent level tier (k_level<T, false, true>): where the eight level-3 subtrees are big enough to be worth a workgroup group each.  A tree on
     // which it once gave up (its workgroups were not resident together: another stream kept the CUs) stays with a launch per level.
     const int persist_knob = ctx->tune[BVHGPU_TUNE_BUILD_LEVEL_PERSIST];
     const bool persist = persist_knob != 0 && !t->persist_broken && level_fused<T>(t) && n >= 32 * (MID_MAX + 1);
@@ -2214,7 +2234,7 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
             // a workgroup group per level-3 subtree, however deep the subtrees turn out to be (no blind pass count, no host loop)
             for (; level < 3; level++) run_level<T>(t, a, g, level);
             const int nx = persist_knob >= 8 ? std::min(persist_knob, 64) : 32;
-            hipLaunchKernelGGL(k_level_xcd<T>, dim3(8 * nx), dim3(LEVEL_THREADS), 0, st, a, 4);
+            hipLaunchKernelGGL((k_level<T, false, true>), dim3(8 * nx), dim3(LEVEL_THREADS), 0, st, a, 4);
             t->pend_persist = true;
             fixed = level;
         }

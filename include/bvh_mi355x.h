@@ -382,9 +382,11 @@ typedef enum {
                                               folded binary array are written by a second pass the first time something asks for them (bvhgpu_flat_nodes,
                                               a binary / STATS / t-slice / ordered walk, nearest_to, scene export, a broadcast) — same arrays, byte for byte;
                                               0 = every flatten writes everything at once */
-    BVHGPU_TUNE_BUILD_LEVEL_PERSIST = 16,  /* builder, level tier with one launch per level: 1 = tree levels 3 and deeper of the tier run as ONE persistent
-                                              launch, every XCD owning one level-3 subtree and synchronising its own workgroups (no chip-wide barrier);
-                                              0 = a launch per level throughout; -1 (default) = by scene (on where the eight subtrees exist) */
+    BVHGPU_TUNE_BUILD_LEVEL_PERSIST = 16,  /* builder, level tier with one launch per level, scenes of 32 x 769 shapes and more: != 0 = the tier's passes from tree level 4 on run as
+                                              ONE persistent launch, a workgroup group per level-3 subtree that synchronises with itself after every pass (1 = 32 workgroups
+                                              per group, 8 .. 64 = that many); 0 (default) = a launch per level throughout.  Measured on configs[1]: 64 per group builds in
+                                              0.1886 - 0.1891 ms against 0.1876 - 0.1895 ms (the pass is a chain of dependent loads, not its launch boundary), 32 per group is
+                                              slower (two tiles per workgroup) — kept selectable and parity-tested, off by default (profiles/r5_persist_ab.log) */
     BVHGPU_TUNE_COUNT = 17
 } bvhgpu_tune;
 int bvhgpu_set_tuning(bvhgpu_ctx *ctx, int knob, int value);

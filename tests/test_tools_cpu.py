@@ -71,11 +71,9 @@ def test_prof_summary_on_a_synthetic_rocpd_database(tmp_path):
 def test_design_numbers_reads_the_committed_bench_line():
     """tools/design_numbers.py renders DESIGN.md §7 from a bench line: run on the newest committed line of a default bench run, it must name the
     headline, every extra config with its CSR-assembly share, the pure f64 walk and the CPU baseline."""
-    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r4_*_bench_default.json")))
-    assert lines, "no committed default bench line under profiles/"
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design_numbers.py"), lines[-1]], capture_output=True, text=True)
+    path, j = _newest_default_line()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "design_numbers.py"), path], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
-    j = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
     assert f"{j['value']:.0f} Mrays/s" in p.stdout and "CSR assembly" in p.stdout and "Pure f64 walk" in p.stdout and "CPU baseline" in p.stdout
     assert p.stdout.count("parity equal: true") + p.stdout.count("`equal: true`") >= 1 + len(j.get("extra_configs", []))
 

@@ -14,17 +14,27 @@ print(f"  Walk roofline: bound `{r['bound']}` at {r['frac']:.3f} of peak (VALU {
       f"{rb.get('frac')} of HBM (a latency chain of {j.get('build_levels')} level launches + 4).")
 if j.get("pipelined"):
     print(f"  `pipelined` (one host thread, two streams, never `value`): {j['pipelined']['value']:.0f} Mrays/s.")
-if j.get("back_to_back"):
-    b = j["back_to_back"]
-    print(f"  `back_to_back` (ONE stream, the host one step behind, no overlap between steps; never `value`): {b['value']:.0f} Mrays/s, {b['ms_per_step']:.4f} ms per step — "
-          f"the per-step wait of `value` costs {1e3 * (j['ms_per_step'] - b['ms_per_step']):.0f} µs of host round trip.")
+x = j.get("step_excludes") or {}
+if x and "error" not in x:
+    print(f"  What the step excludes (each the same step with it inside, {x.get('steps')} steps; never `value`; {j.get('settle_steps')} untimed settle steps precede the warmup): "
+          + "; ".join(f"`{k}` {x[k]['value']:.0f} Mrays/s ({x[k]['delta_ms_vs_value'] * 1e3:+.0f} µs)" for k in ("with_ray_gen", "with_flat_array", "host_io") if k in x)
+          + (f" — host_io moves {sum(x['host_io']['bytes_per_step'].values()) / 1e6:.0f} MB per step at {x['host_io']['pcie_gbs']} GB/s." if "host_io" in x else "."))
 for e in j.get("extra_configs", []):
     if "error" in e:
         print(f"* {e['workload']} {e['dtype']}: ERROR {e['error']}")
         continue
     q, rr = e["phases_ms"], e["roofline"]
+    if e.get("harness"):      # the reference's whole bench iteration: ray generation + build + flatten + walk + triangle stage
+        base = {"cubes120k": "configs[1]", "standin-primary": "configs[2]"}.get(e["workload"].split("+")[0], e["workload"])
+        ch = e.get("cpu_harness") or {}
+        print(f"* {base} harness loop `intersect_bh`, {e['harness']}: **{e['value']:.0f} Mrays/s** ({e['ms_per_step']:.3f} ms per step: ray generation {q.get('ray_gen_ms', 0):.3f}, "
+              f"build {q['build_ms']:.3f}, flatten {q['flatten_ms']:.3f}, walk + triangle stage {q['traverse_kernel_ms']:.3f}, output {q['traverse_total_ms'] - q['traverse_kernel_ms']:.3f}); "
+              f"walk bound `{rr.get('bound')}` {rr.get('frac')}, HBM-side {rr.get('hbm_frac')}; parity equal: {str(e.get('parity', {}).get('equal')).lower()} "
+              f"({e.get('parity', {}).get('what')}); the oracle's same loop on {ch.get('cores')} host threads: {ch.get('value')} Mrays/s.")
+        continue
     tag = {("standin-primary", "weak"): "configs[2] (10 M primary rays, stand-in scene)", ("standin-incoherent", "weak"): "configs[3], one 12.5 M-ray shard",
-           ("standin-incoherent", "strong"): "configs[3] whole (100 M rays on one GPU)", ("cubes120k", "weak"): "configs[4] f64, guide walk"}[(e["workload"], e["scaling"])]
+           ("standin-incoherent", "strong"): "configs[3] whole (100 M rays on one GPU)", ("cubes120k", "weak"): "configs[4] f64, guide walk",
+           ("cubes12m", "weak"): "beyond BASELINE: 12 M triangles, 10 M rays (HBM regime)"}[(e["workload"], e["scaling"])]
     asm = q["traverse_total_ms"] - q["traverse_kernel_ms"] - q.get("ray_convert_ms", 0.0)
     print(f"* {tag}: **{e['value']:.0f} Mrays/s** ({e['ms_per_step']:.3f} ms per step: build {q['build_ms']:.3f}, flatten {q['flatten_ms']:.3f}, walk {q['traverse_kernel_ms']:.3f}, "
           f"CSR assembly {asm:.3f} = {100 * asm / q['traverse_total_ms']:.0f} % of traverse"
@@ -37,5 +47,5 @@ for e in j.get("extra_configs", []):
 c = j.get("cpu_baseline")
 if c:
     print(f"* CPU baseline on the same box (oracle, kind `{c['kind']}`, {c['cores']} threads of {c['host_cpus_visible']} visible CPUs): {c['value']:.1f} Mrays/s "
-          f"(build {c['build_ms']} ms, flatten {c['flatten_ms']} ms, traversal {c['traverse_ms_all_cores']} ms, {c['traverse_ns_per_ray_1thread']} ns/ray single-threaded) — "
+          f"(build {c['build_ms']} ms on {c.get('build_threads')} threads, flatten {c['flatten_ms']} ms, traversal {c['traverse_ms_all_cores']} ms, {c['traverse_ns_per_ray_1thread']} ns/ray single-threaded) — "
           f"the GPU step is {j.get('speedup_vs_cpu_baseline')} x; a reported baseline, not a target.")
