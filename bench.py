@@ -966,7 +966,7 @@ def main():
     #  trace: ≈ 12 µs between the last kernel of a step and the first of the next, EXPERIMENTS.md "Where the step's 342 µs are".)
 
     # ---- what the timed step leaves out, measured beside it (N = 1) — never reported as `value` ----
-    if n_gpus == 1 and args.workload == "cubes120k" and not args.no_excluded:
+    if n_gpus == 1 and args.workload == "cubes120k" and args.harness is None and not args.no_excluded:
         try:
             out["step_excludes"] = measure_excluded(wl, args, env, out["ms_per_step"])
         except Exception as e:   # a supplementary figure must never take the headline down

@@ -1,0 +1,65 @@
+"""bench.py is load-bearing evidence (the driver's record is its one JSON line), so its N = 1 sections run here at a small size on every GPU
+test round: the headline with its roofline lookup by the kernel name the LIBRARY reports, `step_excludes` (ray generation / eager FlatNode
+array / host I/O beside `value`), the reference's whole harness loop as extra configs with parity and the CPU loop beside it, the fair CPU
+baseline, and `--harness` as the headline of a run (what the profile rounds use)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_args, env_extra=None):
+    import bvh_amd
+    if bvh_amd.device_count() <= 0:
+        pytest.fail("GPU test selected but no HIP device is visible (no CPU fallback exists)")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra or {})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--cubes", "2500", "--rays", "200000", "--steps", "5", "--warmup", "2",
+           "--settle-steps", "10", "--extra-steps", "3", "--cpu-sample-rays", "100000"] + extra_args
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_default_line_sections_at_a_small_size():
+    out = _run([], {"BVH_BENCH_EXTRAS": "0,1"})      # extras: the harness loop on the cube scene, closest and triangles
+    assert out["value"] > 0 and out["n_gpus"] == 1 and out["steps"] == 5 and out["warmup"] == 2 and out["settle_steps"] == 10
+    assert out["parity"]["equal"] is True and out["parity"]["checked_rays"] == 200000
+    roof = out["roofline"]
+    assert roof["kernel"].startswith("bvhgpu::k_traverse_wide<float, 0, ") and roof["kernel"].endswith(">")      # as the library spells it
+    assert roof["algorithmic_frac"] > 0 and "reference-equivalent" in roof["slab_tests_note"]
+    ex = out["step_excludes"]
+    for k in ("with_ray_gen", "with_flat_array", "host_io"):
+        assert ex[k]["value"] > 0 and ex[k]["ms_per_step"] > 0, ex
+    assert ex["host_io"]["bytes_per_step"]["aabbs_up"] == 2500 * 12 * 24 and ex["host_io"]["bytes_per_step"]["rays_up"] == 200000 * 36
+    assert ex["host_io"]["value"] < out["value"]          # PCIe-inclusive: never the faster one
+    assert "back_to_back" not in out and out["pipelined"]["hits_every_step_equal"] is True
+    modes = []
+    for e in out["extra_configs"]:
+        assert "error" not in e, e
+        modes.append(e["harness"])
+        assert e["workload"] == "cubes120k+" + e["harness"] and e["parity"]["equal"] is True and e["parity"]["checked_rays"] == e["rays_this_rank"]
+        assert e["phases_ms"]["ray_gen_ms"] > 0 and e["cpu_harness"]["value"] > 0 and e["speedup_vs_cpu_harness"] > 0
+        assert e["roofline"]["kernel"].startswith("bvhgpu::k_traverse_wide<float, %d, " % (3 if e["harness"] == "closest" else 2))
+    assert modes == ["closest", "triangles"]
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["build_threads"] >= 1 and cb["build_ms"] <= cb["build_ms_serial"] * 1.05 and cb["value"] > 0
+
+
+@pytest.mark.parametrize("mode", ["closest", "triangles"])
+def test_harness_as_the_headline(mode):
+    """`bench.py --harness M`: the step is ray generation + build + flatten + walk + triangle stage (intersect_bh, testbase.rs:819-837); the line is
+    tagged so that its profile is looked up under its own workload name"""
+    out = _run(["--harness", mode, "--no-extra", "--no-cpu-baseline", "--pipeline-streams", "0"])
+    assert out["workload_name"] == "cubes120k+" + mode and out["harness"] == mode and out["value"] > 0
+    assert out["parity"]["equal"] is True and out["cpu_harness"]["value"] > 0
+    assert "intersect_bh" in out["config"]["workload"] and out["phases_ms"]["ray_gen_ms"] > 0
+    assert "step_excludes" not in out        # (those compare against the index step of `value`: not measured beside a harness headline)
