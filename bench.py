@@ -990,7 +990,8 @@ def main():
             if only:
                 plan = [plan[int(k)] for k in only.split(",")]
         else:
-            plan = [E("standin-incoherent", scaling="strong", rays=100_000_000)]
+            # (tests shrink the stream: BVH_BENCH_STRONG_RAYS; the driver's run keeps BASELINE's 100 M)
+            plan = [E("standin-incoherent", scaling="strong", rays=int(os.environ.get("BVH_BENCH_STRONG_RAYS", 100_000_000)))]
         # N > 1: the section's barriers and all-reduces are only safe while every rank gets through it — a rank that fails alone (its
         # `except` below skips the collectives) would leave the others waiting for ever, and the headline with them
         import contextlib
