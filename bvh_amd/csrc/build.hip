@@ -1084,18 +1084,26 @@ template <typename T, bool ROOT, bool DEV = false> __global__ __launch_bounds__(
                 a.node_slot[ni] = (uint16_t)heap;
                 if (heap < 16u) atomicOr(&a.ctr[CTR_TOPMASK], 1u << heap);
             }
-            // queue slots of the children that leave this tier: lanes 0 / 1 reserve them at the same time
+            // queue slots of the children that leave this tier: lanes 0 / 1 reserve them at the same time.  Only then — the tier's last one or
+            // two levels — does this wave wait for anything: the slot comes back from a returning atomic, and the wait for it is a wait for
+            // EVERYTHING the wave has in flight (the compiler can only count, s_waitcnt vmcnt(0)), the node record stored above included: with
+            // the wait on every level's path the first-tile workgroups spent 2.0 – 2.3 µs here against 0.7 for the others and were the last to
+            // finish every pass (tools/level_prof.py).  Children that stay in the tier need no slot: nothing to wait for.
             const uint32_t mykind = ch[lane & 1].kind;
-            uint32_t qslot = 0;
-            if (lane < 2) {
-                if (mykind == 0u) qslot = atomicAdd(&a.ctr[CTR_SMALL], 1u);
-                else if (mykind == 1u) qslot = atomicAdd(&a.ctr[CTR_MID2], 1u);
-                else atomicAdd(&a.ctr[CTR_LEVEL0 + 2 * lvl_slot(L)], 1u);   // the host only asks whether the level is empty
+            uint32_t cqs[2] = {0u, 0u};
+            if (ch[0].kind != 3u || ch[1].kind != 3u) {   // (wave-uniform)
+                uint32_t qslot = 0;
+                if (lane < 2) {
+                    if (mykind == 0u) qslot = atomicAdd(&a.ctr[CTR_SMALL], 1u);
+                    else if (mykind == 1u) qslot = atomicAdd(&a.ctr[CTR_MID2], 1u);
+                }
+                cqs[0] = __shfl(qslot, 0); cqs[1] = __shfl(qslot, 1);
             }
+            if (lane < 2 && mykind == 3u) atomicAdd(&a.ctr[CTR_LEVEL0 + 2 * lvl_slot(L)], 1u);   // the host only asks whether the level is empty
 #pragma unroll
             for (int side = 0; side < 2; side++) {
                 const LevelChild<T>& c = ch[side];
-                const uint32_t cq = __shfl(qslot, side);
+                const uint32_t cq = cqs[side];
                 Item<T>* it = c.kind == 0u ? &a.small[cq] : (c.kind == 1u ? &a.mid2[cq] : &v.item[L & 1][c.slot]);
                 if (lane == 0) {
                     stx<DEV>(&it->ni, side ? ri : li); stx<DEV>(&it->parent, ni); stx<DEV>(&it->start, c.start); stx<DEV>(&it->count, c.count);
@@ -1238,14 +1246,14 @@ template <typename T, bool ROOT, bool DEV = false> __global__ __launch_bounds__(
             }
         }
         LEVEL_STAMP(2);
-        __syncthreads();
+        lds_barrier();
         if (!ROOT && threadIdx.x < NUM_BUCKETS) {
             uint32_t r0 = 0;
 #pragma unroll
             for (int ww = 0; ww < LEVEL_THREADS / 64 - 1; ww++) r0 += wsum[ww][threadIdx.x];
             run0[threadIdx.x] = r0;
         }
-        if (!ROOT) __syncthreads();
+        if (!ROOT) lds_barrier();
         const uint32_t nl = sel.nl;
         // ---- the tile's shapes: stable bucket-major move (bvh_node.rs:250-272) + bucket / statistics for the next split
 #pragma unroll
@@ -1292,7 +1300,7 @@ template <typename T, bool ROOT, bool DEV = false> __global__ __launch_bounds__(
                 atomicAdd(&tcnt[rt][b][tgt][nb], 1u);
             }
         }
-        __syncthreads();
+        lds_barrier();
         LEVEL_STAMP(4);
         // ---- merge into the children's statistics (replica = this tile's number in P, like k_bin) and tile counts
         for (int e = threadIdx.x; e < 2 * NUM_BUCKETS * STAT_KEYS; e += LEVEL_THREADS) {
@@ -1327,7 +1335,7 @@ template <typename T, bool ROOT, bool DEV = false> __global__ __launch_bounds__(
         LEVEL_STAMP(5);
         if (!BVH_LEVEL_EARLY_DUTIES && !ROOT && tl == 0 && w == 0) tile0_duties(nl);
         LEVEL_STAMP(6);
-        __syncthreads();
+        lds_barrier();
     }
     if constexpr (!DEV) {
         break;
@@ -1517,7 +1525,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
         const uint32_t* gsrc = a.idx[it->parity];
         uint32_t* gdst = a.idx[it->parity ^ 1];   // where the <= 64-shape children's slices are left
         const uint32_t out_parity = it->parity ^ 1;
-        __syncthreads();  // previous item fully done with LDS
+        lds_barrier();  // previous item fully done with LDS
         for (uint32_t p = tid; p < (uint32_t)MAXN; p += MID_THREADS) {
             if (p < count) {
                 const uint32_t shp = gsrc[istart + p];
@@ -1538,7 +1546,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
             s_nsub = 1;
         }
         int cur = 0;
-        __syncthreads();
+        lds_barrier();
         uint32_t nsub = 1;
         while (nsub) {
             MID_T0();
@@ -1579,7 +1587,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
                 if (lane >= d) { ilo += ul; ihi += uh; }
             }
             if (lane == WAVE - 1) { s_wlo[wv] = ilo; s_whi[wv] = ihi; }
-            __syncthreads();
+            lds_barrier();
             MID_T(1);
             unsigned long long rlo = ilo - mine.lo; uint32_t rhi = ihi - mine.hi;
             for (int w2 = 0; w2 < wv; w2++) { rlo += s_wlo[w2]; rhi += s_whi[w2]; }
@@ -1595,7 +1603,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
                     if (p == m->start + m->count - 1) { m->scanE_lo = rlo; m->scanE_hi = rhi; }
                 }
             }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int j = 0; j < PPT; j++) {
                 if (sg[j] == SEG_NONE) continue;
@@ -1622,7 +1630,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
                 for (int k = 0; k < 6; k++) s_box[6 * dest + k] = bx[j][k];
                 s_idx[dest] = sid[j];
             }
-            __syncthreads();
+            lds_barrier();
             MID_T(2);
             // ---- phase 3: per-(sub-node, bucket) statistics over the sorted order (utils.rs:81-85).
             //      Joins run on floats (one v_min/v_max each, common.hpp join_min/join_max); only a finished run
@@ -1713,7 +1721,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
                 // (a multi-run next lane that continues our run took our value as its carry and flushed it)
                 if (cur_key >= 0 && (lane == WAVE - 1 || !next_cont)) flush(cur_key, sv);
             }
-            __syncthreads();
+            lds_barrier();
             MID_T(3);
             // ---- phase 4a: the SAH selections, one sub-node per wave at a time, each spread over the wave's lanes (lane s of wave 0
             //      running the serial form for sub-node s took 2.9 µs per level whatever the number of sub-nodes)
@@ -1728,7 +1736,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 sah_select_wave<T>(s_keys + sn * NUM_BUCKETS * STAT_KEYS, s_cin[sn], A, m->degen != 0, &s_sel[sn], s_sahscr[wv], lane);
             }
-            __syncthreads();
+            lds_barrier();
             MID_T(6);
             // ---- phase 4b: nodes and children (wave 0; lane s owns sub-node s)
             if (wv == 0) {
@@ -1813,7 +1821,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
                 }
                 if (lane == 0) s_nsub = (uint32_t)(__popcll(mL) + __popcll(mR));
             }
-            __syncthreads();
+            lds_barrier();
             MID_T(4);
             // ---- phase 5: positions follow their sub-node's child; slices of children that leave the
             //      workgroup (<= 64 shapes) are written to the global index buffer for the wave tier
@@ -1826,7 +1834,7 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
                 if (ch != NONE) s_seg[p] = (uint8_t)ch;
                 else { s_seg[p] = SEG_NONE; gdst[istart + p] = s_idx[p]; }
             }
-            __syncthreads();
+            lds_barrier();
             MID_T(5);
             cur ^= 1;
             nsub = s_nsub;

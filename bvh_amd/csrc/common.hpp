@@ -378,6 +378,22 @@ template <int LANE> __device__ __forceinline__ double lane_bcast(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+// Workgroup barrier for data that lives in LDS only.  __syncthreads() is fence + barrier: the fence makes every wave wait until ALL its
+// outstanding memory operations have been acknowledged — global stores included (s_waitcnt vmcnt(0)), ≈ 1.3 µs for a wave that has just
+// written node and item records (tools/level_prof.py: the selection → barrier phase of an item's first-tile workgroup took 2.0 – 2.3 µs
+// against 0.72 for the others, and all four waves of that workgroup waited for it).  Where nothing another wave of the workgroup reads has
+// gone through global memory, waiting for the LDS queue is enough: the stores drain behind the arithmetic that follows.
+// BVH_LDS_BARRIER = 0 (developer variant): __syncthreads() everywhere.
+#ifndef BVH_LDS_BARRIER
+#define BVH_LDS_BARRIER 1
+#endif
+__device__ __forceinline__ void lds_barrier() {
+#if BVH_LDS_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();
+#endif
+}
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     int l = lane_id();
     return l == 0 ? 0ull : (~0ull >> (64 - l));

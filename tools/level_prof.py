@@ -40,4 +40,13 @@ for which, p in enumerate(both):      # the profiled level and the one after it,
     print(f"--- level {'P' if which == 0 else 'P + 1'}: workgroups with a tile {len(live)}, without {len(idle)}")
     for i, nme in enumerate(names):
         col = us(live[:, i])
-        print(f"{nme:58s} mean {col.mean():7.2f}  min {col.min():7.2f}  max {col.max():7.2f} us")
+        print(f"{nme:58s} mean {col.mean():7.2f}  min {col.min():7.2f}  p50 {np.percentile(col, 50):7.2f}  p90 {np.percentile(col, 90):7.2f}  p99 {np.percentile(col, 99):7.2f}  max {col.max():7.2f} us")
+    # where the late workgroups lose their time: phase durations of the ten that end last against the median workgroup
+    order = [0, 1, 7, 3, 2, 4, 5, 6]          # stamps in the order they are taken
+    dur = np.diff(us(live[:, order]), axis=1)
+    med = np.median(dur, axis=0)
+    slow = np.argsort(live[:, 6])[-10:][::-1]
+    print("phase durations (entry→tile record→statistics→selection→ranks→shapes→flush→end), median workgroup: " + " ".join(f"{x:5.2f}" for x in med))
+    for k in slow:
+        wg = int(np.nonzero((p[:, 6] == live[k, 6]) & (p[:, 0] == live[k, 0]))[0][0])
+        print(f"   workgroup {wg:4d} ends {us(live[k, 6]):6.2f}: " + " ".join(f"{x:5.2f}" for x in dur[k]))
