@@ -274,6 +274,34 @@ def test_persistent_level_tier_same_tree(eng, orc, groups_of, dtype):
         off, idx = h.fetch(len(rays))
         assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
     assert bvh.flatten().nodes.tobytes() == oflat.tobytes()
+    # a subtree deeper than the tier's counter slots (f64 only: 1.02^i over 30 000 shapes needs the exponent range; every split peels ≈ 90
+    # shapes off the chain, well over a hundred levels with more than 768 shapes): the persistent launch gives up (BUILD_FLAG_PERSIST_GAVE_UP),
+    # build_finalize builds the same generation again with a launch per level — same arrays, and the tree object stays with that schedule;
+    # an asynchronous batch enqueued on the abandoned build is replayed on the finished tree
+    if dtype == np.float64:
+        m = 30000
+        xs = np.float64(1.02) ** np.arange(m, dtype=np.float64)
+        lo = np.stack([xs, np.zeros(m), np.zeros(m)], axis=1)
+        deep = np.concatenate([lo, lo + 0.5], axis=1)
+        ot = orc.build(deep, threads=orc.max_threads(), schedule="fast")
+        deep_tree = Bvh.from_aabbs(deep, ctx)
+        assert deep_tree.nodes.tobytes() == ot.nodes.tobytes() and np.array_equal(deep_tree.shape_nodes, ot.shape_node)
+        assert deep_tree.build_levels > 92
+        oflat = orc.flatten(ot.nodes)
+        o = np.stack([xs[::3] + 0.25, np.full(len(xs[::3]), 0.25), np.full(len(xs[::3]), -3.0)], axis=1)
+        rays_d = orc.make_rays(np.concatenate([o, o]), np.tile(np.array([[0.0, 0.0, 1.0]]), (2 * len(o), 1)), np.float64)
+        ooff, oidx, _, _ = orc.traverse_flat(oflat, deep, rays_d, threads=orc.max_threads())
+        fresh = Bvh.from_aabbs(scenes[1], ctx)          # (a tree object that has not given up yet: the asynchronous rebuild below does)
+        dev_d = torch.from_numpy(deep).cuda()
+        dev_rd = torch.from_numpy(rays_d.view(np.uint8).reshape(-1)).cuda()
+        rbd = RayBatch.from_device(dev_rd, len(rays_d), np.float64)
+        for _ in range(2):
+            fresh.rebuild_async(dev_d)
+            h = fresh.traverse_async(rbd)
+            h.wait()
+            off, idx = h.fetch(len(rays_d))
+            assert np.array_equal(off, ooff) and np.array_equal(idx, oidx) and len(idx) > 0
+        assert fresh.nodes.tobytes() == ot.nodes.tobytes()
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
