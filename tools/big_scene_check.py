@@ -7,7 +7,7 @@ n_cubes = int(sys.argv[1])
 t0 = time.time(); _, aabbs = tb.create_n_cubes(n_cubes); print("gen", time.time() - t0, len(aabbs))
 t0 = time.time(); bvh = eng.Bvh.from_aabbs(aabbs); bvh.ctx.synchronize(); print("gpu build (incl upload)", time.time() - t0, "levels", bvh.build_levels)
 t0 = time.time(); bvh.rebuild(aabbs); print("gpu rebuild (incl upload)", time.time() - t0)
-t0 = time.time(); ot = orc.build(aabbs, threads=8); print("oracle build", time.time() - t0)
+t0 = time.time(); ot = orc.build(aabbs, threads=orc.max_threads(), schedule="fast"); print("oracle build", time.time() - t0)
 print("nodes identical:", bvh.nodes.tobytes() == ot.nodes.tobytes())
 flat = bvh.flatten(); oflat = orc.flatten(ot.nodes)
 print("flat identical:", flat.nodes.tobytes() == oflat.tobytes())
