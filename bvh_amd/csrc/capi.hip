@@ -968,7 +968,7 @@ void bvhgpu_hits_destroy(bvhgpu_hits* h) {
     detach_waiter(h);   // an asynchronous batch that is never waited for: its tree forgets it
     h->counts.release(); h->offsets.release(); h->pool.release(); h->pool_t.release();
     h->indices.release(); h->tslice.release(); h->blocksums.release(); h->scan_sums.release(); h->ctr.release();
-    h->isect.release(); h->closest.release(); h->closest_prim.release();
+    h->isect.release(); h->closest.release(); h->closest_prim.release(); h->closest_key.release();
     h->heap_dist.release(); h->heap_node.release();
     h->wg_items.release(); h->raybuf.release();
     if (h->ev_items) (void)hipEventDestroy(h->ev_items);

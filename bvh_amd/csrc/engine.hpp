@@ -151,6 +151,8 @@ struct bvhgpu_hits {
     bvhgpu::DevBuf isect;    // total * 3 T: Intersection{distance,u,v} per candidate (TRIANGLES)
     bvhgpu::DevBuf closest;  // n_rays * 3 T (CLOSEST)
     bvhgpu::DevBuf closest_prim;  // n_rays u32
+    bvhgpu::DevBuf closest_key;   // n_rays u64: CLOSEST batches walked as items (traverse.hip WalkOut::closest_key), all-ones between batches
+    bool ckey_clean = false;
     bvhgpu::DevBuf blocksums;
     bvhgpu::DevBuf scan_sums;    // wide walk: two sets of hits per scan block (k_scan_final's input instead of a reduce pass), kept zero
     bvhgpu::DevBuf ctr;      // [0] pool count (u64) [1] visited [2] leaf_visits [3] device_steps [4] ray ticket

@@ -71,6 +71,8 @@ template <typename T> struct WalkOut {
     const T* tris;               // n x 9 vertices (triangle modes)
     T* closest;                  // per ray {distance,u,v} (closest mode)
     uint32_t* closest_prim;      // per ray shape index or NONE
+    unsigned long long* closest_key;   // closest mode with rays cut into items (f32): per ray min over its items of {key(distance) << 32 | item << 28 | shape}
+                                 // (kept all-ones between batches; k_closest_resolve turns the winner into closest / closest_prim).  NULL: one lane owns the ray
     uint32_t* item_cnt;          // wide walk with several items per ray: hits of item (ray, j), written only when non-zero
     uint32_t* ray_items;         // ... and per ray the set of j that wrote one (kept all-zero between batches like counts)
     uint32_t* scan_sums;         // wide walk: hits per SCAN_BLOCK rays, added up by the workgroups as they finish (a zeroed set; NULL: k_scan_reduce does the sums)
@@ -1055,7 +1057,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     static_assert(GUIDE == 0 || (MODE == MODE_INDICES && sizeof(T) == 4), "the guide walk is the f32 index walk");
     static_assert(ITEMS_LOG4 >= 0 && ITEMS_LOG4 <= 2, "1, 4 or 16 items per ray");
     static_assert(MODE != MODE_T_SLICE, "the t-slice output walks the binary array");
-    static_assert(MODE != MODE_CLOSEST || ITEMS_LOG4 == 0, "closest hit: one lane owns the ray");
+    static_assert(MODE != MODE_CLOSEST || ITEMS_LOG4 == 0 || sizeof(T) == 4, "closest hit over items: the per-ray key packs a 32-bit distance");
     constexpr int CH = WideIo<T>::CHUNKS;
     constexpr int L4 = ITEMS_LOG4 > 0 ? ITEMS_LOG4 : 1;      // (so that the item code compiles when it is not used)
     constexpr uint32_t ITEMS = 1u << (2 * L4);
@@ -1169,9 +1171,20 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                 report_pair(false, !run && item != NONE, 0u, ray, pair_pend, w.pool_pair, w.pool_cap, w.ctr, pc, lane, lt);
             if (!run && item != NONE) {   // the item has left the tree: its part of the ray's list is complete
                 if (MODE == MODE_CLOSEST) {
-                    const size_t r = item;
-                    w.closest[3 * r] = ray.best[0]; w.closest[3 * r + 1] = ray.best[1]; w.closest[3 * r + 2] = ray.best[2];
-                    w.closest_prim[r] = ray.best_prim;
+                    if constexpr (ITEMS_LOG4 == 0) {
+                        const size_t r = item;
+                        w.closest[3 * r] = ray.best[0]; w.closest[3 * r + 1] = ray.best[1]; w.closest[3 * r + 2] = ray.best[2];
+                        w.closest_prim[r] = ray.best_prim;
+                    } else if (ray.best_prim != NONE) {
+                        // The ray's other items sit in other lanes: the nearest candidate of the RAY is the minimum over its items of (distance, item
+                        // number) — items are the tree-level-4 subtrees in pre-order, so on equal distances the lower item holds the candidate the
+                        // reference's loop meets first (strict <, testbase.rs:831-833 behind flat_bvh.rs:408), and inside an item this lane kept the
+                        // first one.  Distance (monotone key), item and shape (< 2^28: WIDE_MAX_SHAPES) fit one 64-bit word: one atomicMin.
+                        const uint32_t j = item & ((1u << WIDE_ITEM_BITS) - 1u);
+                        const uint32_t jj = j == WIDE_ITEM_WHOLE ? 0u : j;
+                        const unsigned long long key = ((unsigned long long)Traits<T>::key(ray.best[0]) << 32) | ((unsigned long long)jj << 28) | (unsigned long long)ray.best_prim;
+                        atomicMin(&w.closest_key[item >> WIDE_ITEM_BITS], key);
+                    }
                 } else if (ray.cnt) {
                     uint32_t r = item;
                     if (ITEMS_LOG4 == 0) {
@@ -1674,6 +1687,29 @@ static void launch_walk(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
                        t->slot_entry.as<uint32_t>(), K, first_slot, split_at, rays_dev, (uint32_t)n_items, rpg, w);
 }
 
+// Closest hit of rays that were walked as items (WalkOut::closest_key): the winner's shape comes out of the key, its Intersection is computed
+// again from the ray and the triangle — the same function on the same operands as in the walk, hence the same bits (ray_impl.rs:154-213) —
+// and the key goes back to all-ones for the next batch.  Rays no item of which met a triangle get {+inf, 0, 0} / NONE (testbase.rs:826-836:
+// nothing intersected).
+template <typename T>
+__global__ __launch_bounds__(256) void k_closest_resolve(unsigned long long* __restrict__ key, const typename Traits<T>::Ray* __restrict__ rays,
+                                                         const T* __restrict__ tris, uint32_t n_rays, T* __restrict__ closest, uint32_t* __restrict__ closest_prim) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const unsigned long long k = key[r];
+    T out[3] = {Traits<T>::inf(), 0, 0};
+    uint32_t prim = NONE;
+    if (k != ~0ull) {
+        prim = (uint32_t)(k & 0x0FFFFFFFull);
+        const typename Traits<T>::Ray* rp = rays + r;
+        const T o[3] = {rp->o[0], rp->o[1], rp->o[2]}, d[3] = {rp->d[0], rp->d[1], rp->d[2]};
+        ray_triangle<T>(o, d, tris + 9 * (size_t)prim, out);
+        key[r] = ~0ull;
+    }
+    closest[3 * (size_t)r] = out[0]; closest[3 * (size_t)r + 1] = out[1]; closest[3 * (size_t)r + 2] = out[2];
+    closest_prim[r] = prim;
+}
+
 // ---- wide walk launch ------------------------------------------------------------------------
 // Workgroup geometry: `wg_per_cu` workgroups of `threads` share a CU's 160 KB of LDS; each keeps the per-lane stack
 // (stack_lds entries x threads x 4 B) and as many top-of-tree wide nodes as fit in the rest.
@@ -1787,6 +1823,11 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         const int want = ctx->tune[BVHGPU_TUNE_WIDE_ITEMS_LOG4];
         items_log4 = want >= 0 ? std::min(want, 2) : (few_rays ? 2 : 0);
     }
+    // closest hit (f32): the same cut into 16 items below ~2 M rays — the per-ray minimum over the items goes through WalkOut::closest_key
+    if (use_wide && mode == MODE_CLOSEST && sizeof(T) == 4 && n_rays < WIDE_ITEM_MAX_RAYS) {
+        const int want = ctx->tune[BVHGPU_TUNE_WIDE_ITEMS_LOG4];
+        items_log4 = (want >= 0 ? want >= 2 : few_rays) ? 2 : 0;
+    }
     // the item filter beside the build (launch_wide): the tree is being rebuilt on this stream, the build has recorded the event behind
     // the pass that splits level 3, and the caller says that the rays do not depend on anything enqueued since
     const bool early_items = use_wide && items_log4 == 2 && (flags & BVHGPU_TRAVERSE_RAYS_READY) != 0 && t->pending_build && t->ev_top != nullptr &&
@@ -1821,7 +1862,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
 
     WalkOut<T> w;
     w.counts = nullptr; w.pool = nullptr; w.pool_v = nullptr; w.pool_cap = 0; w.ctr = ctr;
-    w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr; w.item_cnt = nullptr; w.ray_items = nullptr; w.scan_sums = nullptr;
+    w.tris = t->tris.as<T>(); w.closest = nullptr; w.closest_prim = nullptr; w.closest_key = nullptr; w.item_cnt = nullptr; w.ray_items = nullptr; w.scan_sums = nullptr;
     w.raybuf = nullptr; w.stage_shift = 0; w.pool_pair = nullptr;
 
     uint32_t* ovf_flag = reinterpret_cast<uint32_t*>(ctr + 7);   // bit 0 ordered-iterator stack, bit 1 heap workspace, bit 2 wide-walk stack
@@ -1855,7 +1896,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
                 const bvhgpu_ray_f32* r32 = nullptr;   // (the guide walk converts every f64 ray where it loads it: no f32 copy of the batch)
                 WalkOut<float> wg;   // the same outputs: an index batch touches none of the T-typed ones
                 wg.counts = w.counts; wg.pool = w.pool; wg.pool_v = nullptr; wg.pool_cap = w.pool_cap; wg.ctr = w.ctr; wg.tris = nullptr;
-                wg.closest = nullptr; wg.closest_prim = nullptr; wg.item_cnt = w.item_cnt; wg.ray_items = w.ray_items; wg.scan_sums = w.scan_sums;
+                wg.closest = nullptr; wg.closest_prim = nullptr; wg.closest_key = nullptr; wg.item_cnt = w.item_cnt; wg.ray_items = w.ray_items; wg.scan_sums = w.scan_sums;
                 wg.pool_pair = w.pool_pair; wg.raybuf = w.raybuf; wg.stage_shift = w.stage_shift;
                 const GuideArgs ga{reinterpret_cast<const bvhgpu_ray_f64*>(rays_dev), t->aabbs.as<double>(), t->guide_info.as<float>()};
                 if (items_log4 == 2) launch_wide<float, MODE_INDICES, 2, 1>(t, r32, n_rays, wg, h, ovf_flag, false, ga);
@@ -1866,6 +1907,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         }
         if (M != MODE_CLOSEST && items_log4 == 2) launch_wide<T, M, (M == MODE_CLOSEST ? 0 : 2)>(t, rays_dev, n_rays, w, h, ovf_flag, early_items);
         else if (M != MODE_CLOSEST && items_log4 == 1) launch_wide<T, M, (M == MODE_CLOSEST ? 0 : 1)>(t, rays_dev, n_rays, w, h, ovf_flag, false);
+        else if (M == MODE_CLOSEST && sizeof(T) == 4 && items_log4 == 2) launch_wide<T, M, ((M == MODE_CLOSEST && sizeof(T) == 4) ? 2 : 0)>(t, rays_dev, n_rays, w, h, ovf_flag, false);
         else launch_wide<T, M, 0>(t, rays_dev, n_rays, w, h, ovf_flag, false);
     };
 #define DISPATCH_WALK_INNER()                                                                        \
@@ -1906,9 +1948,20 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         h->closest_prim.reserve(std::max<size_t>(n_rays, 1) * 4);
         if (n_rays == 0) { h->pend_tree = nullptr; return; }
         w.closest = h->closest.as<T>(); w.closest_prim = h->closest_prim.as<uint32_t>();
+        const bool by_items = use_wide && items_log4 == 2;   // (f32 only, see above)
+        if (by_items) {   // the per-ray keys: all-ones between batches (k_closest_resolve puts them back)
+            if (h->closest_key.reserve(n_rays * sizeof(unsigned long long))) h->ckey_clean = false;
+            if (!h->ckey_clean) BVH_HIP(hipMemsetAsync(h->closest_key.p, 0xFF, h->closest_key.cap, st));
+            h->ckey_clean = true;
+            w.closest_key = h->closest_key.as<unsigned long long>();
+        }
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
         DISPATCH_WALK();
-        if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[5], st)); BVH_HIP(hipEventRecord(ctx->ev[6], st)); }
+        if (ctx->timing) BVH_HIP(hipEventRecord(ctx->ev[5], st));
+        if (by_items)
+            hipLaunchKernelGGL(k_closest_resolve<T>, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, w.closest_key, rays_dev, t->tris.as<T>(),
+                               (uint32_t)n_rays, w.closest, w.closest_prim);
+        if (ctx->timing) BVH_HIP(hipEventRecord(ctx->ev[6], st));
         hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);   // readback + reset for the next call
         h->ctr_clean = true;
         return;
@@ -2070,7 +2123,7 @@ bool traverse_check(bvhgpu_hits* h) {
         h->no_guide = true; h->wcounts_clean = false; return false;   // (the replay of this batch walks in f64; traverse_enqueue sets the back-off)
     }
     if (h->pend_wide && (pin[7] & 4ull)) {   // a lane's stack outgrew LDS + workspace: the binary walks need no stack
-        h->force_binary = true; h->wcounts_clean = false; h->bs_clean = false; h->ray_items.release(); return false;
+        h->force_binary = true; h->wcounts_clean = false; h->bs_clean = false; h->ckey_clean = false; h->ray_items.release(); return false;
     }
     if (flags & BVHGPU_TRAVERSE_CLOSEST) {
         if (stats) {

@@ -724,6 +724,41 @@ def test_triangle_stage_matches_reference_loop(eng, orc, variant, dtype):
     assert st2["hits"] == ost["hits"] and st2["visited"] == ost["visited"]
     hit = np.isfinite(oclosest[:, 0])
     assert hit.sum() > n // 2 and (~hit).sum() > n // 20               # both outcomes are exercised
+    # the same batch without STATS: the default walk of a batch this size — for f32 closest hits the wide walk over 16 items per ray, the ray's
+    # nearest candidate taken as a minimum over its items (WalkOut::closest_key + k_closest_resolve)
+    ctx3 = Context(0)                                                    # default tuning: the wide walk for batches of 16 384 rays and more
+    flat3 = eng.Bvh.from_aabbs(aabbs, ctx3).flatten()
+    flat3.set_triangles(tris)
+    cl2, prim2, st3 = flat3.closest_hits(_rb(eng, rays))
+    assert cl2.tobytes() == oclosest.tobytes() and np.array_equal(prim2, oprim)
+    assert flat3._hits.walk_kernel().startswith("bvhgpu::k_traverse_wide<%s, 3, %d," % ("float" if dtype == np.float32 else "double", 2 if dtype == np.float32 else 0))
+    # ... and where the minimum is not unique: pairs of overlapping coplanar triangles (planes z = const, a ray along +z meets both at exactly
+    # the same distance) whose centroids lie far apart, so that they sit in different subtrees — different ITEMS of the ray.  The reference keeps
+    # the candidate its loop meets first (strict <, testbase.rs:831-833): the key's item number must reproduce that order.
+    planes = np.arange(-400, 401, 50, dtype=np.float64)
+    big = []
+    for z in planes:
+        big.append([[-2000.0, -600.0, z], [300.0, -600.0, z], [-400.0, 1200.0, z]])   # centroid x = -700
+        big.append([[-300.0, -600.0, z], [2000.0, -600.0, z], [400.0, 1200.0, z]])    # centroid x = +700: the root's split parts them; they overlap around x = 0
+    big = np.array(big)
+    tris_t = np.concatenate([tris.reshape(-1, 3, 3), big.astype(dtype)]).astype(dtype)
+    aabbs_t = np.concatenate([tris_t.min(axis=1), tris_t.max(axis=1)], axis=1).astype(dtype)
+    m = 30000
+    ot_ = rng.uniform(-150, 150, size=(m, 3)); ot_[:, 2] = rng.choice(np.concatenate([planes - 25.0, [-1000.0]]), size=m)
+    dt_ = np.tile(np.array([[0.0, 0.0, 1.0]]), (m, 1)); dt_[m // 2:] *= -1.0          # half of them look down: the order of the planes flips
+    rays_t = orc.make_rays(ot_.astype(dtype), dt_.astype(dtype), dtype)
+    flat_t = eng.Bvh.from_aabbs(aabbs_t, ctx3).flatten()
+    flat_t.set_triangles(tris_t)
+    oflat_t = orc.flatten(orc.build(aabbs_t).nodes)
+    toff, tidx, _, _ = orc.traverse_flat(oflat_t, aabbs_t, rays_t, threads=orc.max_threads())
+    tisect, tclosest, tprim = orc.triangle_stage(tris_t, rays_t, toff, tidx)
+    d_all = tisect[:, 0]
+    ties = sum(1 for r in range(0, m, 7) if np.isfinite(tclosest[r, 0]) and (d_all[toff[r]:toff[r + 1]] == tclosest[r, 0]).sum() > 1)
+    assert ties > 300, ties                                              # the scene does produce equal nearest distances (every one of them across subtrees)
+    cl3, prim3, _ = flat_t.closest_hits(_rb(eng, rays_t))
+    assert cl3.tobytes() == tclosest.tobytes() and np.array_equal(prim3, tprim)
+    cl4, prim4, _ = flat_t.closest_hits(_rb(eng, rays_t), stats=True)    # (the binary walk: one lane owns the ray)
+    assert cl4.tobytes() == tclosest.tobytes() and np.array_equal(prim4, tprim)
     # flags that cannot be combined / missing triangles fail loudly
     bare = eng.Bvh.from_aabbs(aabbs, ctx).flatten()
     with pytest.raises(eng.BvhGpuError):
