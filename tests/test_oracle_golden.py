@@ -509,3 +509,33 @@ def test_distance_iterator_restatements_agree_and_match_reference_tests():
         for i in range(len(r64)):
             assert pyref.traverse_distance(t64.nodes, ab.astype(np.float64), (r64[i]["o"], r64[i]["d"], r64[i]["inv"]), asc) == \
                 idx[off[i]:off[i + 1]].tolist()
+
+
+def test_harness_loop_equals_the_staged_restatement():
+    """orc.harness_loop (bench.py's CPU figure beside the harness entries) is intersect_bh written out whole — create_ray (or a primary ray),
+    FlatBvh::traverse into a growable list, intersects_triangle on every candidate (testbase.rs:819-837).  It must agree with the pieces the
+    parity legs use: the same candidates in total as traverse_flat finds on the generator's rays, and the same checksum — sum of the candidates'
+    shape indices + the number of finite distances — as triangle_stage computes on that CSR.  Any team size, any start of the stream."""
+    tris, aabbs = orc.create_n_cubes(400)
+    flat = orc.flatten(orc.build(aabbs).nodes)
+    bounds = orc.DEFAULT_BOUNDS
+    for first, n in ((0, 4000), (4321, 2500)):
+        rays = orc.create_rays(first, n, bounds)
+        off, idx, _, st = orc.traverse_flat(flat, aabbs, rays)
+        isect, _, _ = orc.triangle_stage(tris, rays, off, idx)
+        want = int(idx.astype(np.uint64).sum() + np.isfinite(isect[:, 0]).sum())
+        for th in (1, 3):
+            total, ck = orc.harness_loop(flat, aabbs, tris, first, n, bounds, threads=th)
+            assert total == st["hits"] == len(idx) and ck == want
+    # primary rays of a camera (configs[2]'s generator): the 21 aligned unit boxes (testbase.rs:109-116), one triangle across each
+    boxes = orc.aligned_boxes()
+    tris = np.stack([boxes[:, :3], boxes[:, 3:], np.stack([boxes[:, 3], boxes[:, 1], boxes[:, 2]], axis=1)], axis=1).astype(np.float32)   # (wound to face the camera: ray_impl.rs:186 culls the other side)
+    flat = orc.flatten(orc.build(boxes).nodes)
+    cam = np.array([0.0, 0.0, -12.0, 1, 0, 0, 0, 1, 0, 0, 0, 1, 1.0, 0.1], dtype=np.float32)
+    W, H = 128, 32
+    rays = orc.primary_rays(cam, W, H, 50, 4000)
+    off, idx, _, st = orc.traverse_flat(flat, boxes, rays)
+    isect, _, _ = orc.triangle_stage(tris, rays, off, idx)
+    total, ck = orc.harness_loop(flat, boxes, tris, 50, 4000, bounds, cam=cam, width=W, height=H, threads=2)
+    assert total == len(idx) and ck == int(idx.astype(np.uint64).sum() + np.isfinite(isect[:, 0]).sum())
+    assert total > 1000 and np.isfinite(isect[:, 0]).sum() > 100
