@@ -6,8 +6,8 @@ api (mirror of the reference's Bounded / BHShape / BoundingHierarchy / Bvh / Fla
 and testbase (the reference's scene and ray generators, used as synthetic inputs).
 """
 from ._lib import BvhGpuError, NONE, device_count  # noqa: F401
-from .api import (Aabb, BHShape, Bounded, Bvh, Context, FlatBvh, Ray, RayBatch,  # noqa: F401
-                  default_context)
+from .api import (Aabb, BHShape, Bounded, Bvh, Context, FlatBvh, HostStep, Ray, RayBatch,  # noqa: F401
+                  default_context, pinned_array)
 
-__all__ = ["Aabb", "BHShape", "Bounded", "Bvh", "Context", "FlatBvh", "Ray", "RayBatch", "BvhGpuError",
+__all__ = ["Aabb", "BHShape", "Bounded", "Bvh", "Context", "FlatBvh", "HostStep", "pinned_array", "Ray", "RayBatch", "BvhGpuError",
            "NONE", "device_count", "default_context"]

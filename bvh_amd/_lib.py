@@ -75,6 +75,10 @@ SYMBOLS = [
     ("bvhgpu_device_alloc", _i, [_vp, _sz, _pp]),
     ("bvhgpu_device_free", _i, [_vp, _vp]),
     ("bvhgpu_device_copy", _i, [_vp, _vp, _i, _vp, _i, _sz]),
+    ("bvhgpu_host_alloc", _i, [_vp, _sz, _pp]),
+    ("bvhgpu_host_free", _i, [_vp, _vp]),
+    ("bvhgpu_host_register", _i, [_vp, _vp, _sz]),
+    ("bvhgpu_host_unregister", _i, [_vp, _vp]),
     ("bvhgpu_build_f32", _i, [_vp, _vp, _sz, _i, _pp]),
     ("bvhgpu_build_f64", _i, [_vp, _vp, _sz, _i, _pp]),
     ("bvhgpu_rebuild_f32", _i, [_vp, _vp, _sz, _i]),
@@ -123,6 +127,11 @@ SYMBOLS = [
     ("bvhgpu_ray_triangle_pairs_f64", _i, [_vp, _vp, _vp, _sz, _i, _vp]),
     ("bvhgpu_traverse_f32", _i, [_vp, _vp, _sz, _i, _u, _pp]),
     ("bvhgpu_traverse_f64", _i, [_vp, _vp, _sz, _i, _u, _pp]),
+    ("bvhgpu_traverse_host_f32", _i, [_vp, _vp, _vp, _sz, _u, _vp, _vp, _sz, C.POINTER(C.c_uint64)]),
+    ("bvhgpu_traverse_host_f64", _i, [_vp, _vp, _vp, _sz, _u, _vp, _vp, _sz, C.POINTER(C.c_uint64)]),
+    ("bvhgpu_traverse_host_indices", _i, [_vp, _vp, _sz]),
+    ("bvhgpu_build_traverse_host_f32", _i, [_vp, _vp, _sz, _vp, _vp, _sz, _u, _vp, _vp, _sz, C.POINTER(C.c_uint64)]),
+    ("bvhgpu_build_traverse_host_f64", _i, [_vp, _vp, _sz, _vp, _vp, _sz, _u, _vp, _vp, _sz, C.POINTER(C.c_uint64)]),
     ("bvhgpu_tree_set_triangles_f32", _i, [_vp, _vp, _sz, _i]),
     ("bvhgpu_tree_set_triangles_f64", _i, [_vp, _vp, _sz, _i]),
     ("bvhgpu_hits_fetch_triangles", _i, [_vp, _vp, _i]),
@@ -151,9 +160,12 @@ TUNE_WIDE_REC8 = 13              # wide walk, whole rays, indices only: pair rec
 TUNE_BUILD_LEVEL_LAUNCHES = 10   # builder, level tier: 1 one launch per level, 2 k_bin + k_split per level, 0 (default) by scene size
 TUNE_WIDE_F64_GUIDE = 14        # wide walk, f64 trees, indices only: walk the f32 guide boxes, test leaf candidates in f64 (1, default) or the f64 walk (0)
 TUNE_FLATTEN_LAZY = 15           # the flatten behind a build writes the wide walk's arrays; FlatNode / binary arrays follow on first use (1, default) or at once (0)
+TUNE_WIDE_MIN_RAYS_PER_WG = 18   # wide walk over items, batches below 512 K rays: spread over all workgroup slots down to this many rays each (256 default, 0 off)
+TUNE_HOST_ZERO_COPY = 19         # host batches on pinned buffers: bit 0 the device reads the ray arrays itself, bit 1 it writes offsets / indices itself (2 default)
+TUNE_HOST_CHUNKS = 17            # bvhgpu_traverse_host_*: chunks the batch is walked in (0, default = by batch size)
 TUNE_BUILD_LEVEL_PERSIST = 16    # builder, level tier: tree levels 3.. of the tier as ONE persistent launch, one level-3 subtree per XCD (1) or a launch per level (0)
 WALK_WIDE, WALK_STAGED, WALK_REC8, WALK_F64_GUIDE = 1, 2, 4, 8   # bvhgpu_hits_walk_info
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 

@@ -137,6 +137,60 @@ class Context:
 _default_ctx: Optional[Context] = None
 
 
+class PinnedArray(np.ndarray):
+    """numpy view of pinned host memory (bvhgpu_host_alloc): the DMA engines read and write it directly"""
+    _bvhgpu_pinned = True
+
+
+def pinned_array(ctx: "Context", shape, dtype) -> np.ndarray:
+    """an uninitialised array in pinned host memory; freed (bvhgpu_host_free) when the last view of it is gone"""
+    lib = _lib.load()
+    dt = np.dtype(dtype)
+    nbytes = int(np.prod(shape)) * dt.itemsize
+    p = C.c_void_p()
+    check(lib.bvhgpu_host_alloc(ctx._h, max(nbytes, 1), C.byref(p)), ctx._h)
+    buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+    ctx._child_add()
+
+    def release(addr=p.value, c=ctx):
+        if not _closing and getattr(c, "_h", None):
+            lib.bvhgpu_host_free(c._h, C.c_void_p(addr))
+        c._child_drop()
+    weakref.finalize(buf, release)
+    a = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape).view(PinnedArray)
+    return a
+
+
+class HostStep:
+    """What a host-resident caller of the drop-in boundary does per frame, with everything in pinned memory: shapes' AABBs, ray origins
+    and directions in; CSR offsets / indices out.  run() = GpuBvh::build + traverse_batch of the Rust shim in one call
+    (bvhgpu_build_traverse_host_*): the ray upload overlaps the build, Ray::new runs on the device."""
+
+    def __init__(self, bvh: "Bvh", n_shapes: int, n_rays: int, dtype=np.float32, index_cap: Optional[int] = None):
+        self.bvh, ctx = bvh, bvh.ctx
+        self.aabbs = pinned_array(ctx, (n_shapes, 6), dtype)
+        self.origins = pinned_array(ctx, (n_rays, 3), dtype)
+        self.directions = pinned_array(ctx, (n_rays, 3), dtype)
+        self.offsets = pinned_array(ctx, (n_rays + 1,), np.uint32)
+        self.indices = pinned_array(ctx, (index_cap or max(n_rays, 1 << 16),), np.uint32)
+        self.total = 0
+
+    def run(self, coherent: bool = False, fused: bool = True):
+        """fused: bvhgpu_build_traverse_host_* (one call, the ray upload enqueued before the build); else the two calls
+        bvhgpu_rebuild_flat_async_*(HOST) + bvhgpu_traverse_host_*"""
+        if not fused:
+            self.bvh.rebuild_async(self.aabbs)
+        self.total = self.bvh.traverse_host(self.origins, self.directions, self.offsets, self.indices, coherent=coherent,
+                                            aabbs=self.aabbs if fused else None)
+        if self.total > self.indices.size:
+            self.indices = pinned_array(self.bvh.ctx, (self.total + self.total // 8,), np.uint32)
+            self.bvh.traverse_host_indices(self.indices)
+        return self.offsets, self.indices[:self.total]
+
+    def close(self):
+        self.aabbs = self.origins = self.directions = self.offsets = self.indices = None
+
+
 def default_context() -> Context:
     global _default_ctx
     if _default_ctx is None:
@@ -675,13 +729,44 @@ class Bvh(_TreeBase):
         return self
 
     def rebuild_async(self, aabbs) -> "Bvh":
-        """bvhgpu_rebuild_flat_async_*: FlatBvh::build enqueued on the context's stream, no wait (`aabbs`: a GPU tensor that
-        stays valid until wait()).  Everything that looks at the tree afterwards completes the build first."""
+        """bvhgpu_rebuild_flat_async_*: FlatBvh::build enqueued on the context's stream, no wait (`aabbs`: a GPU tensor, or a
+        PinnedArray — either stays valid until wait()).  Everything that looks at the tree afterwards completes the build first."""
         fn = getattr(_lib.load(), f"bvhgpu_rebuild_flat_async_{self.sfx}")
+        if isinstance(aabbs, np.ndarray) and getattr(aabbs, "_bvhgpu_pinned", False):
+            check(fn(self._t, ptr(aabbs), aabbs.size // 6, HOST), self.ctx._h)
+            return self
         if not _is_device_tensor(aabbs):
-            raise BvhGpuError(_lib.INVALID_ARG, "rebuild_async takes shape AABBs that are resident in HBM")
+            raise BvhGpuError(_lib.INVALID_ARG, "rebuild_async takes shape AABBs that are resident in HBM (or in pinned host memory: pinned_array)")
         check(fn(self._t, ptr(aabbs.data_ptr()), aabbs.numel() // 6, DEVICE), self.ctx._h)
         return self
+
+    def traverse_host(self, origins, directions, offsets: np.ndarray, indices: np.ndarray, coherent: bool = False, aabbs=None) -> int:
+        """bvhgpu_traverse_host_*: `for (o, d) in rays { flat.traverse(&Ray::new(o, d), shapes) }` for rays in host memory (n x 3 each;
+        directions None: `origins` is an array of Ray structs), CSR written into the caller's `offsets` (n + 1) / `indices`; returns the
+        hit total (indices are written when they fit: fetch with traverse_host_indices otherwise).  The tree may still be building.
+        aabbs (host array, n x 6): bvhgpu_build_traverse_host_* — the tree is rebuilt from them first, underneath the ray upload."""
+        lib = _lib.load()
+        ft = np.float32 if self.sfx == "f32" else np.float64
+        if directions is None:
+            assert origins.dtype == _ray_dtype(self.sfx) and origins.flags.c_contiguous
+            n = len(origins)
+        else:
+            assert origins.dtype == ft and directions.dtype == ft and origins.flags.c_contiguous and directions.flags.c_contiguous
+            n = origins.size // 3
+            assert directions.size == 3 * n
+        assert offsets.dtype == np.uint32 and offsets.size >= n + 1 and indices.dtype == np.uint32
+        total = C.c_uint64(0)
+        tail = (ptr(origins), ptr(directions) if directions is not None else None, n, TRAVERSE_COHERENT if coherent else 0,
+                ptr(offsets), ptr(indices), indices.size, C.byref(total))
+        if aabbs is not None:
+            assert aabbs.dtype == ft and aabbs.flags.c_contiguous
+            check(getattr(lib, f"bvhgpu_build_traverse_host_{self.sfx}")(self._t, ptr(aabbs), aabbs.size // 6, *tail), self.ctx._h)
+        else:
+            check(getattr(lib, f"bvhgpu_traverse_host_{self.sfx}")(self._t, *tail), self.ctx._h)
+        return int(total.value)
+
+    def traverse_host_indices(self, indices: np.ndarray) -> None:
+        check(_lib.load().bvhgpu_traverse_host_indices(self.ctx._h, ptr(indices), indices.size), self.ctx._h)
 
     def wait(self) -> "Bvh":
         check(_lib.load().bvhgpu_tree_wait(self._t), self.ctx._h)

@@ -129,6 +129,7 @@ void finish_hits(bvhgpu_hits* h) {
     for (;;) {
         if (!replay && traverse_check(h)) break;
         replay = false;
+        h->replays++;
         if (h->dtype == BVHGPU_F32) traverse_enqueue<float>(t, static_cast<const bvhgpu_ray_f32*>(rays), h->n_rays, h->flags, h);
         else traverse_enqueue<double>(t, static_cast<const bvhgpu_ray_f64*>(rays), h->n_rays, h->flags, h);
         BVH_HIP(hipStreamSynchronize(ctx->stream));
@@ -242,7 +243,7 @@ int do_traverse(bvhgpu_tree* tree, const typename Traits<T>::Ray* rays, size_t n
         const auto* dev = static_cast<const typename Traits<T>::Ray*>(
             to_device(ctx, rays, n_rays * sizeof(typename Traits<T>::Ray), mem, ctx->upload));
         if (async) {
-            h->force_binary = false; h->pend_attempts = 0; h->deferred_rc = 0;
+            h->force_binary = false; h->pend_attempts = 0; h->deferred_rc = 0; h->replays = 0;
             h->pend_gen = tree->gen; h->pend_on_pending = tree->pending_build || tree->pending_recv;
             traverse_enqueue<T>(tree, dev, n_rays, flags, h);
             h->pend_async = true;
@@ -422,6 +423,254 @@ int do_nearest(bvhgpu_tree* t, const T* points, size_t n, int mem, int kind, uin
     });
 }
 
+
+// ---- host-resident batches (ABI 7): bvhgpu_traverse_host_* ------------------------------------------------------------------------
+// What GpuBvh::traverse_batch of the Rust shim costs a caller whose rays live in host memory and who wants the hit lists back there is a
+// PCIe problem, not a kernel problem: 1 M rays are 36 MB as Ray structs and 24 MB as origins + directions, the CSR offsets 4 MB.  The
+// batch is cut into chunks, each an ordinary asynchronous batch on a result object of its own:
+//   up stream    chunk k+1: origins + directions H2D, Ray::new on the device (k_rays_new: the correctly rounded divide and square
+//                root give the bits Ray::new gives, ray_impl.rs:70-80)
+//   main stream  chunk k: the walk + CSR assembly (behind the tree's build if that is still in flight: the uploads do not wait for
+//                it), then its offsets rebased into the batch's array
+//   down stream  chunk k-1: offsets D2H
+// and one host wait at the end, after which the (small) index lists follow.  A chunk that had to be replayed (hit pool too small on
+// a first batch, a build that finished on the slow path) sends the offsets again, in one piece.
+void free_host_batch(bvhgpu_ctx* ctx) {
+    HostBatch* hb = ctx->host;
+    if (!hb) return;
+    ctx->host = nullptr;
+    for (auto& h : hb->hits) if (h) { bvhgpu_hits_destroy(h); h = nullptr; }
+    for (auto& e : hb->ev_up) if (e) (void)hipEventDestroy(e);
+    for (auto& e : hb->ev_done) if (e) (void)hipEventDestroy(e);
+    if (hb->up) { (void)hipStreamSynchronize(hb->up); (void)hipStreamDestroy(hb->up); }
+    if (hb->up2) { (void)hipStreamSynchronize(hb->up2); (void)hipStreamDestroy(hb->up2); }
+    for (auto& e : hb->ev_up2) if (e) (void)hipEventDestroy(e);
+    if (hb->ev_main) (void)hipEventDestroy(hb->ev_main);
+    if (hb->ev_aabbs) (void)hipEventDestroy(hb->ev_aabbs);
+    hb->indices.release();
+    if (hb->down) { (void)hipStreamSynchronize(hb->down); (void)hipStreamDestroy(hb->down); }
+    hb->od.release(); hb->rays.release(); hb->offsets.release();
+    delete hb;
+}
+
+// the address under which the device sees a host range (pinned: bvhgpu_host_alloc / _register), or NULL for pageable memory
+template <typename U> U* dev_visible(U* p) {
+    void* d = nullptr;
+    if (!p) return nullptr;
+    if (hipHostGetDevicePointer(&d, const_cast<void*>(static_cast<const void*>(p)), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return static_cast<U*>(d);
+}
+constexpr unsigned HOST_READ_BLOCKS = 48;   // workgroups of a kernel that reads pinned host memory: 12 K lanes x 24 B in flight cover the link's latency
+
+void host_batch_init(bvhgpu_ctx* ctx) {
+    if (!ctx->host) ctx->host = new HostBatch();
+    HostBatch& hb = *ctx->host;
+    if (!hb.up) BVH_HIP(hipStreamCreateWithFlags(&hb.up, hipStreamNonBlocking));
+    if (!hb.up2) BVH_HIP(hipStreamCreateWithFlags(&hb.up2, hipStreamNonBlocking));
+    if (!hb.down) BVH_HIP(hipStreamCreateWithFlags(&hb.down, hipStreamNonBlocking));
+    if (!hb.ev_main) BVH_HIP(hipEventCreateWithFlags(&hb.ev_main, hipEventDisableTiming));
+    if (!hb.ev_aabbs) BVH_HIP(hipEventCreateWithFlags(&hb.ev_aabbs, hipEventDisableTiming));
+    // (the upload streams do NOT wait for the main stream: the previous host batch ended with a wait for everything it had enqueued, and
+    //  a build that bvhgpu_rebuild_flat_async_* has just put on the main stream is exactly what the ray upload is meant to run beside)
+}
+
+// phase A: the batch's chunks and their uploads (up stream).  Nothing here depends on the tree, so the fused entry
+// (bvhgpu_build_traverse_host_*) enqueues it right behind the shapes' upload and BEFORE the build's launches: the ray upload — 24 MB
+// against the build's 3 — is the long pole.
+template <typename T>
+void host_batch_upload(bvhgpu_ctx* ctx, const T* origins, const T* directions, size_t n_rays) {
+    using Ray = typename Traits<T>::Ray;
+    HostBatch& hb = *ctx->host;
+    hb.total = 0; hb.fetched = false; hb.n_rays = n_rays; hb.chunks = 0; hb.with_od = directions != nullptr;
+    if (n_rays == 0) return;
+    // Chunks: the walks of all chunks run one after the other on the main stream, each as soon as its rays have arrived; what is
+    // left when the last upload ends is the LAST chunk's conversion + walk + offsets download, so the last chunk is the small one
+    // (an eighth of the batch, at least 64 K rays: below that the walk's persistent workgroups run half empty) and the others share
+    // the rest evenly.  Fewer, larger chunks walk faster in total (1 M rays: 123 µs in one walk, 4 x 47 µs in four).
+    const int knob = ctx->tune[BVHGPU_TUNE_HOST_CHUNKS];
+    const int want = knob & 0xFF;
+    const bool two_up = (knob & 0x100) != 0;   // (experiment: origins and directions on two upload streams)
+    int K = want > 0 ? std::min(want, (int)HostBatch::MAX_CHUNKS) : (n_rays >= 524288 ? 3 : (n_rays >= 262144 ? 2 : 1));
+    K = (int)std::min<size_t>((size_t)K, std::max<size_t>(n_rays / 32768, 1));
+    const size_t last = K > 1 ? std::min(std::max<size_t>(n_rays / 8, 65536), n_rays / (size_t)K) : 0;
+    const size_t body = n_rays - last;
+    for (int k = 0; k <= K; k++) {
+        size_t r = k == K ? n_rays : (k == K - 1 && K > 1 ? body : body * (size_t)k / (size_t)std::max(K - 1, 1));
+        if (k != K) r = std::min(n_rays, (r + 1023) & ~(size_t)1023);
+        hb.r0[k] = r;
+    }
+    for (int k = 1; k <= K; k++) hb.r0[k] = std::max(hb.r0[k], hb.r0[k - 1]);
+    hb.chunks = K;
+    hb.rays.reserve(n_rays * sizeof(Ray));
+    hb.offsets.reserve((n_rays + 1) * 4);
+    Ray* rays_dev = hb.rays.as<Ray>();
+    // pinned ray arrays: the device reads them itself — Ray::new (or a plain copy of the caller's Ray structs) straight out of host memory on
+    // the upload stream, one small launch per chunk: no staging buffer, no conversion pass on the main stream, none of the copy engines'
+    // 10 - 20 µs between two transfers (seven of them per batch)
+    const T* o_vis = (ctx->tune[BVHGPU_TUNE_HOST_ZERO_COPY] & 1) ? dev_visible(origins) : nullptr;
+    const T* d_vis = (o_vis && directions) ? dev_visible(directions) : nullptr;
+    hb.zero_copy_in = o_vis && (!directions || d_vis);
+    if (directions && !hb.zero_copy_in) hb.od.reserve(2 * n_rays * 3 * sizeof(T));
+    for (int k = 0; k < K; k++) {
+        const size_t a = hb.r0[k], nk = hb.r0[k + 1] - a;
+        if (!hb.ev_up[k]) BVH_HIP(hipEventCreateWithFlags(&hb.ev_up[k], hipEventDisableTiming));
+        if (!hb.ev_up2[k]) BVH_HIP(hipEventCreateWithFlags(&hb.ev_up2[k], hipEventDisableTiming));
+        if (!hb.ev_done[k]) BVH_HIP(hipEventCreateWithFlags(&hb.ev_done[k], hipEventDisableTiming));
+        if (nk && hb.zero_copy_in) {
+            if (directions) rays_new<T>(ctx, o_vis + 3 * a, d_vis + 3 * a, nk, rays_dev + a, hb.up, HOST_READ_BLOCKS);
+            else copy16(hb.up, reinterpret_cast<const Ray*>(o_vis) + a, rays_dev + a, nk * sizeof(Ray));
+        } else if (nk) {
+            if (directions) {
+                BVH_HIP(hipMemcpyAsync(hb.od.as<T>() + 3 * a, origins + 3 * a, nk * 3 * sizeof(T), hipMemcpyHostToDevice, hb.up));
+                BVH_HIP(hipMemcpyAsync(hb.od.as<T>() + 3 * n_rays + 3 * a, directions + 3 * a, nk * 3 * sizeof(T), hipMemcpyHostToDevice, two_up ? hb.up2 : hb.up));
+                if (two_up) { BVH_HIP(hipEventRecord(hb.ev_up2[k], hb.up2)); BVH_HIP(hipStreamWaitEvent(hb.up, hb.ev_up2[k], 0)); }
+            } else {   // the caller's own Ray structs (36 / 72 bytes per ray), used as they are
+                BVH_HIP(hipMemcpyAsync(rays_dev + a, reinterpret_cast<const Ray*>(origins) + a, nk * sizeof(Ray), hipMemcpyHostToDevice, hb.up));
+            }
+        }
+        BVH_HIP(hipEventRecord(hb.ev_up[k], hb.up));
+    }
+}
+
+// phase B: per chunk, on the main stream (behind the tree's build if one is in flight): Ray::new, the walk + CSR assembly as an ordinary
+// asynchronous batch, the offsets rebased into the batch's array and the index list appended to the batch's; the offsets' download on the
+// down stream, the index lists' behind the last chunk — as many entries as the PREVIOUS batch had hits (a frame loop's totals change
+// little: the rest, if any, follows after the wait); then ONE host wait
+template <typename T>
+int host_batch_walk(bvhgpu_tree* tree, unsigned flags, uint32_t* offsets, uint32_t* indices, size_t indices_cap, uint64_t* total) {
+    using Ray = typename Traits<T>::Ray;
+    bvhgpu_ctx* ctx = tree->ctx;
+    HostBatch& hb = *ctx->host;
+    const size_t n_rays = hb.n_rays;
+    const int K = hb.chunks;
+    if (n_rays == 0) {   // (the tree's build, if one is in flight, is completed by whoever looks at the tree next)
+        offsets[0] = 0;
+        return BVHGPU_OK;
+    }
+    Ray* rays_dev = hb.rays.as<Ray>();
+    uint32_t* offs_all = hb.offsets.as<uint32_t>();
+    hipStream_t st = ctx->stream;
+    // pinned result arrays: the device writes them itself (k_offsets_rebase / k_indices_append store through the host addresses): no download
+    const bool zc_out = (ctx->tune[BVHGPU_TUNE_HOST_ZERO_COPY] & 2) != 0;
+    hb.offsets_host = zc_out ? dev_visible(offsets) : nullptr;
+    hb.indices_host = (hb.offsets_host && indices && indices_cap) ? dev_visible(indices) : nullptr;
+    hb.idx_stage = hb.indices_host ? indices_cap : (indices ? std::min(indices_cap, HostBatch::IDX_STAGE_MAX) : 0);
+    if (hb.idx_stage && !hb.indices_host) hb.indices.reserve(hb.idx_stage * 4);
+    BVH_HIP(hipMemsetAsync(offs_all, 0, 4, st));   // the first chunk's base
+    int enq = 0;
+    auto finish_all = [&](bool swallow) {   // every chunk that was enqueued is completed, whatever the first failure was
+        bool replayed = false;
+        for (int k = 0; k < enq; k++) {
+            bvhgpu_hits* h = hb.hits[k];
+            if (!swallow) { finish_hits(h); replayed = replayed || h->replays != 0; continue; }
+            try { finish_hits(h); } catch (...) { h->pend_async = false; detach_waiter(h); }
+        }
+        return replayed;
+    };
+    auto rebase_chunk = [&](int k) {
+        const size_t a = hb.r0[k], nk = hb.r0[k + 1] - a;
+        offsets_rebase(st, hb.hits[k]->offsets.template as<uint32_t>(), nk, offs_all + a, hb.offsets_host ? hb.offsets_host + a : nullptr,
+                       hb.hits[k]->indices.template as<uint32_t>(), hb.indices_host ? hb.indices_host : (hb.idx_stage ? hb.indices.as<uint32_t>() : nullptr),
+                       hb.idx_stage);
+    };
+    try {
+        for (int k = 0; k < K; k++) {
+            const size_t a = hb.r0[k], nk = hb.r0[k + 1] - a;
+            BVH_HIP(hipStreamWaitEvent(st, hb.ev_up[k], 0));
+            if (hb.with_od && !hb.zero_copy_in) rays_new<T>(ctx, hb.od.as<T>() + 3 * a, hb.od.as<T>() + 3 * n_rays + 3 * a, nk, rays_dev + a, st);
+            const int rc = do_traverse<T>(tree, rays_dev + a, nk, BVHGPU_DEVICE, flags, &hb.hits[k], true);
+            if (rc != BVHGPU_OK) { const std::string keep = ctx->err; (void)finish_all(true); (void)hipStreamSynchronize(hb.up); ctx->err = keep; return rc; }
+            enq = k + 1;
+            rebase_chunk(k);
+            if (hb.offsets_host) continue;
+            BVH_HIP(hipEventRecord(hb.ev_done[k], st));
+            BVH_HIP(hipStreamWaitEvent(hb.down, hb.ev_done[k], 0));
+            const size_t skip = k ? 1 : 0;   // (offsets[a] of a later chunk is the previous chunk's last entry)
+            if (nk + 1 > skip) BVH_HIP(hipMemcpyAsync(offsets + a + skip, offs_all + a + skip, (nk + 1 - skip) * 4, hipMemcpyDeviceToHost, hb.down));
+        }
+        uint64_t sent = hb.indices_host ? hb.idx_stage : std::min<uint64_t>(hb.guess, hb.idx_stage);
+        if (sent && !hb.indices_host) BVH_HIP(hipMemcpyAsync(indices, hb.indices.p, sent * 4, hipMemcpyDeviceToHost, hb.down));
+        const bool replayed = finish_all(false);
+        BVH_HIP(hipStreamSynchronize(hb.down));
+        uint64_t tot = 0;
+        for (int k = 0; k < K; k++) tot += hb.hits[k]->total;
+        if (tot > 0xFFFFFFFFull) throw HipFail{hipErrorInvalidValue, "OVERFLOW", __LINE__};
+        if (replayed) {   // what went down came from an incomplete walk: rebase again, one copy
+            BVH_HIP(hipMemsetAsync(offs_all, 0, 4, st));
+            for (int k = 0; k < K; k++) rebase_chunk(k);
+            if (!hb.offsets_host) BVH_HIP(hipMemcpyAsync(offsets, offs_all, (n_rays + 1) * 4, hipMemcpyDeviceToHost, st));
+            BVH_HIP(hipStreamSynchronize(st));
+            if (!hb.indices_host) sent = 0;
+        }
+        hb.total = tot;
+        hb.guess = tot;
+        *total = tot;
+        if (indices && tot <= indices_cap) {
+            if (hb.indices_host) {
+                // (written by the device, all of them: idx_stage == indices_cap >= tot)
+            } else if (tot <= hb.idx_stage) {   // the batch's lists are in one piece: whatever the optimistic download did not cover
+                if (tot > sent) { BVH_HIP(hipMemcpyAsync(indices + sent, hb.indices.as<uint32_t>() + sent, (tot - sent) * 4, hipMemcpyDeviceToHost, st)); BVH_HIP(hipStreamSynchronize(st)); }
+            } else {
+                uint64_t base = 0;
+                for (int k = 0; k < K; k++) {
+                    const uint64_t tk = hb.hits[k]->total;
+                    if (tk) BVH_HIP(hipMemcpyAsync(indices + base, hb.hits[k]->indices.p, tk * 4, hipMemcpyDeviceToHost, st));
+                    base += tk;
+                }
+                BVH_HIP(hipStreamSynchronize(st));
+            }
+            hb.fetched = true;
+        }
+    } catch (...) {
+        (void)finish_all(true);
+        (void)hipStreamSynchronize(hb.up); (void)hipStreamSynchronize(hb.up2); (void)hipStreamSynchronize(hb.down);
+        throw;
+    }
+    return BVHGPU_OK;
+}
+
+// rebuild == false: the tree as it is (bvhgpu_traverse_host_*).  rebuild: the shapes' AABBs go up first on the upload stream — the
+// link is one resource: a second copy beside the rays' would slow both — the rays right behind them, and the main stream builds
+// (bvhgpu_rebuild_flat_async_*) as soon as the shapes are there
+template <typename T>
+int do_traverse_host(bvhgpu_tree* tree, const T* aabbs, size_t n_shapes, bool rebuild, const T* origins, const T* directions, size_t n_rays,
+                     unsigned flags, uint32_t* offsets, uint32_t* indices, size_t indices_cap, uint64_t* total) {
+    if (!tree) return BVHGPU_INVALID_ARG;
+    bvhgpu_ctx* ctx = tree->ctx;
+    if (!offsets || !total) return fail(ctx, BVHGPU_INVALID_ARG, "offsets / total is NULL");
+    if (n_rays && !origins) return fail(ctx, BVHGPU_INVALID_ARG, "origins is NULL");
+    if (flags & ~BVHGPU_TRAVERSE_COHERENT) return fail(ctx, BVHGPU_INVALID_ARG, "bvhgpu_traverse_host_* returns index lists: only BVHGPU_TRAVERSE_COHERENT may be set");
+    if (tree->dtype != Traits<T>::dtype) return fail(ctx, BVHGPU_DTYPE_MISMATCH, "tree dtype differs from ray / shape dtype");
+    if (n_rays >= 0xFFFFFFFFull) return fail(ctx, BVHGPU_OVERFLOW, "more than 2^32-2 rays in one batch");
+    if (rebuild && n_shapes && !aabbs) return fail(ctx, BVHGPU_INVALID_ARG, "aabbs is NULL");
+    if (rebuild && n_shapes > MAX_SHAPES) return fail(ctx, BVHGPU_OVERFLOW, "too many shapes for u32 flat indices");
+    *total = 0;
+    return guarded(ctx, [&] {
+        use_device(ctx);
+        if (rebuild) {   // whatever is in flight on the tree is completed before its shape array is overwritten (as bvhgpu_rebuild_* does)
+            try { ensure_built(tree); }
+            catch (const HipFail& e) { if (!e.what || (std::strcmp(e.what, "REBROADCAST") != 0 && std::strcmp(e.what, "NONFINITE") != 0 && std::strncmp(e.what, "RECV_", 5) != 0)) throw; }
+            settle_waiters_impl(tree);
+        }
+        host_batch_init(ctx);
+        HostBatch& hb = *ctx->host;
+        if (rebuild && n_shapes) {
+            tree->aabbs.reserve(n_shapes * 6 * sizeof(T));
+            const T* a_vis = (ctx->tune[BVHGPU_TUNE_HOST_ZERO_COPY] & 1) ? dev_visible(aabbs) : nullptr;
+            if (a_vis) copy16(hb.up, a_vis, tree->aabbs.p, n_shapes * 6 * sizeof(T));
+            else BVH_HIP(hipMemcpyAsync(tree->aabbs.p, aabbs, n_shapes * 6 * sizeof(T), hipMemcpyHostToDevice, hb.up));
+            BVH_HIP(hipEventRecord(hb.ev_aabbs, hb.up));
+        }
+        host_batch_upload<T>(ctx, origins, directions, n_rays);
+        if (rebuild) {
+            if (n_shapes) BVH_HIP(hipStreamWaitEvent(ctx->stream, hb.ev_aabbs, 0));
+            const int rc = do_build<T>(tree, tree->aabbs.as<T>(), n_shapes, BVHGPU_DEVICE, true, true);
+            if (rc != BVHGPU_OK) { (void)hipStreamSynchronize(hb.up); (void)hipStreamSynchronize(hb.up2); return rc; }
+        }
+        return host_batch_walk<T>(tree, flags, offsets, indices, indices_cap, total);
+    });
+}
+
 }  // namespace
 
 namespace bvhgpu {
@@ -498,6 +747,7 @@ void bvhgpu_destroy(bvhgpu_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_host_batch(ctx);
     ctx->upload.release();
     ctx->counters.release();
     for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
@@ -538,6 +788,26 @@ int bvhgpu_device_copy(bvhgpu_ctx* ctx, void* dst, int dst_mem, const void* src,
         }
         return (int)BVHGPU_OK;
     });
+}
+
+// ---- pinned host memory (ABI 7): buffers the DMA engines read and write directly ----
+int bvhgpu_host_alloc(bvhgpu_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return fail(ctx, BVHGPU_INVALID_ARG, "NULL argument");
+    *out = nullptr;
+    return guarded(ctx, [&] { use_device(ctx); BVH_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault)); return (int)BVHGPU_OK; });
+}
+int bvhgpu_host_free(bvhgpu_ctx* ctx, void* p) {
+    if (!ctx) return BVHGPU_INVALID_ARG;
+    if (!p) return BVHGPU_OK;
+    return guarded(ctx, [&] { use_device(ctx); BVH_HIP(hipStreamSynchronize(ctx->stream)); BVH_HIP(hipHostFree(p)); return (int)BVHGPU_OK; });
+}
+int bvhgpu_host_register(bvhgpu_ctx* ctx, void* p, size_t bytes) {
+    if (!ctx || !p || !bytes) return fail(ctx, BVHGPU_INVALID_ARG, "NULL / empty range");
+    return guarded(ctx, [&] { use_device(ctx); BVH_HIP(hipHostRegister(p, bytes, hipHostRegisterDefault)); return (int)BVHGPU_OK; });
+}
+int bvhgpu_host_unregister(bvhgpu_ctx* ctx, void* p) {
+    if (!ctx || !p) return fail(ctx, BVHGPU_INVALID_ARG, "NULL argument");
+    return guarded(ctx, [&] { use_device(ctx); BVH_HIP(hipStreamSynchronize(ctx->stream)); BVH_HIP(hipHostUnregister(p)); return (int)BVHGPU_OK; });
 }
 
 int bvhgpu_build_f32(bvhgpu_ctx* ctx, const float* aabbs, size_t n, int mem, bvhgpu_tree** out) {
@@ -866,6 +1136,42 @@ int bvhgpu_traverse_f32(bvhgpu_tree* tree, const bvhgpu_ray_f32* rays, size_t n_
 }
 int bvhgpu_traverse_f64(bvhgpu_tree* tree, const bvhgpu_ray_f64* rays, size_t n_rays, int mem, unsigned flags, bvhgpu_hits** hits) {
     return do_traverse<double>(tree, rays, n_rays, mem, flags, hits);
+}
+
+int bvhgpu_traverse_host_f32(bvhgpu_tree* tree, const float* origins, const float* directions, size_t n_rays, unsigned flags, uint32_t* offsets,
+                             uint32_t* indices, size_t indices_cap, uint64_t* total) {
+    return do_traverse_host<float>(tree, nullptr, 0, false, origins, directions, n_rays, flags, offsets, indices, indices_cap, total);
+}
+int bvhgpu_traverse_host_f64(bvhgpu_tree* tree, const double* origins, const double* directions, size_t n_rays, unsigned flags, uint32_t* offsets,
+                             uint32_t* indices, size_t indices_cap, uint64_t* total) {
+    return do_traverse_host<double>(tree, nullptr, 0, false, origins, directions, n_rays, flags, offsets, indices, indices_cap, total);
+}
+int bvhgpu_build_traverse_host_f32(bvhgpu_tree* tree, const float* aabbs, size_t n, const float* origins, const float* directions, size_t n_rays,
+                                   unsigned flags, uint32_t* offsets, uint32_t* indices, size_t indices_cap, uint64_t* total) {
+    return do_traverse_host<float>(tree, aabbs, n, true, origins, directions, n_rays, flags, offsets, indices, indices_cap, total);
+}
+int bvhgpu_build_traverse_host_f64(bvhgpu_tree* tree, const double* aabbs, size_t n, const double* origins, const double* directions, size_t n_rays,
+                                   unsigned flags, uint32_t* offsets, uint32_t* indices, size_t indices_cap, uint64_t* total) {
+    return do_traverse_host<double>(tree, aabbs, n, true, origins, directions, n_rays, flags, offsets, indices, indices_cap, total);
+}
+int bvhgpu_traverse_host_indices(bvhgpu_ctx* ctx, uint32_t* indices, size_t indices_cap) {
+    if (!ctx) return BVHGPU_INVALID_ARG;
+    HostBatch* hb = ctx->host;
+    if (!hb || (hb->n_rays && hb->chunks == 0)) return fail(ctx, BVHGPU_INVALID_ARG, "no completed bvhgpu_traverse_host_* batch on this ctx");
+    if (hb->total > indices_cap) return fail(ctx, BVHGPU_INVALID_ARG, "indices_cap is smaller than the batch's hit total");
+    if (hb->total && !indices) return fail(ctx, BVHGPU_INVALID_ARG, "indices is NULL");
+    return guarded(ctx, [&] {
+        use_device(ctx);
+        uint64_t base = 0;
+        for (int k = 0; k < hb->chunks; k++) {
+            const uint64_t tk = hb->hits[k]->total;
+            if (tk) BVH_HIP(hipMemcpyAsync(indices + base, hb->hits[k]->indices.p, tk * 4, hipMemcpyDeviceToHost, ctx->stream));
+            base += tk;
+        }
+        BVH_HIP(hipStreamSynchronize(ctx->stream));
+        hb->fetched = true;
+        return (int)BVHGPU_OK;
+    });
 }
 
 static int set_triangles(bvhgpu_tree* t, const void* verts, size_t n, int mem, int dtype) {

@@ -39,6 +39,33 @@ struct DevBuf {
 
 struct bvhgpu_comm;
 struct bvhgpu_hits;
+namespace bvhgpu {
+// bvhgpu_traverse_host_*: a batch whose rays start in host memory and whose CSR ends there, walked as `chunks` ordinary asynchronous
+// batches so that the upload of one chunk (side stream), the walk of the previous one (main stream) and the download of the offsets of
+// the one before (down stream) overlap
+struct HostBatch {
+    static constexpr int MAX_CHUNKS = 16;
+    bvhgpu_hits* hits[MAX_CHUNKS] = {};
+    hipEvent_t ev_up[MAX_CHUNKS] = {}, ev_done[MAX_CHUNKS] = {};
+    hipStream_t up = nullptr, up2 = nullptr, down = nullptr;
+    hipEvent_t ev_main = nullptr, ev_aabbs = nullptr, ev_up2[MAX_CHUNKS] = {};
+    DevBuf indices;   // the batch's index lists in one piece, as far as the caller's buffer reaches (at most IDX_STAGE_MAX entries)
+    static constexpr size_t IDX_STAGE_MAX = (size_t)1 << 26;
+    size_t idx_stage = 0;      // entries of `indices` this batch may fill
+    uint64_t guess = 0;        // entries of `indices` whose download was enqueued before the batch's total was known (the previous batch's total)
+    DevBuf od;        // origins + directions of the batch as uploaded (2 x n_rays x 3 T), or nothing when the caller hands over Ray structs
+    DevBuf rays;      // n_rays x Ray
+    DevBuf offsets;   // n_rays + 1 u32: the whole batch's CSR offsets (chunks rebased)
+    size_t n_rays = 0, r0[MAX_CHUNKS + 1] = {};
+    int chunks = 0;
+    uint64_t total = 0;
+    bool fetched = false;
+    bool zero_copy_in = false;   // the device reads the caller's (pinned) ray arrays itself: Ray::new straight out of host memory, no staging copy
+    uint32_t* offsets_host = nullptr;   // device-visible address of the caller's (pinned) offsets / indices arrays: written by the device, no download
+    uint32_t* indices_host = nullptr;
+    bool with_od = false;   // the batch came as origins + directions (Ray::new on the device) rather than as Ray structs
+};
+}
 
 struct bvhgpu_ctx {
     int device = 0;
@@ -46,7 +73,7 @@ struct bvhgpu_ctx {
     bool own_stream = false;
     std::string err;
     int n_cu = 256;
-    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0, 0, -1, 1, 1, 1, 0};  // bvhgpu_set_tuning defaults
+    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0, 0, -1, 1, 1, 1, 0, 0, 256, 2};  // bvhgpu_set_tuning defaults
     // timing
     bool timing = false;
     hipEvent_t ev[8] = {};
@@ -56,6 +83,7 @@ struct bvhgpu_ctx {
     bvhgpu::DevBuf upload;    // staging for host→device inputs (aabbs / rays)
     bvhgpu::DevBuf counters;  // small device counters
     void* pinned = nullptr;   // 4 KiB pinned host page for tiny D2H reads
+    bvhgpu::HostBatch* host = nullptr;   // state of bvhgpu_traverse_host_* (capi.hip), made on first use
     hipStream_t side = nullptr;   // second stream of the ctx (created on first use): work that may run BESIDE the main chain — the
                                   // item filter of a batch whose tree is still building (traverse.hip k_wide_items)
 };
@@ -192,6 +220,7 @@ struct bvhgpu_hits {
     hipEvent_t ev_items = nullptr;      // the early item filter of this batch has finished (side stream → main stream)
     bvhgpu::DevBuf wg_items;            // per workgroup of the wide walk: {items at the front, items at the back} of its list region, written by
                                         // the early filter (front == NONE: the workgroup filters its rays itself)
+    uint32_t replays = 0;               // times bvhgpu_hits_wait had to enqueue the asynchronous batch again
     int deferred_rc = 0;                // status of a completion that ran on behalf of another call (rebuild / destroy of the tree)
     std::string deferred_err;
 };
@@ -234,7 +263,13 @@ void nearest_batch(bvhgpu_tree* t, const T* points_dev, size_t n, int kind, uint
 template <typename T>
 void ray_triangle_pairs(bvhgpu_ctx* ctx, const typename Traits<T>::Ray* rays_dev, const T* tris_dev, size_t n, T* out_dev);
 template <typename T>
-void rays_new(bvhgpu_ctx* ctx, const T* origins_dev, const T* dirs_dev, size_t n, typename Traits<T>::Ray* out_dev);
+void rays_new(bvhgpu_ctx* ctx, const T* origins_dev, const T* dirs_dev, size_t n, typename Traits<T>::Ray* out_dev, hipStream_t st = nullptr,
+              unsigned max_blocks = 0);
+// out[i] = out[0] + offs[i], i = 1..n_rays; idx_all_dev != NULL: the chunk's index list copied to idx_all_dev[out[0] ..) as far as idx_cap entries reach
+// out_host (device-visible pinned host memory, or NULL): the same values stored there as well; idx_all (device or such host memory)
+void offsets_rebase(hipStream_t st, const uint32_t* offs_dev, size_t n_rays, uint32_t* out_dev, uint32_t* out_host = nullptr,
+                    const uint32_t* idx_dev = nullptr, uint32_t* idx_all = nullptr, size_t idx_cap = 0);
+void copy16(hipStream_t st, const void* src, void* dst, size_t bytes);   // a copy KERNEL (src / dst may be device-visible host memory)
 template <typename T>
 void gen_primary(bvhgpu_ctx* ctx, const float cam[14], uint32_t width, uint32_t height, uint64_t first, size_t n,
                  typename Traits<T>::Ray* out_dev);

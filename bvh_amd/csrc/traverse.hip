@@ -1738,6 +1738,21 @@ template <typename T> struct WideGeom {
         lds_bytes = 80 + (size_t)K * per_slot + (size_t)stack_lds * stack_stride * 4;
     }
 };
+// Workgroups of the wide walk for a batch: one ray per lane — unless the rays are cut into items (16 per ray: a workgroup's lanes stay busy
+// with a quarter of the rays) and the batch is too small to fill the chip's workgroup slots that way: then the rays are spread over all
+// slots, down to BVHGPU_TUNE_WIDE_MIN_RAYS_PER_WG rays per workgroup.  (One ray per lane, a small batch takes the time of ONE workgroup's
+// 1024 rays whatever its size; bvhgpu_traverse_host_* walks its batches in such chunks.  profiles/r6_walk_size_sweep.log)
+inline size_t wide_grid(const bvhgpu_ctx* ctx, uint32_t threads, uint32_t wg_per_cu, size_t n_rays, int items_log4) {
+    const size_t slots = (size_t)ctx->n_cu * wg_per_cu;
+    size_t per_wg = threads;
+    const int min_rays = ctx->tune[BVHGPU_TUNE_WIDE_MIN_RAYS_PER_WG];
+    if (items_log4 == 2 && min_rays > 0 && n_rays * 4 <= slots * threads) {   // (measured: 33 K / 66 K / 125 K rays 48 -> 37 / 38 / 41 µs; 250 K rays 49 -> 53)
+        const size_t spread = ((n_rays + slots - 1) / slots + 63) & ~(size_t)63;
+        per_wg = std::min<size_t>(threads, std::max<size_t>(spread, (size_t)std::max(64, min_rays & ~63)));
+    }
+    const size_t full = (n_rays + per_wg - 1) / per_wg;
+    return std::min<size_t>(std::max<size_t>(full, 1), slots);
+}
 constexpr uint32_t WIDE_GSTACK = 24;   // stack entries per lane beyond the LDS part, in HBM (a walk pushes at most 3 per wide level)
 
 // GUIDE: T = float on an f64 tree — the nodes are the tree's guide boxes, rays_dev unused (NULL), ga the f64 batch: every ray is converted where the walk loads it (guide_ray_load)
@@ -1747,8 +1762,7 @@ static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev,
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
     const WideGeom<T> g(ctx, ITEMS_LOG4 == 0, (h->flags & BVHGPU_TRAVERSE_COHERENT) != 0);
-    const size_t full = (n_rays + g.threads - 1) / g.threads;
-    const dim3 grid((unsigned)std::min<size_t>(std::max<size_t>(full, 1), (size_t)ctx->n_cu * g.wg_per_cu));
+    const dim3 grid((unsigned)wide_grid(ctx, g.threads, g.wg_per_cu, n_rays, ITEMS_LOG4));
     uint32_t* list = nullptr;
     if (ITEMS_LOG4 > 0) {   // every workgroup's region of the live-item list: its rays x 4^L entries
         const size_t n_blocks = (n_rays + 63) / 64;
@@ -2022,8 +2036,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
             const WideGeom<T> gt(ctx, items_log4 == 0, coherent);
             const WideGeom<float> gf(ctx, items_log4 == 0, coherent);   // (the guide walk of an f64 batch launches the f32 geometry)
             const uint32_t g_threads = use_guide ? gf.threads : gt.threads, g_wg_per_cu = use_guide ? gf.wg_per_cu : gt.wg_per_cu;
-            const size_t full = (n_rays + g_threads - 1) / g_threads;
-            const size_t grid = std::min<size_t>(std::max<size_t>(full, 1), (size_t)ctx->n_cu * g_wg_per_cu);   // launch_wide: the same
+            const size_t grid = wide_grid(ctx, g_threads, g_wg_per_cu, n_rays, items_log4);   // launch_wide: the same
             const size_t n_blocks = (n_rays + 63) / 64;
             if (nb <= SCAN_FUSED_MAX_BLOCKS && (n_blocks + grid - 1) / grid <= WIDE_BSUM_MAX) {
                 // two sets of SCAN_FUSED_MAX_BLOCKS sums, used alternately like the counter sets (k_scan_final zeroes the other one)
@@ -2397,22 +2410,63 @@ template <typename T> __device__ __forceinline__ void ray_new(const T o[3], cons
 template <typename T>
 __global__ __launch_bounds__(256) void k_rays_new(const T* __restrict__ origins, const T* __restrict__ dirs, uint32_t n,
                                                   typename Traits<T>::Ray* __restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    T o[3] = {origins[3 * (size_t)i], origins[3 * (size_t)i + 1], origins[3 * (size_t)i + 2]};
-    T d[3] = {dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2]};
-    ray_new<T>(o, d, out + i);
+    // (a grid-stride loop: with origins / dirs in pinned HOST memory the launch is kept small — a few thousand lanes keep the PCIe link busy —
+    //  so that it leaves the CUs to the build running beside it)
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        T o[3] = {origins[3 * (size_t)i], origins[3 * (size_t)i + 1], origins[3 * (size_t)i + 2]};
+        T d[3] = {dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2]};
+        ray_new<T>(o, d, out + i);
+    }
 }
 
 template <typename T>
-void rays_new(bvhgpu_ctx* ctx, const T* origins_dev, const T* dirs_dev, size_t n, typename Traits<T>::Ray* out_dev) {
+void rays_new(bvhgpu_ctx* ctx, const T* origins_dev, const T* dirs_dev, size_t n, typename Traits<T>::Ray* out_dev, hipStream_t st, unsigned max_blocks) {
     if (!n) return;
-    hipLaunchKernelGGL(k_rays_new<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, origins_dev, dirs_dev,
-                       (uint32_t)n, out_dev);
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (max_blocks) blocks = std::min(blocks, max_blocks);
+    hipLaunchKernelGGL(k_rays_new<T>, dim3(blocks), dim3(256), 0, st ? st : ctx->stream, origins_dev, dirs_dev, (uint32_t)n, out_dev);
     BVH_HIP(hipGetLastError());
 }
-template void rays_new<float>(bvhgpu_ctx*, const float*, const float*, size_t, bvhgpu_ray_f32*);
-template void rays_new<double>(bvhgpu_ctx*, const double*, const double*, size_t, bvhgpu_ray_f64*);
+template void rays_new<float>(bvhgpu_ctx*, const float*, const float*, size_t, bvhgpu_ray_f32*, hipStream_t, unsigned);
+template void rays_new<double>(bvhgpu_ctx*, const double*, const double*, size_t, bvhgpu_ray_f64*, hipStream_t, unsigned);
+
+// CSR offsets of one chunk of a host-resident batch (bvhgpu_traverse_host_*), moved to their place in the whole batch's array:
+// out[0] holds the hits of all chunks before this one (written by the previous chunk's pass on the same stream; 0 for the first)
+// (out_host: the caller's own array when it is pinned memory the device can write — the offsets then need no download)
+__global__ __launch_bounds__(256) void k_offsets_rebase(const uint32_t* __restrict__ offs, uint32_t n_plus_1, uint32_t* __restrict__ out,
+                                                        uint32_t* __restrict__ out_host) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_plus_1) return;
+    const uint32_t v = out[0] + (i ? offs[i] : 0u);
+    if (i) out[i] = v;        // (out[0] is the base itself)
+    if (out_host) out_host[i] = v;
+}
+// ... and its index list appended to the batch's (what fits into `cap` entries): base = out[0], count = offs[n_rays]
+__global__ __launch_bounds__(256) void k_indices_append(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ offs, uint32_t n_rays,
+                                                        const uint32_t* __restrict__ base_ptr, uint32_t* __restrict__ dst, unsigned long long cap) {
+    const unsigned long long base = base_ptr[0], cnt = offs[n_rays];
+    for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < cnt && base + i < cap; i += (unsigned long long)gridDim.x * blockDim.x)
+        dst[base + i] = idx[i];
+}
+void offsets_rebase(hipStream_t st, const uint32_t* offs_dev, size_t n_rays, uint32_t* out_dev, uint32_t* out_host, const uint32_t* idx_dev,
+                    uint32_t* idx_all, size_t idx_cap) {
+    // (the index list first: it reads the chunk's base out[0] and the chunk-local count, both untouched by the rebase)
+    if (idx_all && idx_cap)
+        hipLaunchKernelGGL(k_indices_append, dim3(128), dim3(256), 0, st, idx_dev, offs_dev, (uint32_t)n_rays, out_dev, idx_all, (unsigned long long)idx_cap);
+    hipLaunchKernelGGL(k_offsets_rebase, dim3((unsigned)((n_rays + 1 + 255) / 256)), dim3(256), 0, st, offs_dev, (uint32_t)(n_rays + 1), out_dev, out_host);
+    BVH_HIP(hipGetLastError());
+}
+
+// 16-byte copy (the caller's Ray structs out of pinned host memory, read by the device directly)
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void copy16(hipStream_t st, const void* src, void* dst, size_t bytes) {   // bytes: a multiple of 4; the tail goes word by word
+    const size_t n16 = bytes / 16;
+    if (n16) hipLaunchKernelGGL(k_copy16, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 128)), dim3(256), 0, st, static_cast<const uint4*>(src), static_cast<uint4*>(dst), n16);
+    if (bytes & 15) BVH_HIP(hipMemcpyAsync(static_cast<char*>(dst) + n16 * 16, static_cast<const char*>(src) + n16 * 16, bytes & 15, hipMemcpyDefault, st));
+    BVH_HIP(hipGetLastError());
+}
 
 // ------------------------------------------------------------------------------------------------
 // bench ray stream: create_ray (testbase.rs:687-691) over splitmix64 (:558-564), next_point3 (:567-595).

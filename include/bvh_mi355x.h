@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BVHGPU_ABI_VERSION 6 /* 6: BVHGPU_TUNE_COUNT 17 (slots 15 = FLATTEN_LAZY, 16 = BUILD_LEVEL_PERSIST), bvhgpu_hits_walk_kernel.  5: bvhgpu_rccl_info.  4: BVHGPU_TUNE_COUNT 15 (slot 14 = WIDE_F64_GUIDE), bvhgpu_hits_walk_info.  3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 14 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT, 13 = WIDE_REC8), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
+#define BVHGPU_ABI_VERSION 7 /* 7: bvhgpu_host_alloc/free/register/unregister, bvhgpu_traverse_host_*, bvhgpu_build_traverse_host_*, bvhgpu_traverse_host_indices, BVHGPU_TUNE_COUNT 20 (slots 17 = HOST_CHUNKS, 18 = WIDE_MIN_RAYS_PER_WG, 19 = HOST_ZERO_COPY).  6: BVHGPU_TUNE_COUNT 17 (slots 15 = FLATTEN_LAZY, 16 = BUILD_LEVEL_PERSIST), bvhgpu_hits_walk_kernel.  5: bvhgpu_rccl_info.  4: BVHGPU_TUNE_COUNT 15 (slot 14 = WIDE_F64_GUIDE), bvhgpu_hits_walk_info.  3: BVHGPU_REBROADCAST, broadcast status header, scene blob BVH6 (exact_only), BVHGPU_TUNE_COUNT 14 (slots 11 = WIDE_EARLY_ITEMS, 12 = WIDE_STAGE_SHIFT, 13 = WIDE_REC8), BVHGPU_TRAVERSE_RAYS_READY, bvhgpu_device_alloc/free/copy */
 #define BVHGPU_NONE 0xFFFFFFFFu /* u32::MAX marker (flat_bvh.rs:51-53, :124, :137) */
 
 typedef enum {
@@ -135,6 +135,16 @@ void *bvhgpu_stream(bvhgpu_ctx *ctx); /* the hipStream_t work is enqueued on */
 int bvhgpu_device_alloc(bvhgpu_ctx *ctx, size_t bytes, void **out);
 int bvhgpu_device_free(bvhgpu_ctx *ctx, void *ptr);
 int bvhgpu_device_copy(bvhgpu_ctx *ctx, void *dst, int dst_mem, const void *src, int src_mem, size_t bytes);
+
+/* ---- pinned host memory (ABI 7).  Every BVHGPU_HOST argument may be ordinary (pageable) memory; memory from
+ * bvhgpu_host_alloc — or a range the caller owns and has announced with bvhgpu_host_register, e.g. the allocation behind a
+ * Vec that lives as long as the scene — is read and written by the DMA engines directly (≈ 55 GB/s on the PCIe 5 link instead of
+ * ≈ 30 through the runtime's staging copies) and lets the asynchronous entry points return before the copy has happened.
+ * hipHostMalloc / hipHostFree / hipHostRegister / hipHostUnregister on the ctx's device. ---- */
+int bvhgpu_host_alloc(bvhgpu_ctx *ctx, size_t bytes, void **out);
+int bvhgpu_host_free(bvhgpu_ctx *ctx, void *ptr);
+int bvhgpu_host_register(bvhgpu_ctx *ctx, void *ptr, size_t bytes);
+int bvhgpu_host_unregister(bvhgpu_ctx *ctx, void *ptr);
 
 /* ---- build: replaces Bvh::build / Bvh::build_par / build_with_executor (bvh_impl.rs:40-96,
  * bounding_hierarchy.rs:158-177) once the caller has gathered shape.aabb() for every shape
@@ -299,6 +309,34 @@ int bvhgpu_traverse_f32(bvhgpu_tree *tree, const bvhgpu_ray_f32 *rays, size_t n_
                         bvhgpu_hits **hits);
 int bvhgpu_traverse_f64(bvhgpu_tree *tree, const bvhgpu_ray_f64 *rays, size_t n_rays, int mem, unsigned flags,
                         bvhgpu_hits **hits);
+
+/* ---- the same for a caller whose rays live in HOST memory and who wants the hit lists back in host memory (ABI 7): what
+ * GpuBvh::traverse_batch of the Rust shim does, in one call.  Replaces `for ray in rays { flat.traverse(&Ray::new(o, d), shapes) }`
+ * (ray_impl.rs:70-80, flat_bvh.rs:396-431).
+ *   origins, directions   n_rays x 3 T each: Ray::new runs on the device (normalised direction and 1/d correctly rounded: the bits
+ *                         Ray::new gives) — 24 bytes per ray cross the link instead of the 36 of a Ray struct.
+ *                         directions == NULL: `origins` points to n_rays Ray structs (bvhgpu_ray_f32 / _f64), used as they are.
+ *   offsets               n_rays + 1 entries, always written.
+ *   indices, indices_cap  written when the batch's hit total fits (total <= indices_cap); otherwise the call still succeeds,
+ *                         *total says what is needed and bvhgpu_traverse_host_indices fetches them (no second traversal).
+ *   flags                 0 or BVHGPU_TRAVERSE_COHERENT.
+ * The tree may still be building (bvhgpu_rebuild_flat_async_* with BVHGPU_HOST shapes): the ray upload does not wait for the build.
+ * The batch is walked in chunks (BVHGPU_TUNE_HOST_CHUNKS: by default three, the last one an eighth of the batch) on three streams — upload of
+ * chunk k+1, Ray::new + walk of chunk k, download of the offsets of chunk k-1 — with one host wait at the end; with pinned buffers (bvhgpu_host_alloc / _register) the copies are DMA at link
+ * speed.  Results are those of bvhgpu_traverse_* on the same rays, byte for byte.  Returns when everything is in the caller's buffers. */
+int bvhgpu_traverse_host_f32(bvhgpu_tree *tree, const float *origins, const float *directions, size_t n_rays, unsigned flags,
+                             uint32_t *offsets, uint32_t *indices, size_t indices_cap, uint64_t *total);
+int bvhgpu_traverse_host_f64(bvhgpu_tree *tree, const double *origins, const double *directions, size_t n_rays, unsigned flags,
+                             uint32_t *offsets, uint32_t *indices, size_t indices_cap, uint64_t *total);
+int bvhgpu_traverse_host_indices(bvhgpu_ctx *ctx, uint32_t *indices, size_t indices_cap);
+/* GpuBvh::build + traverse_batch of a frame in ONE call: bvhgpu_rebuild_flat_async_*(aabbs, BVHGPU_HOST) + bvhgpu_traverse_host_*, with the
+ * ray upload enqueued FIRST — it is the long pole (24 MB against the build's 3) and depends on nothing — so that the build (Bvh::build_par +
+ * flatten, bvh_impl.rs:40-96, flat_bvh.rs:240-319) runs underneath it.  Same results, same errors (NaN / inf shapes: BVHGPU_INVALID_ARG,
+ * nothing usable built). */
+int bvhgpu_build_traverse_host_f32(bvhgpu_tree *tree, const float *aabbs, size_t n, const float *origins, const float *directions, size_t n_rays,
+                                   unsigned flags, uint32_t *offsets, uint32_t *indices, size_t indices_cap, uint64_t *total);
+int bvhgpu_build_traverse_host_f64(bvhgpu_tree *tree, const double *aabbs, size_t n, const double *origins, const double *directions, size_t n_rays,
+                                   unsigned flags, uint32_t *offsets, uint32_t *indices, size_t indices_cap, uint64_t *total);
 int bvhgpu_traverse_async_f32(bvhgpu_tree *tree, const bvhgpu_ray_f32 *rays, size_t n_rays, int mem, unsigned flags,
                               bvhgpu_hits **hits);
 int bvhgpu_traverse_async_f64(bvhgpu_tree *tree, const bvhgpu_ray_f64 *rays, size_t n_rays, int mem, unsigned flags,
@@ -387,7 +425,19 @@ typedef enum {
                                               per group, 8 .. 64 = that many); 0 (default) = a launch per level throughout.  Measured on configs[1]: 64 per group builds in
                                               0.1886 - 0.1891 ms against 0.1876 - 0.1895 ms (the pass is a chain of dependent loads, not its launch boundary), 32 per group is
                                               slower (two tiles per workgroup) — kept selectable and parity-tested, off by default (profiles/r5_persist_ab.log) */
-    BVHGPU_TUNE_COUNT = 17
+    BVHGPU_TUNE_HOST_CHUNKS = 17,          /* bvhgpu_traverse_host_*: the batch is walked as this many chunks, so that the upload of one overlaps the walk of the
+                                              previous one and the download of the offsets of the one before (1 .. 16); 0 (default) = by batch size: 3 from 512 K
+                                              rays, 2 from 256 K, else 1.  The last chunk is an eighth of the batch (what is left to do when the upload ends) */
+    BVHGPU_TUNE_WIDE_MIN_RAYS_PER_WG = 18, /* variant 3, rays cut into 16 items, batches that fill at most a quarter of the chip's workgroup slots at one ray per lane
+                                              (up to 128 K rays): the rays are spread over all slots, down to this many rays per workgroup (multiple of 64; default
+                                              256); 0 = one ray per lane always */
+    BVHGPU_TUNE_HOST_ZERO_COPY = 19,       /* bvhgpu_traverse_host_* / bvhgpu_build_traverse_host_* on PINNED buffers (bvhgpu_host_alloc / _register): bit 1 = the device
+                                              writes offsets / indices straight into the caller's arrays (no download, no hop to a third stream); bit 0 = the device
+                                              reads the caller's ray arrays itself (Ray::new straight out of host memory, no staging copy).  Default 2: bit 0 moves the
+                                              bytes at link speed (56 GB/s) but the build running beside it slows down four-fold while a kernel streams host memory
+                                              (k_level 12 -> 50 µs: profiles/r6_host_zero_copy.log), so the copy engines keep the upload.  0 = copy engines both
+                                              ways.  Pageable buffers always go through the copy engines */
+    BVHGPU_TUNE_COUNT = 20
 } bvhgpu_tune;
 int bvhgpu_set_tuning(bvhgpu_ctx *ctx, int knob, int value);
 int bvhgpu_get_tuning(const bvhgpu_ctx *ctx, int knob, int *value);

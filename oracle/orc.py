@@ -94,6 +94,12 @@ def is_native() -> bool:
     return _native
 
 
+def library_path() -> str:
+    """the shared object every call of this module goes through right now (the portable -O2 build, or the native one after use_native())"""
+    lib()
+    return os.path.join(_HERE, "liboracle_native.so") if _native else _SO
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 

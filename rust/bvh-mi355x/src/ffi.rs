@@ -1,9 +1,9 @@
-//! Declarations of include/bvh_mi355x.h (ABI version 5), one for one.  Every function returns a `bvhgpu_status`
+//! Declarations of include/bvh_mi355x.h (ABI version 7), one for one.  Every function returns a `bvhgpu_status`
 //! (0 = OK) and never unwinds; `bvhgpu_last_error` gives the text of the last failure on a ctx.
 #![allow(non_camel_case_types, dead_code)]
 use core::ffi::{c_char, c_int, c_uint, c_void};
 
-pub const BVHGPU_ABI_VERSION: c_int = 6;
+pub const BVHGPU_ABI_VERSION: c_int = 7;
 pub const BVHGPU_NONE: u32 = u32::MAX; // flat_bvh.rs:51-53
 
 // bvhgpu_status
@@ -88,6 +88,10 @@ extern "C" {
     pub fn bvhgpu_device_alloc(ctx: *mut bvhgpu_ctx, bytes: usize, out: *mut *mut c_void) -> c_int;
     pub fn bvhgpu_device_free(ctx: *mut bvhgpu_ctx, ptr: *mut c_void) -> c_int;
     pub fn bvhgpu_device_copy(ctx: *mut bvhgpu_ctx, dst: *mut c_void, dst_mem: c_int, src: *const c_void, src_mem: c_int, bytes: usize) -> c_int;
+    pub fn bvhgpu_host_alloc(ctx: *mut bvhgpu_ctx, bytes: usize, out: *mut *mut c_void) -> c_int;
+    pub fn bvhgpu_host_free(ctx: *mut bvhgpu_ctx, ptr: *mut c_void) -> c_int;
+    pub fn bvhgpu_host_register(ctx: *mut bvhgpu_ctx, ptr: *mut c_void, bytes: usize) -> c_int;
+    pub fn bvhgpu_host_unregister(ctx: *mut bvhgpu_ctx, ptr: *mut c_void) -> c_int;
     // build: Bvh::build / build_par / build_with_executor (bvh_impl.rs:40-96)
     pub fn bvhgpu_build_f32(ctx: *mut bvhgpu_ctx, aabbs: *const f32, n: usize, mem: c_int, out: *mut *mut bvhgpu_tree) -> c_int;
     pub fn bvhgpu_build_f64(ctx: *mut bvhgpu_ctx, aabbs: *const f64, n: usize, mem: c_int, out: *mut *mut bvhgpu_tree) -> c_int;
@@ -142,6 +146,11 @@ extern "C" {
     // traverse: FlatBvh::traverse (flat_bvh.rs:396-431) for a batch → CSR
     pub fn bvhgpu_traverse_f32(t: *mut bvhgpu_tree, rays: *const bvhgpu_ray_f32, n_rays: usize, mem: c_int, flags: c_uint, hits: *mut *mut bvhgpu_hits) -> c_int;
     pub fn bvhgpu_traverse_f64(t: *mut bvhgpu_tree, rays: *const bvhgpu_ray_f64, n_rays: usize, mem: c_int, flags: c_uint, hits: *mut *mut bvhgpu_hits) -> c_int;
+    pub fn bvhgpu_traverse_host_f32(t: *mut bvhgpu_tree, origins: *const f32, directions: *const f32, n_rays: usize, flags: c_uint, offsets: *mut u32, indices: *mut u32, indices_cap: usize, total: *mut u64) -> c_int;
+    pub fn bvhgpu_traverse_host_f64(t: *mut bvhgpu_tree, origins: *const f64, directions: *const f64, n_rays: usize, flags: c_uint, offsets: *mut u32, indices: *mut u32, indices_cap: usize, total: *mut u64) -> c_int;
+    pub fn bvhgpu_traverse_host_indices(ctx: *mut bvhgpu_ctx, indices: *mut u32, indices_cap: usize) -> c_int;
+    pub fn bvhgpu_build_traverse_host_f32(t: *mut bvhgpu_tree, aabbs: *const f32, n: usize, origins: *const f32, directions: *const f32, n_rays: usize, flags: c_uint, offsets: *mut u32, indices: *mut u32, indices_cap: usize, total: *mut u64) -> c_int;
+    pub fn bvhgpu_build_traverse_host_f64(t: *mut bvhgpu_tree, aabbs: *const f64, n: usize, origins: *const f64, directions: *const f64, n_rays: usize, flags: c_uint, offsets: *mut u32, indices: *mut u32, indices_cap: usize, total: *mut u64) -> c_int;
     pub fn bvhgpu_traverse_async_f32(t: *mut bvhgpu_tree, rays: *const bvhgpu_ray_f32, n_rays: usize, mem: c_int, flags: c_uint, hits: *mut *mut bvhgpu_hits) -> c_int;
     pub fn bvhgpu_traverse_async_f64(t: *mut bvhgpu_tree, rays: *const bvhgpu_ray_f64, n_rays: usize, mem: c_int, flags: c_uint, hits: *mut *mut bvhgpu_hits) -> c_int;
     pub fn bvhgpu_hits_wait(h: *mut bvhgpu_hits) -> c_int;

@@ -76,6 +76,11 @@ pub trait GpuScalar: BHValue + sealed::Sealed + Default + 'static {
 
     unsafe fn build_flat(ctx: *mut ffi::bvhgpu_ctx, aabbs: *const Self, n: usize, mem: c_int, out: *mut *mut ffi::bvhgpu_tree) -> c_int;
     unsafe fn rebuild_flat(t: *mut ffi::bvhgpu_tree, aabbs: *const Self, n: usize, mem: c_int) -> c_int;
+    unsafe fn rebuild_flat_async(t: *mut ffi::bvhgpu_tree, aabbs: *const Self, n: usize, mem: c_int) -> c_int;
+    #[allow(clippy::too_many_arguments)]
+    unsafe fn traverse_host(t: *mut ffi::bvhgpu_tree, origins: *const Self, directions: *const Self, n: usize, flags: c_uint, offsets: *mut u32, indices: *mut u32, cap: usize, total: *mut u64) -> c_int;
+    #[allow(clippy::too_many_arguments)]
+    unsafe fn build_traverse_host(t: *mut ffi::bvhgpu_tree, aabbs: *const Self, n_shapes: usize, origins: *const Self, directions: *const Self, n: usize, flags: c_uint, offsets: *mut u32, indices: *mut u32, cap: usize, total: *mut u64) -> c_int;
     unsafe fn refit(t: *mut ffi::bvhgpu_tree, aabbs: *const Self, n: usize, mem: c_int) -> c_int;
     unsafe fn traverse(t: *mut ffi::bvhgpu_tree, rays: *const Self::RayC, n: usize, mem: c_int, flags: c_uint, hits: *mut *mut ffi::bvhgpu_hits) -> c_int;
     unsafe fn set_triangles(t: *mut ffi::bvhgpu_tree, verts: *const Self, n: usize, mem: c_int) -> c_int;
@@ -89,7 +94,7 @@ pub trait GpuScalar: BHValue + sealed::Sealed + Default + 'static {
 
 macro_rules! impl_gpu_scalar {
     ($t:ty, $dtype:expr, $node:ident, $flat:ident, $ray:ident, $build_flat:ident, $rebuild_flat:ident, $refit:ident, $traverse:ident,
-     $set_tris:ident, $from_flat:ident, $flat_ctor:expr) => {
+     $set_tris:ident, $from_flat:ident, $rebuild_async:ident, $traverse_host:ident, $build_traverse_host:ident, $flat_ctor:expr) => {
         impl GpuScalar for $t {
             type Node = ffi::$node;
             type Flat = ffi::$flat;
@@ -100,6 +105,15 @@ macro_rules! impl_gpu_scalar {
             }
             unsafe fn rebuild_flat(t: *mut ffi::bvhgpu_tree, aabbs: *const $t, n: usize, mem: c_int) -> c_int {
                 ffi::$rebuild_flat(t, aabbs, n, mem)
+            }
+            unsafe fn rebuild_flat_async(t: *mut ffi::bvhgpu_tree, aabbs: *const $t, n: usize, mem: c_int) -> c_int {
+                ffi::$rebuild_async(t, aabbs, n, mem)
+            }
+            unsafe fn traverse_host(t: *mut ffi::bvhgpu_tree, origins: *const $t, directions: *const $t, n: usize, flags: c_uint, offsets: *mut u32, indices: *mut u32, cap: usize, total: *mut u64) -> c_int {
+                ffi::$traverse_host(t, origins, directions, n, flags, offsets, indices, cap, total)
+            }
+            unsafe fn build_traverse_host(t: *mut ffi::bvhgpu_tree, aabbs: *const $t, n_shapes: usize, origins: *const $t, directions: *const $t, n: usize, flags: c_uint, offsets: *mut u32, indices: *mut u32, cap: usize, total: *mut u64) -> c_int {
+                ffi::$build_traverse_host(t, aabbs, n_shapes, origins, directions, n, flags, offsets, indices, cap, total)
             }
             unsafe fn refit(t: *mut ffi::bvhgpu_tree, aabbs: *const $t, n: usize, mem: c_int) -> c_int {
                 ffi::$refit(t, aabbs, n, mem)
@@ -151,9 +165,11 @@ macro_rules! impl_gpu_scalar {
 }
 impl_gpu_scalar!(f32, ffi::BVHGPU_F32, bvhgpu_node_f32, bvhgpu_flat_f32, bvhgpu_ray_f32, bvhgpu_build_flat_f32, bvhgpu_rebuild_flat_f32,
                  bvhgpu_refit_f32, bvhgpu_traverse_f32, bvhgpu_tree_set_triangles_f32, bvhgpu_tree_from_flat_f32,
+                 bvhgpu_rebuild_flat_async_f32, bvhgpu_traverse_host_f32, bvhgpu_build_traverse_host_f32,
                  |min, max, entry, exit, shape| ffi::bvhgpu_flat_f32 { min, max, entry, exit, shape });
 impl_gpu_scalar!(f64, ffi::BVHGPU_F64, bvhgpu_node_f64, bvhgpu_flat_f64, bvhgpu_ray_f64, bvhgpu_build_flat_f64, bvhgpu_rebuild_flat_f64,
                  bvhgpu_refit_f64, bvhgpu_traverse_f64, bvhgpu_tree_set_triangles_f64, bvhgpu_tree_from_flat_f64,
+                 bvhgpu_rebuild_flat_async_f64, bvhgpu_traverse_host_f64, bvhgpu_build_traverse_host_f64,
                  |min, max, entry, exit, shape| ffi::bvhgpu_flat_f64 { min, max, entry, exit, shape, _pad: 0 });
 
 fn aabb_to_6<T: GpuScalar>(b: &Aabb<T, 3>) -> [T; 6] {
@@ -171,6 +187,8 @@ pub struct GpuBvh<T: GpuScalar> {
     n_shapes: usize,
     /// CPU copy of the flat array in the crate's own layout, for the generic queries of the trait
     flat: FlatBvh<T, 3>,
+    /// `rebuild_async` ran and `sync_flat` has not: the CPU copy is the previous tree's
+    flat_stale: bool,
 }
 /// `BoundingHierarchy<f32, 3>` on the GPU (BASELINE configs[1]-[3])
 pub type GpuBvh32 = GpuBvh<f32>;
@@ -194,6 +212,30 @@ pub struct ClosestHit<T> {
     pub shape: u32,
 }
 
+/// A fixed-length slice in pinned host memory (`bvhgpu_host_alloc` / `bvhgpu_host_free`); derefs to `[U]`.  Must not outlive the
+/// `GpuBvh` it came from.
+pub struct PinnedVec<U> {
+    ctx: *mut ffi::bvhgpu_ctx,
+    ptr: *mut U,
+    len: usize,
+}
+impl<U> core::ops::Deref for PinnedVec<U> {
+    type Target = [U];
+    fn deref(&self) -> &[U] {
+        unsafe { core::slice::from_raw_parts(self.ptr, self.len) }
+    }
+}
+impl<U> core::ops::DerefMut for PinnedVec<U> {
+    fn deref_mut(&mut self) -> &mut [U] {
+        unsafe { core::slice::from_raw_parts_mut(self.ptr, self.len) }
+    }
+}
+impl<U> Drop for PinnedVec<U> {
+    fn drop(&mut self) {
+        unsafe { ffi::bvhgpu_host_free(self.ctx, self.ptr.cast()) };
+    }
+}
+
 impl<T: GpuScalar> GpuBvh<T> {
     /// Bvh::build_par + Bvh::flatten on GPU `device` from the shapes' AABBs (n x [min xyz, max xyz])
     pub fn from_aabbs(aabbs: &[[T; 6]], device: i32) -> GpuBvh<T> {
@@ -203,7 +245,7 @@ impl<T: GpuScalar> GpuBvh<T> {
             check(ctx, ffi::bvhgpu_create(device, core::ptr::null_mut(), &mut ctx));
             check(ctx, T::build_flat(ctx, aabbs.as_ptr().cast(), aabbs.len(), ffi::BVHGPU_HOST, &mut tree));
         }
-        let mut me = GpuBvh { ctx, tree, device, n_shapes: aabbs.len(), flat: Vec::new() };
+        let mut me = GpuBvh { ctx, tree, device, n_shapes: aabbs.len(), flat: Vec::new(), flat_stale: false };
         me.flat = me.download_flat();
         me
     }
@@ -237,19 +279,75 @@ impl<T: GpuScalar> GpuBvh<T> {
 
     /// `FlatBvh::traverse` (src/flat_bvh.rs:396-431) for many rays at once — what the GPU is for
     pub fn traverse_batch(&self, rays: &[Ray<T, 3>]) -> BatchHits {
+        // `bvhgpu_traverse_host_*` with directions == NULL: the crate's own Ray structs (origin, direction, inv_direction), uploaded in
+        // chunks beside the walk of the previous chunk, CSR offsets downloaded behind it — one call, one host wait
         let r: Vec<T::RayC> = rays.iter().map(T::ray_to_ffi).collect();
-        let mut hits = core::ptr::null_mut();
+        self.host_batch(r.as_ptr().cast(), core::ptr::null(), r.len())
+    }
+
+    /// The same for rays given as origins and directions (what `Ray::new` takes, src/ray/ray_impl.rs:70-80): `Ray::new` runs on the
+    /// device — the correctly rounded divide and square root give its bits — and 24 bytes per ray cross the link instead of 36.
+    /// With both slices in pinned memory (`PinnedVec`) the copies are DMA at link speed.
+    pub fn traverse_batch_od(&self, origins: &[[T; 3]], directions: &[[T; 3]]) -> BatchHits {
+        assert_eq!(origins.len(), directions.len(), "one direction per origin");
+        self.host_batch(origins.as_ptr().cast(), directions.as_ptr().cast(), origins.len())
+    }
+
+    /// One frame of a host-resident caller in one call: `rebuild(aabbs)` + `traverse_batch_od(origins, directions)`, the ray upload
+    /// enqueued before the build so that the build runs underneath it (`bvhgpu_build_traverse_host_*`).  The CPU copy the trait's
+    /// generic queries walk is refreshed by `sync_flat()`.
+    pub fn rebuild_and_traverse(&mut self, aabbs: &[[T; 6]], origins: &[[T; 3]], directions: &[[T; 3]]) -> BatchHits {
+        assert_eq!(origins.len(), directions.len(), "one direction per origin");
+        let n = origins.len();
+        let mut offsets = vec![0u32; n + 1];
+        let mut indices = vec![0u32; n.max(1 << 16)];
         let mut total = 0u64;
         unsafe {
-            check(self.ctx, T::traverse(self.tree, r.as_ptr(), r.len(), ffi::BVHGPU_HOST, 0, &mut hits));
-            check(self.ctx, ffi::bvhgpu_hits_info(hits, core::ptr::null_mut(), &mut total, core::ptr::null_mut()));
+            check(self.ctx, T::build_traverse_host(self.tree, aabbs.as_ptr().cast(), aabbs.len(), origins.as_ptr().cast(), directions.as_ptr().cast(), n, 0,
+                                                   offsets.as_mut_ptr(), indices.as_mut_ptr(), indices.len(), &mut total));
+            if total as usize > indices.len() {
+                indices.resize(total as usize, 0);
+                check(self.ctx, ffi::bvhgpu_traverse_host_indices(self.ctx, indices.as_mut_ptr(), indices.len()));
+            }
         }
-        let (mut offsets, mut indices) = (vec![0u32; rays.len() + 1], vec![0u32; total as usize]);
-        unsafe {
-            check(self.ctx, ffi::bvhgpu_hits_fetch(hits, offsets.as_mut_ptr(), indices.as_mut_ptr(), core::ptr::null_mut(), ffi::BVHGPU_HOST));
-            ffi::bvhgpu_hits_destroy(hits);
-        }
+        self.n_shapes = aabbs.len();
+        self.flat_stale = true;
+        indices.truncate(total as usize);
         BatchHits { offsets, indices }
+    }
+
+    fn host_batch(&self, origins: *const T, directions: *const T, n: usize) -> BatchHits {
+        let mut offsets = vec![0u32; n + 1];
+        let mut indices = vec![0u32; n.max(1 << 16)];
+        let mut total = 0u64;
+        unsafe {
+            check(self.ctx, T::traverse_host(self.tree, origins, directions, n, 0, offsets.as_mut_ptr(), indices.as_mut_ptr(), indices.len(), &mut total));
+            if total as usize > indices.len() {
+                indices.resize(total as usize, 0);
+                check(self.ctx, ffi::bvhgpu_traverse_host_indices(self.ctx, indices.as_mut_ptr(), indices.len()));
+            }
+        }
+        indices.truncate(total as usize);
+        BatchHits { offsets, indices }
+    }
+
+    /// `rebuild` without the wait: the build is enqueued and the call returns; a `traverse_batch*` that follows uploads its rays
+    /// beside it.  `aabbs` must stay untouched until the next call that looks at the tree (pinned memory: the copy is asynchronous).
+    pub fn rebuild_async(&mut self, aabbs: &[[T; 6]]) {
+        unsafe { check(self.ctx, T::rebuild_flat_async(self.tree, aabbs.as_ptr().cast(), aabbs.len(), ffi::BVHGPU_HOST)); }
+        self.n_shapes = aabbs.len();
+        self.flat_stale = true;
+    }
+
+    /// Pinned host memory for `n` elements on this hierarchy's ctx (`bvhgpu_host_alloc`): read and written by the DMA engines directly
+    pub fn pinned<U: Copy + Default>(&self, n: usize) -> PinnedVec<U> {
+        let mut p = core::ptr::null_mut();
+        unsafe { check(self.ctx, ffi::bvhgpu_host_alloc(self.ctx, n * core::mem::size_of::<U>(), &mut p)); }
+        let v = PinnedVec { ctx: self.ctx, ptr: p.cast::<U>(), len: n };
+        for i in 0..n {
+            unsafe { v.ptr.add(i).write(U::default()) };
+        }
+        v
     }
 
     /// The triangle stage needs the vertices (one triangle per shape, n x [a xyz, b xyz, c xyz]): src/testbase.rs:325-333
@@ -279,6 +377,13 @@ impl<T: GpuScalar> GpuBvh<T> {
         unsafe { check(self.ctx, T::rebuild_flat(self.tree, aabbs.as_ptr().cast(), aabbs.len(), ffi::BVHGPU_HOST)); }
         self.n_shapes = aabbs.len();
         self.flat = self.download_flat();
+        self.flat_stale = false;
+    }
+
+    /// After `rebuild_async`: wait for the build and refresh the CPU copy the trait's generic queries walk
+    pub fn sync_flat(&mut self) {
+        self.flat = self.download_flat();
+        self.flat_stale = false;
     }
 
     /// the shapes moved, the topology stays: `Bvh::fix_aabbs_ascending` (src/bvh/optimization.rs:355-391) over the whole tree
@@ -324,6 +429,7 @@ impl<T: GpuScalar> BoundingHierarchy<T, 3> for GpuBvh<T> {
     ) -> Vec<&'a Shape> {
         // one generic query: the crate's own loop over the downloaded flat array (src/flat_bvh.rs:396-431);
         // ray BATCHES go through `traverse_batch`
+        assert!(!self.flat_stale, "rebuild_async: call sync_flat() before a generic query");
         self.flat.traverse(query, shapes)
     }
 

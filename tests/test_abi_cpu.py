@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(built):
     nm = subprocess.run(["nm", "-D", "--defined-only", built.SO_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (bvhgpu_[a-z0-9_]+)", nm))
     assert set(declared) <= exported
-    assert lib.bvhgpu_abi_version() == built.ABI_VERSION == 6
+    assert lib.bvhgpu_abi_version() == built.ABI_VERSION == 7
 
 
 def test_library_contains_gfx950_code_object(built):
