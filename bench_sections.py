@@ -400,8 +400,9 @@ def measure_excluded(wl, args, env, ms_step):
     (device sync on both sides):
       with_ray_gen      Ray::new for every ray of the batch (ray_impl.rs:70-80 via create_ray, testbase.rs:687-691: the reference's
                         bench iteration starts with it) generated on the device inside the step — k_gen_rays on the step's stream
-      lazy_flat_array   the reverse case: the step of `value` writes the reference-layout FlatNode array + the folded binary array in
-                        every flatten (flat_bvh.rs:60-143); with BVHGPU_TUNE_FLATTEN_LAZY = 1 they follow on first use instead
+      lazy / eager / beside_flat_array   the step of `value` writes the reference-layout FlatNode array + the folded binary array in every
+                        step (flat_bvh.rs:60-143; --flat-array); the other ways: on first use (lazy: NOT in the step), in the flatten kernel
+                        itself (eager), by a second pass on the side stream beside the walk (beside)
       host_io           shape AABBs and rays start in HOST memory, the CSR ends in host memory: what GpuBvh::build + traverse_batch
                         of the Rust shim costs a caller whose data lives in Vecs (rust/bvh-mi355x/src/lib.rs) — upload, step, download"""
     import torch
@@ -438,14 +439,18 @@ def measure_excluded(wl, args, env, ms_step):
     res["with_ray_gen"] = entry(timed(step_gen, K))
 
     prev = ctx.get_tuning(TUNE_FLATTEN_LAZY)
-    ctx.set_tuning(TUNE_FLATTEN_LAZY, 1)
-    try:
-        def step_lazy():
-            bvh.rebuild_async(wl.aabbs)
-            return bvh.traverse_async(wl.rays, flags=TRAVERSE_RAYS_READY).wait()
-        res["lazy_flat_array"] = entry(timed(step_lazy, K))
-    finally:
-        ctx.set_tuning(TUNE_FLATTEN_LAZY, prev)
+
+    def step_index():
+        bvh.rebuild_async(wl.aabbs)
+        return bvh.traverse_async(wl.rays, flags=TRAVERSE_RAYS_READY).wait()
+    for mode, key in ((1, "lazy_flat_array"), (0, "eager_flat_array"), (2, "beside_flat_array")):
+        if mode == prev:
+            continue
+        ctx.set_tuning(TUNE_FLATTEN_LAZY, mode)
+        try:
+            res[key] = entry(timed(step_index, K))
+        finally:
+            ctx.set_tuning(TUNE_FLATTEN_LAZY, prev)
 
     res["host_io"] = host_io_steps(wl, env, bvh, timed, entry, K)
     bvh.close()

@@ -2169,6 +2169,7 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     using Key = typename Tr::Key;
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
+    join_flat(t);   // (a flatten part still running on the side stream reads the arrays this build is about to overwrite)
     t->built = false; t->flattened = false; t->lazy_flat = false; t->pending_build = false; t->exact_only = false; t->pending_recv = false;
     t->pend_persist = false;
     if (!redo) t->gen++;   // results enqueued from here on belong to this build (bvhgpu_hits_wait compares generations)
@@ -2277,6 +2278,7 @@ template <typename T> void build_finalize(bvhgpu_tree* t) {
     t->pending_build = false;
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
+    join_flat(t);
     BVH_HIP(hipStreamSynchronize(st));
     BVH_HIP(hipGetLastError());
     const size_t n = t->n;

@@ -68,6 +68,7 @@ void copy_out(bvhgpu_ctx* ctx, void* dst, const void* src_dev, size_t bytes, int
 }
 
 void free_tree_buffers(bvhgpu_tree* t) {
+    if (t->flat_beside && t->ctx && t->ctx->side) { (void)hipStreamSynchronize(t->ctx->side); t->flat_beside = false; }
     t->aabbs.release(); t->nodes.release(); t->node_start.release(); t->node_count.release();
     t->xbar.release(); t->shape_node.release(); t->flat.release(); t->trav.release(); t->slot_entry.release(); t->node_slot.release(); t->tris.release();
     t->idx[0].release(); t->idx[1].release(); t->bk.release(); t->lvbuf.release();
@@ -76,6 +77,8 @@ void free_tree_buffers(bvhgpu_tree* t) {
     t->tile_item[0].release(); t->tile_item[1].release(); t->tile_cnt.release(); t->ctr.release(); t->refit_seg.release();
     t->wide.release(); t->wslot_node.release(); t->wide_guide.release(); t->guide_info.release();
     t->bstat.release();
+    if (t->ev_flat0) { (void)hipEventDestroy(t->ev_flat0); t->ev_flat0 = nullptr; }
+    if (t->ev_flat) { (void)hipEventDestroy(t->ev_flat); t->ev_flat = nullptr; }
     if (t->ev_top) { (void)hipEventDestroy(t->ev_top); t->ev_top = nullptr; }
     if (t->pin) { (void)hipHostFree(t->pin); t->pin = nullptr; }
     if (t->pin_recv) { (void)hipHostFree(t->pin_recv); t->pin_recv = nullptr; }
@@ -182,6 +185,7 @@ template <typename T> int do_refit(bvhgpu_tree* t, const T* aabbs, size_t n, int
     ensure_built(t);
     settle_waiters_impl(t);
     if (!t->built) return fail(ctx, BVHGPU_INVALID_ARG, "refit needs a tree that was built here (imported scenes carry no BvhNode array)");
+    join_flat(t);
     if (n != t->n) return fail(ctx, BVHGPU_INVALID_ARG, "refit: the number of shapes differs from the tree's (build again)");
     if (n && !aabbs) return fail(ctx, BVHGPU_INVALID_ARG, "aabbs is NULL");
     if (mem != BVHGPU_HOST && mem != BVHGPU_DEVICE) return fail(ctx, BVHGPU_INVALID_ARG, "bad mem kind");

@@ -99,6 +99,8 @@ struct bvhgpu_tree {
     bool flattened = false; // has trav (+ flat if built) — or owes them: see lazy_flat
     bool lazy_flat = false; // the flatten of this generation wrote the wide walk's arrays only (BVHGPU_TUNE_FLATTEN_LAZY): flat / trav /
                             // slot_entry are written by ensure_flat_arrays() the first time something reads them
+    bool flat_beside = false;   // part 1 of this generation's flatten (flat / trav / slot_entry) is in flight on the ctx's SIDE stream
+    hipEvent_t ev_flat0 = nullptr, ev_flat = nullptr;   // (BVHGPU_TUNE_FLATTEN_LAZY = 2): main → side, side → main (join_flat)
     bool unfolded = false;  // trav mirrors an uploaded FlatBvh 1:1 (nav and leaf entries kept apart)
     bool ctr_ready = false; // build counters / root keys were reset by the previous build
     bool pending_build = false;  // build_enqueue ran, build_finalize has not (asynchronous entry points)
@@ -240,6 +242,9 @@ template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr = null
 // the FlatNode array, the folded binary array and the binary walk's LDS slot table of a tree whose flatten was lazy: enqueued on the
 // tree's stream now (a no-op for every other tree).  Everything that reads t->flat / t->trav / t->slot_entry calls this first.
 void ensure_flat_arrays(bvhgpu_tree* t);
+// BVHGPU_TUNE_FLATTEN_LAZY = 2: the main stream waits for the part of the flatten that runs on the side stream (a no-op otherwise).  Called
+// behind the walk a batch enqueues (so that the batch's wait covers it), and before anything reads those arrays or overwrites what they are made from.
+void join_flat(bvhgpu_tree* t);
 constexpr uint32_t BSTAT_NONFINITE = 1u, BSTAT_EMPTY_SPLIT = 2u;   // = build.hip BUILD_FLAG_*
 constexpr uint32_t BSTAT_UNFINISHED = 0x100u;
 constexpr int BUILD_CTR_TOPMASK = 5;   // u32 slot of the build counters: bit h = the level tier wrote the BvhNode of heap number h (h < 16)                      // the optimistic schedule left nodes in the level queue

@@ -311,10 +311,11 @@ template void wide_from_trav<float>(bvhgpu_tree*);
 template void wide_from_trav<double>(bvhgpu_tree*);
 
 template <typename T, int PARTS> static void launch_flatten(bvhgpu_tree* t, bool with_wide, bool with_guide, uint32_t* pub_ctr, uint32_t* pub_host,
-                                                             uint32_t pub_words, uint32_t* bstat, uint32_t flags_idx, uint32_t level_idx) {
+                                                             uint32_t pub_words, uint32_t* bstat, uint32_t flags_idx, uint32_t level_idx,
+                                                             hipStream_t st = nullptr) {
     using Tr = Traits<T>;
     const uint32_t nn = (uint32_t)t->n_nodes;
-    hipLaunchKernelGGL((k_flatten<T, PARTS>), dim3((nn + 255) / 256), dim3(256), 0, t->ctx->stream,
+    hipLaunchKernelGGL((k_flatten<T, PARTS>), dim3((nn + 255) / 256), dim3(256), 0, st ? st : t->ctx->stream,
                        t->nodes.as<typename Tr::Node>(), t->node_start.as<uint32_t>(), t->node_count.as<uint32_t>(),
                        t->aabbs.as<T>(), t->node_slot.as<uint16_t>(), t->slot_entry.as<uint32_t>(),
                        t->flat.as<typename Tr::Flat>(),
@@ -324,9 +325,34 @@ template <typename T, int PARTS> static void launch_flatten(bvhgpu_tree* t, bool
     BVH_HIP(hipGetLastError());
 }
 
+void join_flat(bvhgpu_tree* t) {
+    if (!t->flat_beside) return;
+    t->flat_beside = false;
+    BVH_HIP(hipStreamWaitEvent(t->ctx->stream, t->ev_flat, 0));
+}
+
+// BVHGPU_TUNE_FLATTEN_LAZY = 2: part 1 of the flatten at once, but on the ctx's side stream — the walk that follows on the main stream reads
+// none of what it writes (flat / trav / the binary slot table), both only read the BvhNode array, and the 20 MB it streams out fit beside
+// a walk that is bound by instruction issue
+template <typename T> static void flat_beside(bvhgpu_tree* t) {
+    bvhgpu_ctx* ctx = t->ctx;
+    if (!ctx->side) BVH_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    if (!t->ev_flat0) BVH_HIP(hipEventCreateWithFlags(&t->ev_flat0, hipEventDisableTiming));
+    if (!t->ev_flat) BVH_HIP(hipEventCreateWithFlags(&t->ev_flat, hipEventDisableTiming));
+    t->flat.reserve(t->n_flat * sizeof(typename Traits<T>::Flat));
+    t->trav.reserve(t->n_trav * sizeof(TravNode<T>));
+    BVH_HIP(hipEventRecord(t->ev_flat0, ctx->stream));
+    BVH_HIP(hipStreamWaitEvent(ctx->side, t->ev_flat0, 0));
+    launch_flatten<T, FLATTEN_FLAT>(t, false, false, nullptr, nullptr, 0, nullptr, 0, 0, ctx->side);
+    BVH_HIP(hipEventRecord(t->ev_flat, ctx->side));
+    t->lazy_flat = false;
+    t->flat_beside = true;
+}
+
 template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr, uint32_t* pub_host, uint32_t pub_words, uint32_t* bstat,
                                         uint32_t flags_idx, uint32_t level_idx, bool wide_only) {
     using Tr = Traits<T>;
+    join_flat(t);
     t->lazy_flat = false;
     if (t->n == 0) { t->flattened = true; return; }
     // the wide nodes come out of the same pass (their LDS slot table was cleared by the build's first kernel)
@@ -338,6 +364,7 @@ template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr, uint3
     if (wide_only && with_wide) {   // (a tree without wide nodes is walked by the binary kernels: nothing to postpone)
         launch_flatten<T, FLATTEN_WIDE>(t, true, with_guide, pub_ctr, pub_host, pub_words, bstat, flags_idx, level_idx);
         t->lazy_flat = true;
+        if (t->ctx->tune[BVHGPU_TUNE_FLATTEN_LAZY] == 2) flat_beside<T>(t);
     } else {
         t->flat.reserve(t->n_flat * sizeof(typename Tr::Flat));
         t->trav.reserve(t->n_trav * sizeof(TravNode<T>));
@@ -351,6 +378,7 @@ template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr, uint3
 // part 1 of a lazy flatten, on the tree's stream (behind the build and the wide-only pass if they are still in flight: on an unfinished
 // tree build_finalize flattens again, completely).  The slot table k_prep cleared is filled here.
 void ensure_flat_arrays(bvhgpu_tree* t) {
+    join_flat(t);
     if (!t->lazy_flat) return;
     t->lazy_flat = false;
     if (t->dtype == BVHGPU_F32) {

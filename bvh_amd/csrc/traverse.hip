@@ -1978,6 +1978,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         if (ctx->timing) BVH_HIP(hipEventRecord(ctx->ev[6], st));
         hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);   // readback + reset for the next call
         h->ctr_clean = true;
+        join_flat(t);
         return;
     }
 
@@ -2113,6 +2114,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         h->ctr_set ^= 1;   // the set that was just zeroed
     }
     h->ctr_clean = true;
+    join_flat(t);   // (BVHGPU_TUNE_FLATTEN_LAZY = 2: the flatten part that ran beside this walk — the batch's wait covers it)
 #undef DISPATCH_WALK
 }
 

@@ -419,7 +419,8 @@ typedef enum {
                                               reads (wide nodes, their LDS slot table, an f64 tree's guide nodes); the reference-layout FlatNode array and the
                                               folded binary array are written by a second pass the first time something asks for them (bvhgpu_flat_nodes,
                                               a binary / STATS / t-slice / ordered walk, nearest_to, scene export, a broadcast) — same arrays, byte for byte;
-                                              0 = every flatten writes everything at once */
+                                              0 = every flatten writes everything at once; 2 = every flatten writes everything, the second pass on the ctx's side
+                                              stream BESIDE the walk that follows (the walk reads none of it); the batch's wait covers it */
     BVHGPU_TUNE_BUILD_LEVEL_PERSIST = 16,  /* builder, level tier with one launch per level, scenes of 32 x 769 shapes and more: != 0 = the tier's passes from tree level 4 on run as
                                               ONE persistent launch, a workgroup group per level-3 subtree that synchronises with itself after every pass (1 = 32 workgroups
                                               per group, 8 .. 64 = that many); 0 (default) = a launch per level throughout.  Measured on configs[1]: 64 per group builds in
