@@ -460,10 +460,10 @@ def measure_excluded(wl, args, env, ms_step):
 def host_io_steps(wl, env, bvh, timed, entry, K):
     """host-resident callers (the drop-in boundary as a Rust caller meets it): inputs in host memory, CSR back in host memory, inside
     every step.  "pageable" = the synchronous entry points on plain host arrays (bvhgpu_rebuild_flat + bvhgpu_traverse +
-    bvhgpu_hits_fetch: Ray structs, 36 B per ray); "pinned" = ABI 7's bvhgpu_build_traverse_host on pinned buffers (bvhgpu_host_alloc):
-    origins + directions only (24 B per ray, Ray::new on the device), the ray upload in chunks beside the build, the walk of a chunk beside
-    the upload of the next, offsets / indices written into the caller's arrays by the device.  Median of 5 blocks of steps (a host
-    thread of a shared box is descheduled for tens of ms now and then: one such stall in one block must not become the figure)."""
+    bvhgpu_hits_fetch: Ray structs, 36 B per ray); "pinned" = ABI 7's host batch on pinned buffers (bvhgpu_host_alloc): origin + direction
+    only (24 B per ray, one array, Ray::new on the device), the ray upload in chunks beside the build, the walk of a chunk beside the upload
+    of the next, offsets / indices written into the caller's arrays by the device — as two calls and as one.  Median of 5 blocks of
+    steps (a host thread of a shared box is descheduled for tens of ms now and then: one stall in one block must not become the figure)."""
     import torch
     from bvh_amd import HostStep, RayBatch
     from bvh_amd._lib import RAY_F32, RAY_F64
@@ -492,7 +492,7 @@ def host_io_steps(wl, env, bvh, timed, entry, K):
     # origins and un-normalised directions whose Ray::new is the batch's rays: the stream's raw points (create_ray, testbase.rs:687-691)
     from bvh_amd import testbase as tb
     k = np.arange(wl.first, wl.first + wl.R, dtype=np.uint64)
-    hs = HostStep(bvh, wl.n_tri, wl.R, wl.np_dtype)
+    hs = HostStep(bvh, wl.n_tri, wl.R, wl.np_dtype, od6=True)     # origin and direction side by side: one transfer per chunk
     hs.aabbs[:] = a_host
     if wl.cam is None:
         hs.origins[:] = tb.next_point3_at(2 * k + 1, wl.bounds).astype(wl.np_dtype)
@@ -500,15 +500,17 @@ def host_io_steps(wl, env, bvh, timed, entry, K):
     else:       # (a camera batch: the normalised directions; Ray::new of a unit vector need not give its bits back — not compared below)
         hs.origins[:] = rays_np["o"]
         hs.directions[:] = rays_np["d"]
-    off2, idx2 = hs.run()
-    same = bool(np.array_equal(off, off2) and np.array_equal(idx, idx2)) if wl.cam is None else None
-    nb2 = {"aabbs_up": int(a_host.nbytes), "rays_up": int(hs.origins.nbytes + hs.directions.nbytes),
-           "csr_down": int(off2.nbytes + idx2.nbytes)}
-    ms2, blocks2 = median_of_blocks(hs.run)
-    e2 = entry(ms2)
-    e2.update(steps=kh, blocks_ms=blocks2, bytes_per_step=nb2, pcie_gbs=round(sum(nb2.values()) / (ms2 * 1e-3) / 1e9, 2),
-              csr_equal_to_pageable_path=same)
-    out["pinned"] = e2
+    for key, fused in (("pinned", False), ("pinned_one_call", True)):
+        # two calls = GpuBvh::rebuild_async + traverse_batch_od6 of the Rust shim (bvhgpu_rebuild_flat_async + bvhgpu_traverse_host);
+        # one call = bvhgpu_build_traverse_host (shapes and rays through the same upload stream, the build behind an event)
+        off2, idx2 = hs.run(fused=fused)
+        same = bool(np.array_equal(off, off2) and np.array_equal(idx, idx2)) if wl.cam is None else None
+        nb2 = {"aabbs_up": int(a_host.nbytes), "rays_up": int(hs.od.nbytes), "csr_down": int(off2.nbytes + idx2.nbytes)}
+        ms2, blocks2 = median_of_blocks(lambda: hs.run(fused=fused))
+        e2 = entry(ms2)
+        e2.update(steps=kh, blocks_ms=blocks2, bytes_per_step=nb2, pcie_gbs=round(sum(nb2.values()) / (ms2 * 1e-3) / 1e9, 2),
+                  csr_equal_to_pageable_path=same)
+        out[key] = e2
     hs.close()
     best = max(out.values(), key=lambda q: q["value"])
     return dict(best, paths=out)

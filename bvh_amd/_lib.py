@@ -164,6 +164,7 @@ TUNE_WIDE_MIN_RAYS_PER_WG = 18   # wide walk over items, batches below 512 K ray
 TUNE_HOST_ZERO_COPY = 19         # host batches on pinned buffers: bit 0 the device reads the ray arrays itself, bit 1 it writes offsets / indices itself (2 default)
 TUNE_HOST_CHUNKS = 17            # bvhgpu_traverse_host_*: chunks the batch is walked in (0, default = by batch size)
 TUNE_BUILD_LEVEL_PERSIST = 16    # builder, level tier: tree levels 3.. of the tier as ONE persistent launch, one level-3 subtree per XCD (1) or a launch per level (0)
+TRAVERSE_RAYS_OD6 = 512
 WALK_WIDE, WALK_STAGED, WALK_REC8, WALK_F64_GUIDE = 1, 2, 4, 8   # bvhgpu_hits_walk_info
 ABI_VERSION = 7
 

@@ -166,11 +166,14 @@ class HostStep:
     and directions in; CSR offsets / indices out.  run() = GpuBvh::build + traverse_batch of the Rust shim in one call
     (bvhgpu_build_traverse_host_*): the ray upload overlaps the build, Ray::new runs on the device."""
 
-    def __init__(self, bvh: "Bvh", n_shapes: int, n_rays: int, dtype=np.float32, index_cap: Optional[int] = None):
+    def __init__(self, bvh: "Bvh", n_shapes: int, n_rays: int, dtype=np.float32, index_cap: Optional[int] = None, od6: bool = False):
+        """od6: origin and direction of a ray side by side in ONE pinned array (`od`, n x 6; `origins` / `directions` are views of its
+        halves) — BVHGPU_TRAVERSE_RAYS_OD6: one transfer per chunk instead of two"""
         self.bvh, ctx = bvh, bvh.ctx
         self.aabbs = pinned_array(ctx, (n_shapes, 6), dtype)
-        self.origins = pinned_array(ctx, (n_rays, 3), dtype)
-        self.directions = pinned_array(ctx, (n_rays, 3), dtype)
+        self.od = pinned_array(ctx, (n_rays, 6), dtype) if od6 else None
+        self.origins = self.od[:, :3] if od6 else pinned_array(ctx, (n_rays, 3), dtype)
+        self.directions = self.od[:, 3:] if od6 else pinned_array(ctx, (n_rays, 3), dtype)
         self.offsets = pinned_array(ctx, (n_rays + 1,), np.uint32)
         self.indices = pinned_array(ctx, (index_cap or max(n_rays, 1 << 16),), np.uint32)
         self.total = 0
@@ -180,15 +183,19 @@ class HostStep:
         bvhgpu_rebuild_flat_async_*(HOST) + bvhgpu_traverse_host_*"""
         if not fused:
             self.bvh.rebuild_async(self.aabbs)
-        self.total = self.bvh.traverse_host(self.origins, self.directions, self.offsets, self.indices, coherent=coherent,
-                                            aabbs=self.aabbs if fused else None)
+        if self.od is not None:
+            self.total = self.bvh.traverse_host(self.od, None, self.offsets, self.indices, coherent=coherent, aabbs=self.aabbs if fused else None,
+                                                od6=True)
+        else:
+            self.total = self.bvh.traverse_host(self.origins, self.directions, self.offsets, self.indices, coherent=coherent,
+                                                aabbs=self.aabbs if fused else None)
         if self.total > self.indices.size:
             self.indices = pinned_array(self.bvh.ctx, (self.total + self.total // 8,), np.uint32)
             self.bvh.traverse_host_indices(self.indices)
         return self.offsets, self.indices[:self.total]
 
     def close(self):
-        self.aabbs = self.origins = self.directions = self.offsets = self.indices = None
+        self.aabbs = self.origins = self.directions = self.od = self.offsets = self.indices = None
 
 
 def default_context() -> Context:
@@ -740,14 +747,19 @@ class Bvh(_TreeBase):
         check(fn(self._t, ptr(aabbs.data_ptr()), aabbs.numel() // 6, DEVICE), self.ctx._h)
         return self
 
-    def traverse_host(self, origins, directions, offsets: np.ndarray, indices: np.ndarray, coherent: bool = False, aabbs=None) -> int:
+    def traverse_host(self, origins, directions, offsets: np.ndarray, indices: np.ndarray, coherent: bool = False, aabbs=None,
+                      od6: bool = False) -> int:
         """bvhgpu_traverse_host_*: `for (o, d) in rays { flat.traverse(&Ray::new(o, d), shapes) }` for rays in host memory (n x 3 each;
         directions None: `origins` is an array of Ray structs), CSR written into the caller's `offsets` (n + 1) / `indices`; returns the
         hit total (indices are written when they fit: fetch with traverse_host_indices otherwise).  The tree may still be building.
-        aabbs (host array, n x 6): bvhgpu_build_traverse_host_* — the tree is rebuilt from them first, underneath the ray upload."""
+        aabbs (host array, n x 6): bvhgpu_build_traverse_host_* — the tree is rebuilt from them first, underneath the ray upload.
+        od6: `origins` is ONE array n x 6 = [o xyz, d xyz] per ray (BVHGPU_TRAVERSE_RAYS_OD6: one transfer per chunk), directions None."""
         lib = _lib.load()
         ft = np.float32 if self.sfx == "f32" else np.float64
-        if directions is None:
+        if od6:
+            assert directions is None and origins.dtype == ft and origins.flags.c_contiguous and origins.size % 6 == 0
+            n = origins.size // 6
+        elif directions is None:
             assert origins.dtype == _ray_dtype(self.sfx) and origins.flags.c_contiguous
             n = len(origins)
         else:
@@ -756,7 +768,8 @@ class Bvh(_TreeBase):
             assert directions.size == 3 * n
         assert offsets.dtype == np.uint32 and offsets.size >= n + 1 and indices.dtype == np.uint32
         total = C.c_uint64(0)
-        tail = (ptr(origins), ptr(directions) if directions is not None else None, n, TRAVERSE_COHERENT if coherent else 0,
+        tail = (ptr(origins), ptr(directions) if directions is not None else None, n,
+                (TRAVERSE_COHERENT if coherent else 0) | (_lib.TRAVERSE_RAYS_OD6 if od6 else 0),
                 ptr(offsets), ptr(indices), indices.size, C.byref(total))
         if aabbs is not None:
             assert aabbs.dtype == ft and aabbs.flags.c_contiguous

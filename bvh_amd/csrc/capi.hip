@@ -482,10 +482,11 @@ void host_batch_init(bvhgpu_ctx* ctx) {
 // (bvhgpu_build_traverse_host_*) enqueues it right behind the shapes' upload and BEFORE the build's launches: the ray upload — 24 MB
 // against the build's 3 — is the long pole.
 template <typename T>
-void host_batch_upload(bvhgpu_ctx* ctx, const T* origins, const T* directions, size_t n_rays) {
+void host_batch_upload(bvhgpu_ctx* ctx, const T* origins, const T* directions, size_t n_rays, bool od6) {
     using Ray = typename Traits<T>::Ray;
     HostBatch& hb = *ctx->host;
-    hb.total = 0; hb.fetched = false; hb.n_rays = n_rays; hb.chunks = 0; hb.with_od = directions != nullptr;
+    if (od6) directions = origins + 3;
+    hb.total = 0; hb.fetched = false; hb.n_rays = n_rays; hb.chunks = 0; hb.with_od = directions != nullptr; hb.od6 = od6;
     if (n_rays == 0) return;
     // Chunks: the walks of all chunks run one after the other on the main stream, each as soon as its rays have arrived; what is
     // left when the last upload ends is the LAST chunk's conversion + walk + offsets download, so the last chunk is the small one
@@ -512,7 +513,7 @@ void host_batch_upload(bvhgpu_ctx* ctx, const T* origins, const T* directions, s
     // the upload stream, one small launch per chunk: no staging buffer, no conversion pass on the main stream, none of the copy engines'
     // 10 - 20 µs between two transfers (seven of them per batch)
     const T* o_vis = (ctx->tune[BVHGPU_TUNE_HOST_ZERO_COPY] & 1) ? dev_visible(origins) : nullptr;
-    const T* d_vis = (o_vis && directions) ? dev_visible(directions) : nullptr;
+    const T* d_vis = (o_vis && directions) ? (od6 ? o_vis + 3 : dev_visible(directions)) : nullptr;
     hb.zero_copy_in = o_vis && (!directions || d_vis);
     if (directions && !hb.zero_copy_in) hb.od.reserve(2 * n_rays * 3 * sizeof(T));
     for (int k = 0; k < K; k++) {
@@ -521,10 +522,12 @@ void host_batch_upload(bvhgpu_ctx* ctx, const T* origins, const T* directions, s
         if (!hb.ev_up2[k]) BVH_HIP(hipEventCreateWithFlags(&hb.ev_up2[k], hipEventDisableTiming));
         if (!hb.ev_done[k]) BVH_HIP(hipEventCreateWithFlags(&hb.ev_done[k], hipEventDisableTiming));
         if (nk && hb.zero_copy_in) {
-            if (directions) rays_new<T>(ctx, o_vis + 3 * a, d_vis + 3 * a, nk, rays_dev + a, hb.up, HOST_READ_BLOCKS);
+            if (directions) rays_new<T>(ctx, o_vis + (od6 ? 6 : 3) * a, d_vis + (od6 ? 6 : 3) * a, nk, rays_dev + a, hb.up, HOST_READ_BLOCKS, od6 ? 6u : 3u);
             else copy16(hb.up, reinterpret_cast<const Ray*>(o_vis) + a, rays_dev + a, nk * sizeof(Ray));
         } else if (nk) {
-            if (directions) {
+            if (od6) {   // origin and direction of a ray side by side: ONE transfer per chunk
+                BVH_HIP(hipMemcpyAsync(hb.od.as<T>() + 6 * a, origins + 6 * a, nk * 6 * sizeof(T), hipMemcpyHostToDevice, hb.up));
+            } else if (directions) {
                 BVH_HIP(hipMemcpyAsync(hb.od.as<T>() + 3 * a, origins + 3 * a, nk * 3 * sizeof(T), hipMemcpyHostToDevice, hb.up));
                 BVH_HIP(hipMemcpyAsync(hb.od.as<T>() + 3 * n_rays + 3 * a, directions + 3 * a, nk * 3 * sizeof(T), hipMemcpyHostToDevice, two_up ? hb.up2 : hb.up));
                 if (two_up) { BVH_HIP(hipEventRecord(hb.ev_up2[k], hb.up2)); BVH_HIP(hipStreamWaitEvent(hb.up, hb.ev_up2[k], 0)); }
@@ -581,7 +584,10 @@ int host_batch_walk(bvhgpu_tree* tree, unsigned flags, uint32_t* offsets, uint32
         for (int k = 0; k < K; k++) {
             const size_t a = hb.r0[k], nk = hb.r0[k + 1] - a;
             BVH_HIP(hipStreamWaitEvent(st, hb.ev_up[k], 0));
-            if (hb.with_od && !hb.zero_copy_in) rays_new<T>(ctx, hb.od.as<T>() + 3 * a, hb.od.as<T>() + 3 * n_rays + 3 * a, nk, rays_dev + a, st);
+            if (hb.with_od && !hb.zero_copy_in) {
+                if (hb.od6) rays_new<T>(ctx, hb.od.as<T>() + 6 * a, hb.od.as<T>() + 6 * a + 3, nk, rays_dev + a, st, 0, 6);
+                else rays_new<T>(ctx, hb.od.as<T>() + 3 * a, hb.od.as<T>() + 3 * n_rays + 3 * a, nk, rays_dev + a, st);
+            }
             const int rc = do_traverse<T>(tree, rays_dev + a, nk, BVHGPU_DEVICE, flags, &hb.hits[k], true);
             if (rc != BVHGPU_OK) { const std::string keep = ctx->err; (void)finish_all(true); (void)hipStreamSynchronize(hb.up); ctx->err = keep; return rc; }
             enq = k + 1;
@@ -643,7 +649,10 @@ int do_traverse_host(bvhgpu_tree* tree, const T* aabbs, size_t n_shapes, bool re
     bvhgpu_ctx* ctx = tree->ctx;
     if (!offsets || !total) return fail(ctx, BVHGPU_INVALID_ARG, "offsets / total is NULL");
     if (n_rays && !origins) return fail(ctx, BVHGPU_INVALID_ARG, "origins is NULL");
-    if (flags & ~BVHGPU_TRAVERSE_COHERENT) return fail(ctx, BVHGPU_INVALID_ARG, "bvhgpu_traverse_host_* returns index lists: only BVHGPU_TRAVERSE_COHERENT may be set");
+    if (flags & ~(BVHGPU_TRAVERSE_COHERENT | BVHGPU_TRAVERSE_RAYS_OD6))
+        return fail(ctx, BVHGPU_INVALID_ARG, "bvhgpu_traverse_host_* returns index lists: only BVHGPU_TRAVERSE_COHERENT and BVHGPU_TRAVERSE_RAYS_OD6 may be set");
+    const bool od6 = (flags & BVHGPU_TRAVERSE_RAYS_OD6) != 0;
+    flags &= ~BVHGPU_TRAVERSE_RAYS_OD6;
     if (tree->dtype != Traits<T>::dtype) return fail(ctx, BVHGPU_DTYPE_MISMATCH, "tree dtype differs from ray / shape dtype");
     if (n_rays >= 0xFFFFFFFFull) return fail(ctx, BVHGPU_OVERFLOW, "more than 2^32-2 rays in one batch");
     if (rebuild && n_shapes && !aabbs) return fail(ctx, BVHGPU_INVALID_ARG, "aabbs is NULL");
@@ -665,7 +674,7 @@ int do_traverse_host(bvhgpu_tree* tree, const T* aabbs, size_t n_shapes, bool re
             else BVH_HIP(hipMemcpyAsync(tree->aabbs.p, aabbs, n_shapes * 6 * sizeof(T), hipMemcpyHostToDevice, hb.up));
             BVH_HIP(hipEventRecord(hb.ev_aabbs, hb.up));
         }
-        host_batch_upload<T>(ctx, origins, directions, n_rays);
+        host_batch_upload<T>(ctx, origins, directions, n_rays, od6);
         if (rebuild) {
             if (n_shapes) BVH_HIP(hipStreamWaitEvent(ctx->stream, hb.ev_aabbs, 0));
             const int rc = do_build<T>(tree, tree->aabbs.as<T>(), n_shapes, BVHGPU_DEVICE, true, true);

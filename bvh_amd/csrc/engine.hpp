@@ -63,6 +63,7 @@ struct HostBatch {
     bool zero_copy_in = false;   // the device reads the caller's (pinned) ray arrays itself: Ray::new straight out of host memory, no staging copy
     uint32_t* offsets_host = nullptr;   // device-visible address of the caller's (pinned) offsets / indices arrays: written by the device, no download
     uint32_t* indices_host = nullptr;
+    bool od6 = false;       // ... side by side in ONE array of n_rays x 6 (BVHGPU_TRAVERSE_RAYS_OD6)
     bool with_od = false;   // the batch came as origins + directions (Ray::new on the device) rather than as Ray structs
 };
 }
@@ -269,7 +270,7 @@ template <typename T>
 void ray_triangle_pairs(bvhgpu_ctx* ctx, const typename Traits<T>::Ray* rays_dev, const T* tris_dev, size_t n, T* out_dev);
 template <typename T>
 void rays_new(bvhgpu_ctx* ctx, const T* origins_dev, const T* dirs_dev, size_t n, typename Traits<T>::Ray* out_dev, hipStream_t st = nullptr,
-              unsigned max_blocks = 0);
+              unsigned max_blocks = 0, unsigned stride = 3);
 // out[i] = out[0] + offs[i], i = 1..n_rays; idx_all_dev != NULL: the chunk's index list copied to idx_all_dev[out[0] ..) as far as idx_cap entries reach
 // out_host (device-visible pinned host memory, or NULL): the same values stored there as well; idx_all (device or such host memory)
 void offsets_rebase(hipStream_t st, const uint32_t* offs_dev, size_t n_rays, uint32_t* out_dev, uint32_t* out_host = nullptr,

@@ -1057,7 +1057,6 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     static_assert(GUIDE == 0 || (MODE == MODE_INDICES && sizeof(T) == 4), "the guide walk is the f32 index walk");
     static_assert(ITEMS_LOG4 >= 0 && ITEMS_LOG4 <= 2, "1, 4 or 16 items per ray");
     static_assert(MODE != MODE_T_SLICE, "the t-slice output walks the binary array");
-    static_assert(MODE != MODE_CLOSEST || ITEMS_LOG4 == 0 || sizeof(T) == 4, "closest hit over items: the per-ray key packs a 32-bit distance");
     constexpr int CH = WideIo<T>::CHUNKS;
     constexpr int L4 = ITEMS_LOG4 > 0 ? ITEMS_LOG4 : 1;      // (so that the item code compiles when it is not used)
     constexpr uint32_t ITEMS = 1u << (2 * L4);
@@ -1182,8 +1181,18 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                         // first one.  Distance (monotone key), item and shape (< 2^28: WIDE_MAX_SHAPES) fit one 64-bit word: one atomicMin.
                         const uint32_t j = item & ((1u << WIDE_ITEM_BITS) - 1u);
                         const uint32_t jj = j == WIDE_ITEM_WHOLE ? 0u : j;
-                        const unsigned long long key = ((unsigned long long)Traits<T>::key(ray.best[0]) << 32) | ((unsigned long long)jj << 28) | (unsigned long long)ray.best_prim;
-                        atomicMin(&w.closest_key[item >> WIDE_ITEM_BITS], key);
+                        if constexpr (sizeof(T) == 4) {
+                            const unsigned long long key = ((unsigned long long)Traits<T>::key(ray.best[0]) << 32) | ((unsigned long long)jj << 28) | (unsigned long long)ray.best_prim;
+                            atomicMin(&w.closest_key[item >> WIDE_ITEM_BITS], key);
+                        } else {
+                            // f64: a 64-bit distance leaves no room for item and shape in one word.  Every item that found a candidate files its shape
+                            // under (ray, item) — the slots the index walk uses for hit counts — and marks itself in the ray's item set;
+                            // k_closest_resolve_slots walks the set in item order with the reference's strict <, recomputing each candidate's
+                            // Intersection (the same instruction sequence: the same bits)
+                            const size_t r = item >> WIDE_ITEM_BITS;
+                            w.item_cnt[(r << (2 * ITEMS_LOG4)) + jj] = ray.best_prim;
+                            atomicOr(&w.ray_items[r], 1u << jj);
+                        }
                     }
                 } else if (ray.cnt) {
                     uint32_t r = item;
@@ -1710,6 +1719,35 @@ __global__ __launch_bounds__(256) void k_closest_resolve(unsigned long long* __r
     closest_prim[r] = prim;
 }
 
+// closest hit of a ray whose items filed their candidates under (ray, item) (f64): the minimum over the ray's items in item order — items are
+// the tree-level-4 subtrees in pre-order, so a later item replaces an earlier one only on a strictly smaller distance, as the reference's
+// loop does over its candidate list (testbase.rs:831-833 behind flat_bvh.rs:408).  Leaves the item set all-zero for the next batch.
+template <typename T>
+__global__ __launch_bounds__(256) void k_closest_resolve_slots(uint32_t* __restrict__ ray_items, const uint32_t* __restrict__ item_prim,
+                                                               const typename Traits<T>::Ray* __restrict__ rays, const T* __restrict__ tris, uint32_t n_rays,
+                                                               T* __restrict__ closest, uint32_t* __restrict__ closest_prim) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    uint32_t m = ray_items[r];
+    T best[3] = {Traits<T>::inf(), 0, 0};
+    uint32_t prim = NONE;
+    if (m) {
+        ray_items[r] = 0u;
+        const typename Traits<T>::Ray* rp = rays + r;
+        const T o[3] = {rp->o[0], rp->o[1], rp->o[2]}, d[3] = {rp->d[0], rp->d[1], rp->d[2]};
+        while (m) {
+            const int j = __ffs((int)m) - 1;
+            m &= m - 1u;
+            const uint32_t p = item_prim[((size_t)r << 4) + (uint32_t)j];
+            T out[3];
+            ray_triangle<T>(o, d, tris + 9 * (size_t)p, out);
+            if (out[0] < best[0]) { best[0] = out[0]; best[1] = out[1]; best[2] = out[2]; prim = p; }
+        }
+    }
+    closest[3 * (size_t)r] = best[0]; closest[3 * (size_t)r + 1] = best[1]; closest[3 * (size_t)r + 2] = best[2];
+    closest_prim[r] = prim;
+}
+
 // ---- wide walk launch ------------------------------------------------------------------------
 // Workgroup geometry: `wg_per_cu` workgroups of `threads` share a CU's 160 KB of LDS; each keeps the per-lane stack
 // (stack_lds entries x threads x 4 B) and as many top-of-tree wide nodes as fit in the rest.
@@ -1837,8 +1875,9 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         const int want = ctx->tune[BVHGPU_TUNE_WIDE_ITEMS_LOG4];
         items_log4 = want >= 0 ? std::min(want, 2) : (few_rays ? 2 : 0);
     }
-    // closest hit (f32): the same cut into 16 items below ~2 M rays — the per-ray minimum over the items goes through WalkOut::closest_key
-    if (use_wide && mode == MODE_CLOSEST && sizeof(T) == 4 && n_rays < WIDE_ITEM_MAX_RAYS) {
+    // closest hit: the same cut into 16 items below ~2 M rays — the per-ray minimum over the items goes through WalkOut::closest_key (f32: one
+    // 64-bit atomicMin per item with a candidate) or through the (ray, item) slots (f64: k_closest_resolve_slots)
+    if (use_wide && mode == MODE_CLOSEST && n_rays < WIDE_ITEM_MAX_RAYS) {
         const int want = ctx->tune[BVHGPU_TUNE_WIDE_ITEMS_LOG4];
         items_log4 = (want >= 0 ? want >= 2 : few_rays) ? 2 : 0;
     }
@@ -1921,7 +1960,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         }
         if (M != MODE_CLOSEST && items_log4 == 2) launch_wide<T, M, (M == MODE_CLOSEST ? 0 : 2)>(t, rays_dev, n_rays, w, h, ovf_flag, early_items);
         else if (M != MODE_CLOSEST && items_log4 == 1) launch_wide<T, M, (M == MODE_CLOSEST ? 0 : 1)>(t, rays_dev, n_rays, w, h, ovf_flag, false);
-        else if (M == MODE_CLOSEST && sizeof(T) == 4 && items_log4 == 2) launch_wide<T, M, ((M == MODE_CLOSEST && sizeof(T) == 4) ? 2 : 0)>(t, rays_dev, n_rays, w, h, ovf_flag, false);
+        else if (M == MODE_CLOSEST && items_log4 == 2) launch_wide<T, M, (M == MODE_CLOSEST ? 2 : 0)>(t, rays_dev, n_rays, w, h, ovf_flag, false);
         else launch_wide<T, M, 0>(t, rays_dev, n_rays, w, h, ovf_flag, false);
     };
 #define DISPATCH_WALK_INNER()                                                                        \
@@ -1962,19 +2001,27 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         h->closest_prim.reserve(std::max<size_t>(n_rays, 1) * 4);
         if (n_rays == 0) { h->pend_tree = nullptr; return; }
         w.closest = h->closest.as<T>(); w.closest_prim = h->closest_prim.as<uint32_t>();
-        const bool by_items = use_wide && items_log4 == 2;   // (f32 only, see above)
-        if (by_items) {   // the per-ray keys: all-ones between batches (k_closest_resolve puts them back)
+        const bool by_items = use_wide && items_log4 == 2;
+        if (by_items && sizeof(T) == 4) {   // the per-ray keys: all-ones between batches (k_closest_resolve puts them back)
             if (h->closest_key.reserve(n_rays * sizeof(unsigned long long))) h->ckey_clean = false;
             if (!h->ckey_clean) BVH_HIP(hipMemsetAsync(h->closest_key.p, 0xFF, h->closest_key.cap, st));
             h->ckey_clean = true;
             w.closest_key = h->closest_key.as<unsigned long long>();
+        } else if (by_items) {   // f64: candidates by (ray, item), the rays' item sets all-zero between batches (k_closest_resolve_slots puts the zeros back)
+            h->item_cnt.reserve(((n_rays << 4) + 1) * 4);
+            if (h->ray_items.reserve((n_rays + 1) * 4)) BVH_HIP(hipMemsetAsync(h->ray_items.p, 0, h->ray_items.cap, st));
+            w.item_cnt = h->item_cnt.as<uint32_t>();
+            w.ray_items = h->ray_items.as<uint32_t>();
         }
         if (ctx->timing) { BVH_HIP(hipEventRecord(ctx->ev[4], st)); }
         DISPATCH_WALK();
         if (ctx->timing) BVH_HIP(hipEventRecord(ctx->ev[5], st));
-        if (by_items)
+        if (by_items && sizeof(T) == 4)
             hipLaunchKernelGGL(k_closest_resolve<T>, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, w.closest_key, rays_dev, t->tris.as<T>(),
                                (uint32_t)n_rays, w.closest, w.closest_prim);
+        else if (by_items)
+            hipLaunchKernelGGL(k_closest_resolve_slots<T>, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, w.ray_items, (const uint32_t*)w.item_cnt, rays_dev,
+                               t->tris.as<T>(), (uint32_t)n_rays, w.closest, w.closest_prim);
         if (ctx->timing) BVH_HIP(hipEventRecord(ctx->ev[6], st));
         hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);   // readback + reset for the next call
         h->ctr_clean = true;
@@ -2411,26 +2458,28 @@ template <typename T> __device__ __forceinline__ void ray_new(const T o[3], cons
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_rays_new(const T* __restrict__ origins, const T* __restrict__ dirs, uint32_t n,
-                                                  typename Traits<T>::Ray* __restrict__ out) {
+                                                  typename Traits<T>::Ray* __restrict__ out, uint32_t stride) {
     // (a grid-stride loop: with origins / dirs in pinned HOST memory the launch is kept small — a few thousand lanes keep the PCIe link busy —
     //  so that it leaves the CUs to the build running beside it)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        T o[3] = {origins[3 * (size_t)i], origins[3 * (size_t)i + 1], origins[3 * (size_t)i + 2]};
-        T d[3] = {dirs[3 * (size_t)i], dirs[3 * (size_t)i + 1], dirs[3 * (size_t)i + 2]};
+        // (stride 3: two arrays; stride 6 with dirs = origins + 3: origin and direction of a ray side by side)
+        T o[3] = {origins[stride * (size_t)i], origins[stride * (size_t)i + 1], origins[stride * (size_t)i + 2]};
+        T d[3] = {dirs[stride * (size_t)i], dirs[stride * (size_t)i + 1], dirs[stride * (size_t)i + 2]};
         ray_new<T>(o, d, out + i);
     }
 }
 
 template <typename T>
-void rays_new(bvhgpu_ctx* ctx, const T* origins_dev, const T* dirs_dev, size_t n, typename Traits<T>::Ray* out_dev, hipStream_t st, unsigned max_blocks) {
+void rays_new(bvhgpu_ctx* ctx, const T* origins_dev, const T* dirs_dev, size_t n, typename Traits<T>::Ray* out_dev, hipStream_t st, unsigned max_blocks,
+              unsigned stride) {
     if (!n) return;
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (max_blocks) blocks = std::min(blocks, max_blocks);
-    hipLaunchKernelGGL(k_rays_new<T>, dim3(blocks), dim3(256), 0, st ? st : ctx->stream, origins_dev, dirs_dev, (uint32_t)n, out_dev);
+    hipLaunchKernelGGL(k_rays_new<T>, dim3(blocks), dim3(256), 0, st ? st : ctx->stream, origins_dev, dirs_dev, (uint32_t)n, out_dev, (uint32_t)stride);
     BVH_HIP(hipGetLastError());
 }
-template void rays_new<float>(bvhgpu_ctx*, const float*, const float*, size_t, bvhgpu_ray_f32*, hipStream_t, unsigned);
-template void rays_new<double>(bvhgpu_ctx*, const double*, const double*, size_t, bvhgpu_ray_f64*, hipStream_t, unsigned);
+template void rays_new<float>(bvhgpu_ctx*, const float*, const float*, size_t, bvhgpu_ray_f32*, hipStream_t, unsigned, unsigned);
+template void rays_new<double>(bvhgpu_ctx*, const double*, const double*, size_t, bvhgpu_ray_f64*, hipStream_t, unsigned, unsigned);
 
 // CSR offsets of one chunk of a host-resident batch (bvhgpu_traverse_host_*), moved to their place in the whole batch's array:
 // out[0] holds the hits of all chunks before this one (written by the previous chunk's pass on the same stream; 0 for the first)

@@ -83,6 +83,9 @@ typedef enum { BVHGPU_HOST = 0, BVHGPU_DEVICE = 1 } bvhgpu_mem;
                                           enqueued (resident ray buffers of a frame loop).  The engine may then read them while the build
                                           is still running — the wide walk's per-ray item filter runs beside the build on a second
                                           stream instead of in front of the walk.  Results never depend on it */
+#define BVHGPU_TRAVERSE_RAYS_OD6 512u /* bvhgpu_traverse_host_* / bvhgpu_build_traverse_host_* only: `origins` points to n_rays x 6 T — origin xyz, direction xyz
+                                        per ray, the arguments of Ray::new side by side — and `directions` is ignored.  One transfer per chunk
+                                        instead of two: the copy engines idle 10 - 20 µs between two transfers */
 #define BVHGPU_TRAVERSE_COHERENT 16u /* hint: neighbouring rays are similar (primary rays).  Large whole-ray batches then hand their hits over
                                         through per-ray slots instead of pool records (BVHGPU_TUNE_WIDE_STAGE_SHIFT); results never depend on it */
 
@@ -319,7 +322,7 @@ int bvhgpu_traverse_f64(bvhgpu_tree *tree, const bvhgpu_ray_f64 *rays, size_t n_
  *   offsets               n_rays + 1 entries, always written.
  *   indices, indices_cap  written when the batch's hit total fits (total <= indices_cap); otherwise the call still succeeds,
  *                         *total says what is needed and bvhgpu_traverse_host_indices fetches them (no second traversal).
- *   flags                 0 or BVHGPU_TRAVERSE_COHERENT.
+ *   flags                 0, BVHGPU_TRAVERSE_COHERENT, BVHGPU_TRAVERSE_RAYS_OD6 (origins = n_rays x [o xyz, d xyz], directions ignored).
  * The tree may still be building (bvhgpu_rebuild_flat_async_* with BVHGPU_HOST shapes): the ray upload does not wait for the build.
  * The batch is walked in chunks (BVHGPU_TUNE_HOST_CHUNKS: by default three, the last one an eighth of the batch) on three streams — upload of
  * chunk k+1, Ray::new + walk of chunk k, download of the offsets of chunk k-1 — with one host wait at the end; with pinned buffers (bvhgpu_host_alloc / _register) the copies are DMA at link

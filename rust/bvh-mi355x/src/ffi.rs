@@ -32,6 +32,7 @@ pub const BVHGPU_TRAVERSE_NEAREST_FIRST: c_uint = 32;
 pub const BVHGPU_TRAVERSE_FARTHEST_FIRST: c_uint = 64;
 pub const BVHGPU_TRAVERSE_BEST_FIRST: c_uint = 128;
 pub const BVHGPU_TRAVERSE_RAYS_READY: c_uint = 256;
+pub const BVHGPU_TRAVERSE_RAYS_OD6: c_uint = 512;
 // bvhgpu_hits_walk_info
 pub const BVHGPU_WALK_WIDE: c_uint = 1;
 pub const BVHGPU_WALK_STAGED: c_uint = 2;

@@ -316,12 +316,21 @@ impl<T: GpuScalar> GpuBvh<T> {
         BatchHits { offsets, indices }
     }
 
+    /// ... and as ONE slice of `[o.x, o.y, o.z, d.x, d.y, d.z]` per ray (`BVHGPU_TRAVERSE_RAYS_OD6`): one transfer per chunk instead of two
+    pub fn traverse_batch_od6(&self, rays: &[[T; 6]]) -> BatchHits {
+        self.host_batch_flags(rays.as_ptr().cast(), core::ptr::null(), rays.len(), ffi::BVHGPU_TRAVERSE_RAYS_OD6)
+    }
+
     fn host_batch(&self, origins: *const T, directions: *const T, n: usize) -> BatchHits {
+        self.host_batch_flags(origins, directions, n, 0)
+    }
+
+    fn host_batch_flags(&self, origins: *const T, directions: *const T, n: usize, flags: c_uint) -> BatchHits {
         let mut offsets = vec![0u32; n + 1];
         let mut indices = vec![0u32; n.max(1 << 16)];
         let mut total = 0u64;
         unsafe {
-            check(self.ctx, T::traverse_host(self.tree, origins, directions, n, 0, offsets.as_mut_ptr(), indices.as_mut_ptr(), indices.len(), &mut total));
+            check(self.ctx, T::traverse_host(self.tree, origins, directions, n, flags, offsets.as_mut_ptr(), indices.as_mut_ptr(), indices.len(), &mut total));
             if total as usize > indices.len() {
                 indices.resize(total as usize, 0);
                 check(self.ctx, ffi::bvhgpu_traverse_host_indices(self.ctx, indices.as_mut_ptr(), indices.len()));

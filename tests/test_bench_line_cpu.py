@@ -84,7 +84,7 @@ def _detail(n_gpus=1):
             "bytes_per_step": {"aabbs_up": 2880000, "rays_up": 24000000, "csr_down": 4040004}, "pcie_gbs": 45.03, "csr_equal_to_pageable_path": True}
     d["step_excludes"] = {"steps": 100, "with_ray_gen": {"value": 2966.178, "unit": "Mrays/s", "ms_per_step": 0.3371, "delta_ms_vs_value": 0.0135},
                           "lazy_flat_array": {"value": 3150.2, "unit": "Mrays/s", "ms_per_step": 0.3174, "delta_ms_vs_value": -0.0062},
-                          "host_io": dict(path, paths={"pageable": dict(path, value=802.5), "pinned": path})}
+                          "host_io": dict(path, paths={"pageable": dict(path, value=802.5), "pinned": path, "pinned_one_call": dict(path, value=1440.1)})}
     d["extra_configs"] = [
         _extra("cubes120k", "closest"), _extra("cubes120k", "triangles"), _extra("standin-primary", "closest", config=2, rays=10_000_000),
         _extra("standin-primary", config=2, rays=10_000_000), _extra("standin-incoherent", config=3, rays=12_500_000),
@@ -122,7 +122,7 @@ def test_full_line_fits_the_budget_and_keeps_the_contract():
             cb = out["cpu_baseline"]
             assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] == "port" and len(cb["host_load_1m"]) == 2
             assert len(out["extra_configs"]) == 9 and all(e["parity"]["equal"] is True for e in out["extra_configs"])
-            assert out["step_excludes"]["host_io"] == 1456.2 and set(out["step_excludes"]["host_io_detail"]) == {"pageable", "pinned"}
+            assert out["step_excludes"]["host_io"] == 1456.2 and set(out["step_excludes"]["host_io_detail"]) == {"pageable", "pinned", "pinned_one_call"}
             assert out["extra_configs"][5]["pure_f64_walk"]["parity_equal"] is True and out["parity"] == {"equal": True, "checked_rays": 1000000,
                                                                                                          "bvh_nodes_equal": True}
         else:

@@ -64,6 +64,18 @@ def test_host_batch_equals_oracle_and_device_path(eng, orc, dtype, chunks, zero_
         hs.offsets[:] = 0xDEADBEEF; hs.indices[:] = 0xDEADBEEF
         off, idx = hs.run(fused=rep != 1)
         assert np.array_equal(off, ooff) and np.array_equal(idx, oidx), (rep, chunks)
+    # origin and direction side by side in one pinned array (BVHGPU_TRAVERSE_RAYS_OD6), one call and two
+    hs6 = HostStep(bvh, len(aabbs), n, dtype, od6=True)
+    hs6.aabbs[:] = aabbs; hs6.origins[:] = o; hs6.directions[:] = d
+    for fused in (True, False):
+        hs6.offsets[:] = 0; hs6.indices[:] = 0
+        off, idx = hs6.run(fused=fused)
+        assert np.array_equal(off, ooff) and np.array_equal(idx, oidx), (fused, chunks)
+    od_page = np.ascontiguousarray(np.concatenate([o, d], axis=1))     # ... and out of pageable memory
+    off6, idx6 = np.zeros(n + 1, np.uint32), np.zeros(max(len(oidx), 1), np.uint32)
+    assert bvh.traverse_host(od_page, None, off6, idx6, od6=True) == len(oidx)
+    assert np.array_equal(off6, ooff) and np.array_equal(idx6[:len(oidx)], oidx)
+    hs6.close()
     # the caller's own Ray structs out of pinned memory
     from bvh_amd.api import pinned_array
     pr = pinned_array(ctx, (n,), rays.dtype)

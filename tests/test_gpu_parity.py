@@ -724,14 +724,15 @@ def test_triangle_stage_matches_reference_loop(eng, orc, variant, dtype):
     assert st2["hits"] == ost["hits"] and st2["visited"] == ost["visited"]
     hit = np.isfinite(oclosest[:, 0])
     assert hit.sum() > n // 2 and (~hit).sum() > n // 20               # both outcomes are exercised
-    # the same batch without STATS: the default walk of a batch this size — for f32 closest hits the wide walk over 16 items per ray, the ray's
-    # nearest candidate taken as a minimum over its items (WalkOut::closest_key + k_closest_resolve)
+    # the same batch without STATS: the default walk of a batch this size — the wide walk over 16 items per ray, the ray's nearest candidate
+    # taken as a minimum over its items (f32: WalkOut::closest_key + k_closest_resolve; f64: (ray, item) slots + k_closest_resolve_slots)
     ctx3 = Context(0)                                                    # default tuning: the wide walk for batches of 16 384 rays and more
     flat3 = eng.Bvh.from_aabbs(aabbs, ctx3).flatten()
     flat3.set_triangles(tris)
     cl2, prim2, st3 = flat3.closest_hits(_rb(eng, rays))
     assert cl2.tobytes() == oclosest.tobytes() and np.array_equal(prim2, oprim)
-    assert flat3._hits.walk_kernel().startswith("bvhgpu::k_traverse_wide<%s, 3, %d," % ("float" if dtype == np.float32 else "double", 2 if dtype == np.float32 else 0))
+    # (f64: the candidates filed by (ray, item), k_closest_resolve_slots)
+    assert flat3._hits.walk_kernel().startswith("bvhgpu::k_traverse_wide<%s, 3, 2," % ("float" if dtype == np.float32 else "double"))
     # ... and where the minimum is not unique: pairs of overlapping coplanar triangles (planes z = const, a ray along +z meets both at exactly
     # the same distance) whose centroids lie far apart, so that they sit in different subtrees — different ITEMS of the ray.  The reference keeps
     # the candidate its loop meets first (strict <, testbase.rs:831-833): the key's item number must reproduce that order.

@@ -30,15 +30,26 @@ def med(fn, blocks=7, n=20):
     v = sorted(t(fn, n) for _ in range(blocks))
     return v[len(v) // 2], v[0], v[-1]
 from bvh_amd._lib import TUNE_HOST_ZERO_COPY
-for zc in (3, 1, 2, 0):
+for zc in (2,):
   ctx.set_tuning(TUNE_HOST_ZERO_COPY, zc)
   for fused in (True, False):
-    for ch in (0, 1, 2, 3, 4, 6):
+    for ch in (0, 3):
         ctx.set_tuning(TUNE_HOST_CHUNKS, ch)
         ms, lo, hi = med(lambda: hs.run(fused=fused))
         print(f"pinned, zero_copy={zc}, {'bvhgpu_build_traverse_host' if fused else 'rebuild_flat_async + traverse_host'} (24 B/ray), chunks={ch}: median {ms:.4f} ms "
               f"[{lo:.4f} .. {hi:.4f}]  {R / ms / 1e3:.0f} Mrays/s  total={hs.total}", flush=True)
-ctx.set_tuning(TUNE_HOST_ZERO_COPY, 3)
+ctx.set_tuning(TUNE_HOST_ZERO_COPY, 2)
+hs6 = HostStep(bvh, len(aabbs), R, np.float32, od6=True)
+hs6.aabbs[:] = aabbs; hs6.origins[:] = o; hs6.directions[:] = d
+for zc in (2, 0):
+  ctx.set_tuning(TUNE_HOST_ZERO_COPY, zc)
+  for fused in (True, False):
+    for ch in (0, 2, 3, 4):
+        ctx.set_tuning(TUNE_HOST_CHUNKS, ch)
+        ms, lo, hi = med(lambda: hs6.run(fused=fused))
+        print(f"pinned OD6, zero_copy={zc}, {'bvhgpu_build_traverse_host' if fused else 'rebuild_flat_async + traverse_host'} (24 B/ray, one array), chunks={ch}: median {ms:.4f} ms "
+              f"[{lo:.4f} .. {hi:.4f}]  {R / ms / 1e3:.0f} Mrays/s  total={hs6.total}", flush=True)
+ctx.set_tuning(TUNE_HOST_ZERO_COPY, 2); ctx.set_tuning(TUNE_HOST_CHUNKS, 0)
 ctx.set_tuning(TUNE_HOST_CHUNKS, 0)
 # pageable origins / directions through the same entry point
 off = np.zeros(R + 1, np.uint32); idx = np.zeros(1 << 20, np.uint32)

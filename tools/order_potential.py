@@ -50,16 +50,25 @@ def keys(rays9, bounds, kind):
     raise ValueError(kind)
 
 
-_, aabbs_s, bounds_s = scene.parse_obj(scene.make_atrium_obj(16))
-_, aabbs_c = tb.create_n_cubes(100_000)     # 1.2 M triangles: a scene that outgrows the L2s on the cube generator too
-for scene_name, aabbs, bounds in (("standin", aabbs_s, bounds_s), ("cubes1.2M", aabbs_c, tb.default_bounds())):
+which = os.environ.get("ORDER_SCENES", "standin,cubes1.2M").split(",")
+scenes = []
+if "standin" in which:
+    _, aabbs_s, bounds_s = scene.parse_obj(scene.make_atrium_obj(16))
+    scenes.append(("standin", aabbs_s, bounds_s))
+if "cubes1.2M" in which:     # 1.2 M triangles: a scene that outgrows the L2s on the cube generator too
+    scenes.append(("cubes1.2M", tb.create_n_cubes(100_000)[1], tb.default_bounds()))
+if "cubes12m" in which:      # round 6: bench.py's beyond-BASELINE entry — 12 M triangles, the regime where the walk is HBM-bound (0.52 of peak)
+    scenes.append(("cubes12m", tb.create_n_cubes(1_000_000)[1], tb.default_bounds()))
+first_ray = int(os.environ.get("ORDER_FIRST", "62500000"))
+kinds = os.environ.get("ORDER_KINDS", "none,cell3,cell4,cell5,oct_cell3,oct_cell4,dir4c3,dir8c2,dir8c3,dir16c2").split(",")
+for scene_name, aabbs, bounds in scenes:
     bvh = Bvh.from_aabbs(torch.from_numpy(aabbs).to(dev), ctx)
     bvh.flatten_in_place()
     buf = torch.empty(n * RAY_F32.itemsize, dtype=torch.uint8, device=dev)
-    rays = RayBatch.generate(62_500_000, n, bounds, buf, np.float32, ctx)
+    rays = RayBatch.generate(first_ray, n, bounds, buf, np.float32, ctx)
     torch.cuda.synchronize()
     r9 = buf.view(torch.float32).view(n, 9)
-    for kind in ("none", "cell3", "cell4", "cell5", "oct_cell3", "oct_cell4", "dir4c3", "dir8c2", "dir8c3", "dir16c2"):
+    for kind in kinds:
         if kind == "none":
             sbuf = buf
         else:
