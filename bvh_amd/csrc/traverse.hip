@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(256) void k_wide_items(const typename Traits<T>::No
 // flags rays the containment argument does not cover; the f32 wide walk then runs over `wide_guide` unchanged, except that a leaf
 // CANDIDATE is confirmed by the f64 slab test of the shape's own f64 box with the f64 ray before it is reported.  Same lists, same order.
 constexpr unsigned long long WALK_FLAG_GUIDE_RANGE = 16ull;   // ctr[7] bit: a ray was outside the guide walk's range — the host replays in f64
-struct GuideArgs { const bvhgpu_ray_f64* rays64; const double* aabbs64; const float* info; };   // info[0] = S (tree->guide_info)
+struct GuideArgs { const bvhgpu_ray_f64* rays64; const double* aabbs64; const float* info; const double* tris64; };   // info[0] = S (tree->guide_info); tris64: closest-hit batches
 // The guide walk's f32 view of an f64 ray, made where the ray is loaded (round 4: a kernel of its own wrote an f32 copy of the batch first
 // — 72 B read + 36 B written per ray and a launch, 19-22 µs per 1 M rays): origin and 1/d rounded to nearest, and the range test of the
 // containment argument (common.hpp "guide boxes"); `bad` = the argument does not cover this ray.
@@ -1038,6 +1038,21 @@ __device__ __forceinline__ bool guide_leaf_hit(const GuideArgs& ga, uint32_t ray
     return slab_hit_finite<double>(o, inv, mn, mx);
 }
 
+// a leaf candidate of the guide walk that passed its f64 box, in a closest-hit batch: Ray::intersects_triangle in f64 (ray_impl.rs:154-213) and the
+// reference's strict < against the lane's nearest so far (testbase.rs:831-833).  Inlined, although candidates are rare and the f64
+// Möller–Trumbore needs more registers than the f32 walk around it owns: as a real call (__noinline__) the walk took 0.208 ms instead of
+// 0.141 — the calling convention's register split costs the hot loop more than the spills around the rare branch do.
+#ifndef BVH_GUIDE_CANDIDATE_ATTR
+#define BVH_GUIDE_CANDIDATE_ATTR __forceinline__
+#endif
+__device__ BVH_GUIDE_CANDIDATE_ATTR double guide_candidate_distance(const bvhgpu_ray_f64* __restrict__ rays64, const double* __restrict__ tris64, uint32_t ray, uint32_t shape) {
+    const bvhgpu_ray_f64* rp = rays64 + ray;
+    const double o[3] = {rp->o[0], rp->o[1], rp->o[2]}, d[3] = {rp->d[0], rp->d[1], rp->d[2]};
+    double out[3];
+    ray_triangle<double>(o, d, tris64 + 9 * (size_t)shape, out);
+    return out[0];
+}
+
 #ifdef BVH_WIDE_PROFILE   // developer build: per-wave timestamps (100 MHz wall clock) of the wide walk's phases
 __device__ unsigned long long g_wide_prof[4 * 16384];
 // lane-utilisation counts per wave (16 per wave): [0] wave-steps, [1] lanes on an inner node, [2] steps with a resident fetch,
@@ -1054,7 +1069,9 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
     const WideNode<T>* __restrict__ wide, const uint32_t* __restrict__ wslot_node, uint32_t K, uint32_t stack_lds,
     const typename Traits<T>::Ray* __restrict__ rays, uint32_t n_rays, uint32_t* __restrict__ list_all, const uint32_t* __restrict__ wg_items,
     WalkOut<T> w, uint32_t* __restrict__ gstack, uint32_t gstack_cap, uint32_t* __restrict__ overflow, GuideArgs ga, uint32_t whole_steps) {
-    static_assert(GUIDE == 0 || (MODE == MODE_INDICES && sizeof(T) == 4), "the guide walk is the f32 index walk");
+    static_assert(GUIDE == 0 || ((MODE == MODE_INDICES || MODE == MODE_CLOSEST) && sizeof(T) == 4), "the guide walk is the f32 walk of an f64 index / closest-hit batch");
+    constexpr bool GUIDE_CLOSEST = GUIDE != 0 && MODE == MODE_CLOSEST;   // candidates are decided in f64 (guide_closest_candidate); the lane keeps (distance, shape)
+    double gbest = 0.0;
     static_assert(ITEMS_LOG4 >= 0 && ITEMS_LOG4 <= 2, "1, 4 or 16 items per ray");
     static_assert(MODE != MODE_T_SLICE, "the t-slice output walks the binary array");
     constexpr int CH = WideIo<T>::CHUNKS;
@@ -1172,8 +1189,8 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                 if (MODE == MODE_CLOSEST) {
                     if constexpr (ITEMS_LOG4 == 0) {
                         const size_t r = item;
-                        w.closest[3 * r] = ray.best[0]; w.closest[3 * r + 1] = ray.best[1]; w.closest[3 * r + 2] = ray.best[2];
-                        w.closest_prim[r] = ray.best_prim;
+                        if constexpr (!GUIDE_CLOSEST) { w.closest[3 * r] = ray.best[0]; w.closest[3 * r + 1] = ray.best[1]; w.closest[3 * r + 2] = ray.best[2]; }
+                        w.closest_prim[r] = ray.best_prim;   // (guide: the shape only — k_closest_from_prim recomputes its Intersection in f64)
                     } else if (ray.best_prim != NONE) {
                         // The ray's other items sit in other lanes: the nearest candidate of the RAY is the minimum over its items of (distance, item
                         // number) — items are the tree-level-4 subtrees in pre-order, so on equal distances the lower item holds the candidate the
@@ -1181,7 +1198,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                         // first one.  Distance (monotone key), item and shape (< 2^28: WIDE_MAX_SHAPES) fit one 64-bit word: one atomicMin.
                         const uint32_t j = item & ((1u << WIDE_ITEM_BITS) - 1u);
                         const uint32_t jj = j == WIDE_ITEM_WHOLE ? 0u : j;
-                        if constexpr (sizeof(T) == 4) {
+                        if constexpr (sizeof(T) == 4 && !GUIDE_CLOSEST) {
                             const unsigned long long key = ((unsigned long long)Traits<T>::key(ray.best[0]) << 32) | ((unsigned long long)jj << 28) | (unsigned long long)ray.best_prim;
                             atomicMin(&w.closest_key[item >> WIDE_ITEM_BITS], key);
                         } else {
@@ -1220,7 +1237,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                     if (ITEMS_LOG4 == 0) {
                         item = ray_of(mine);
                         if (item < n_rays) {
-                            if constexpr (GUIDE != 0) { bool bad; guide_ray_load(ga.rays64, item, guide_S, ray.o, ray.inv, bad); guide_bad = guide_bad || bad; ray.loaded(item); }
+                            if constexpr (GUIDE != 0) { bool bad; guide_ray_load(ga.rays64, item, guide_S, ray.o, ray.inv, bad); guide_bad = guide_bad || bad; ray.loaded(item); gbest = __builtin_inf(); }
                             else ray.load(rays, item);
                             cur = WIDE_INNER | WIDE_RESIDENT | 0u;   // the root is heap slot 0 (K >= 1)
                         } else {
@@ -1229,7 +1246,7 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                     } else {
                         item = list[mine < n_front ? mine : per_wg * ITEMS - 1u - (mine - n_front)];
                         const uint32_t j = item & ((1u << WIDE_ITEM_BITS) - 1u);
-                        if constexpr (GUIDE != 0) { bool bad; guide_ray_load(ga.rays64, item >> WIDE_ITEM_BITS, guide_S, ray.o, ray.inv, bad); ray.loaded(item >> WIDE_ITEM_BITS); }   // (the filter has looked at its range)
+                        if constexpr (GUIDE != 0) { bool bad; guide_ray_load(ga.rays64, item >> WIDE_ITEM_BITS, guide_S, ray.o, ray.inv, bad); ray.loaded(item >> WIDE_ITEM_BITS); gbest = __builtin_inf(); }   // (the filter has looked at its range)
                         else ray.load(rays, item >> WIDE_ITEM_BITS);
                         cur = j == WIDE_ITEM_WHOLE ? (WIDE_INNER | WIDE_RESIDENT | 0u) : s_item_ref[j];
                         if (j == WIDE_ITEM_WHOLE) item = item & ~((1u << WIDE_ITEM_BITS) - 1u);   // filed under j = 0
@@ -1302,7 +1319,15 @@ __global__ __launch_bounds__(MAX_THREADS, MIN_WAVES) void k_traverse_wide(
                     rec = false;
                 }
             }
-            if (MODE == MODE_INDICES && ITEMS_LOG4 == 0 && w.pool_pair) report_pair(rec, false, shape, ray, pair_pend, w.pool_pair, w.pool_cap, w.ctr, pc, lane, lt);   // (wave-uniform)
+            if constexpr (GUIDE_CLOSEST) {   // (wave-uniform skip, like the f64 box test above: candidates are rare)
+                if (__any(rec)) {
+                    if (rec) {
+                        const double dist = guide_candidate_distance(ga.rays64, ga.tris64, ITEMS_LOG4 == 0 ? ray.r : (ray.r >> WIDE_ITEM_BITS), shape);
+                        if (dist < gbest) { gbest = dist; ray.best_prim = shape; }
+                        ray.cnt++;
+                    }
+                }
+            } else if (MODE == MODE_INDICES && ITEMS_LOG4 == 0 && w.pool_pair) report_pair(rec, false, shape, ray, pair_pend, w.pool_pair, w.pool_cap, w.ctr, pc, lane, lt);   // (wave-uniform)
             else report<T, MODE>(rec, shape, (T)0, (T)0, ray, w, pc, lane, lt);
         }
         if (ovf) { cur = CUR_NONE; sp = 0; }
@@ -1748,6 +1773,22 @@ __global__ __launch_bounds__(256) void k_closest_resolve_slots(uint32_t* __restr
     closest_prim[r] = prim;
 }
 
+// closest-hit batch of the guide walk, whole rays: the walk left the nearest shape per ray; its Intersection, recomputed in f64
+template <typename T>
+__global__ __launch_bounds__(256) void k_closest_from_prim(const uint32_t* __restrict__ closest_prim, const typename Traits<T>::Ray* __restrict__ rays,
+                                                           const T* __restrict__ tris, uint32_t n_rays, T* __restrict__ closest) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const uint32_t p = closest_prim[r];
+    T out[3] = {Traits<T>::inf(), 0, 0};
+    if (p != NONE) {
+        const typename Traits<T>::Ray* rp = rays + r;
+        const T o[3] = {rp->o[0], rp->o[1], rp->o[2]}, d[3] = {rp->d[0], rp->d[1], rp->d[2]};
+        ray_triangle<T>(o, d, tris + 9 * (size_t)p, out);
+    }
+    closest[3 * (size_t)r] = out[0]; closest[3 * (size_t)r + 1] = out[1]; closest[3 * (size_t)r + 2] = out[2];
+}
+
 // ---- wide walk launch ------------------------------------------------------------------------
 // Workgroup geometry: `wg_per_cu` workgroups of `threads` share a CU's 160 KB of LDS; each keeps the per-lane stack
 // (stack_lds entries x threads x 4 B) and as many top-of-tree wide nodes as fit in the rest.
@@ -1796,7 +1837,7 @@ constexpr uint32_t WIDE_GSTACK = 24;   // stack entries per lane beyond the LDS 
 // GUIDE: T = float on an f64 tree — the nodes are the tree's guide boxes, rays_dev unused (NULL), ga the f64 batch: every ray is converted where the walk loads it (guide_ray_load)
 template <typename T, int MODE, int ITEMS_LOG4, int GUIDE = 0>
 static void launch_wide(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, size_t n_rays, const WalkOut<T>& w, bvhgpu_hits* h,
-                        uint32_t* ovf_flag, bool early_items, GuideArgs ga = GuideArgs{nullptr, nullptr, nullptr}) {
+                        uint32_t* ovf_flag, bool early_items, GuideArgs ga = GuideArgs{nullptr, nullptr, nullptr, nullptr}) {
     bvhgpu_ctx* ctx = t->ctx;
     hipStream_t st = ctx->stream;
     const WideGeom<T> g(ctx, ITEMS_LOG4 == 0, (h->flags & BVHGPU_TRAVERSE_COHERENT) != 0);
@@ -1890,7 +1931,7 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     // A result object that met a ray outside the guide walk's range backs off: the next `guide_skip` f64 index batches take the f64 walk
     // straight away (1, 2, 4 … 64 batches on consecutive failures — a workload of axis-parallel rays pays one wasted guide walk in 65),
     // then the guide is tried again; a batch that stays in range resets the back-off (the fall-back used to be for ever).
-    const bool guide_ok = sizeof(T) == 8 && use_wide && mode == MODE_INDICES && t->has_guide && !early_items && ctx->tune[BVHGPU_TUNE_WIDE_F64_GUIDE] != 0;
+    const bool guide_ok = sizeof(T) == 8 && use_wide && (mode == MODE_INDICES || mode == MODE_CLOSEST) && t->has_guide && !early_items && ctx->tune[BVHGPU_TUNE_WIDE_F64_GUIDE] != 0;
     const bool replaying_out_of_range = h->no_guide;      // traverse_check sent this very batch back
     // (one back-off slot per BATCH: a replay of the same batch — pool / index growth, a stack overflow's switch to the binary walk — takes none)
     const bool first_enqueue = h->pend_attempts == 0 && !h->force_binary && !replaying_out_of_range;
@@ -1951,10 +1992,22 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
                 wg.counts = w.counts; wg.pool = w.pool; wg.pool_v = nullptr; wg.pool_cap = w.pool_cap; wg.ctr = w.ctr; wg.tris = nullptr;
                 wg.closest = nullptr; wg.closest_prim = nullptr; wg.closest_key = nullptr; wg.item_cnt = w.item_cnt; wg.ray_items = w.ray_items; wg.scan_sums = w.scan_sums;
                 wg.pool_pair = w.pool_pair; wg.raybuf = w.raybuf; wg.stage_shift = w.stage_shift;
-                const GuideArgs ga{reinterpret_cast<const bvhgpu_ray_f64*>(rays_dev), t->aabbs.as<double>(), t->guide_info.as<float>()};
+                const GuideArgs ga{reinterpret_cast<const bvhgpu_ray_f64*>(rays_dev), t->aabbs.as<double>(), t->guide_info.as<float>(), nullptr};
                 if (items_log4 == 2) launch_wide<float, MODE_INDICES, 2, 1>(t, r32, n_rays, wg, h, ovf_flag, false, ga);
                 else if (items_log4 == 1) launch_wide<float, MODE_INDICES, 1, 1>(t, r32, n_rays, wg, h, ovf_flag, false, ga);
                 else launch_wide<float, MODE_INDICES, 0, 1>(t, r32, n_rays, wg, h, ovf_flag, false, ga);
+                return;
+            }
+        }
+        if constexpr (sizeof(T) == 8 && M == MODE_CLOSEST) {
+            if (use_guide) {   // closest hit of an f64 batch: the f32 walk over the guide boxes; every leaf candidate's box AND triangle decided in f64
+                WalkOut<float> wg;
+                wg.counts = nullptr; wg.pool = nullptr; wg.pool_v = nullptr; wg.pool_cap = 0; wg.ctr = w.ctr; wg.tris = nullptr;
+                wg.closest = nullptr; wg.closest_prim = w.closest_prim; wg.closest_key = nullptr; wg.item_cnt = w.item_cnt; wg.ray_items = w.ray_items; wg.scan_sums = nullptr;
+                wg.pool_pair = nullptr; wg.raybuf = nullptr; wg.stage_shift = 0;
+                const GuideArgs ga{reinterpret_cast<const bvhgpu_ray_f64*>(rays_dev), t->aabbs.as<double>(), t->guide_info.as<float>(), t->tris.as<double>()};
+                if (items_log4 == 2) launch_wide<float, MODE_CLOSEST, 2, 1>(t, nullptr, n_rays, wg, h, ovf_flag, false, ga);
+                else launch_wide<float, MODE_CLOSEST, 0, 1>(t, nullptr, n_rays, wg, h, ovf_flag, false, ga);
                 return;
             }
         }
@@ -2022,6 +2075,9 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
         else if (by_items)
             hipLaunchKernelGGL(k_closest_resolve_slots<T>, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, w.ray_items, (const uint32_t*)w.item_cnt, rays_dev,
                                t->tris.as<T>(), (uint32_t)n_rays, w.closest, w.closest_prim);
+        else if (use_guide)   // whole rays of the guide walk: the shapes are in closest_prim, their Intersections follow
+            hipLaunchKernelGGL(k_closest_from_prim<T>, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, st, (const uint32_t*)w.closest_prim, rays_dev, t->tris.as<T>(),
+                               (uint32_t)n_rays, w.closest);
         if (ctx->timing) BVH_HIP(hipEventRecord(ctx->ev[6], st));
         hipLaunchKernelGGL(k_publish_counters, dim3(1), dim3(64), 0, st, ctr, pin);   // readback + reset for the next call
         h->ctr_clean = true;

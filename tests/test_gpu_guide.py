@@ -181,3 +181,39 @@ def test_guide_walk_at_the_edges_of_its_range(eng, orc, log2_s, log2_inv, guide)
     off, idx, st = _csr(eng, flat, rays)
     assert st["walk"] & WALK_WIDE and bool(st["walk"] & WALK_F64_GUIDE) == guide
     assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+
+
+@pytest.mark.parametrize("items", [-1, 0])
+def test_guide_walk_closest_hit_is_the_oracles(eng, orc, items):
+    """round 6: closest-hit batches of an f64 tree through the guide walk — inner tests in f32 on the grown boxes, every leaf candidate's box AND
+    triangle (Ray::intersects_triangle, ray_impl.rs:154-213) decided in f64, the nearest one kept with the reference's strict < (testbase.rs:831-833):
+    (distance, u, v, shape) of every ray byte-equal to the oracle's loop, rays cut into items and whole, and a batch with a ray outside the
+    guide's range replayed in f64 without the caller noticing."""
+    from bvh_amd import testbase as tb
+    from bvh_amd._lib import TUNE_WIDE_ITEMS_LOG4
+    tris32, a32 = tb.create_n_cubes(2500)
+    tris, aabbs = tris32.astype(np.float64), a32.astype(np.float64)
+    ctx = eng.Context(0)
+    ctx.set_tuning(TUNE_WIDE_ITEMS_LOG4, items)
+    flat = eng.Bvh.from_aabbs(aabbs, ctx).flatten()
+    flat.set_triangles(tris)
+    rng = np.random.default_rng(11)
+    n = 50_000
+    centres = tris.reshape(2500, 36, 3).mean(axis=1)
+    target = centres[rng.integers(0, 2500, size=n)] + rng.uniform(-0.6, 0.6, size=(n, 3))
+    o = rng.uniform(-1e5, 1e5, size=(n, 3))
+    rays = np.concatenate([orc.make_rays(o, target - o, np.float64), _grazing_rays(orc, aabbs, 30_000, 5), orc.create_rays(0, 20_000, dtype=np.float64)])
+    oflat = orc.flatten(orc.build(aabbs).nodes)
+
+    def check(r):
+        ooff, oidx, _, _ = orc.traverse_flat(oflat, aabbs, r, threads=orc.max_threads())
+        _, oclosest, oprim = orc.triangle_stage(tris, r, ooff, oidx)
+        cl, prim, _ = flat.closest_hits(eng.RayBatch(len(r), np.float64, host=np.ascontiguousarray(r)))
+        assert cl.tobytes() == oclosest.tobytes() and np.array_equal(prim, oprim)
+        return np.isfinite(oclosest[:, 0]).sum()
+    assert check(rays) > n // 2
+    assert flat._hits.walk_kernel() == "bvhgpu::k_traverse_wide<float, 3, %d, 1024, 8, 1>" % (2 if items < 0 else 0)
+    S = np.abs(aabbs).max()
+    axis = orc.make_rays(np.array([[-S, 1.0, 2.0]]), np.array([[1.0, 0.0, 0.0]]), np.float64)               # 1/d = inf on two axes: outside the guide's range
+    check(np.concatenate([rays[:30_000], axis, rays[30_000:60_000]]))
+    assert flat._hits.walk_kernel().startswith("bvhgpu::k_traverse_wide<double, 3, ")                       # replayed with the f64 walk

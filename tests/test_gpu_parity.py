@@ -731,8 +731,16 @@ def test_triangle_stage_matches_reference_loop(eng, orc, variant, dtype):
     flat3.set_triangles(tris)
     cl2, prim2, st3 = flat3.closest_hits(_rb(eng, rays))
     assert cl2.tobytes() == oclosest.tobytes() and np.array_equal(prim2, oprim)
-    # (f64: the candidates filed by (ray, item), k_closest_resolve_slots)
-    assert flat3._hits.walk_kernel().startswith("bvhgpu::k_traverse_wide<%s, 3, 2," % ("float" if dtype == np.float32 else "double"))
+    # (f64: the candidates filed by (ray, item), k_closest_resolve_slots — walked over the f32 guide boxes, every candidate's box and triangle decided
+    #  in f64; with the guide off, the f64 walk)
+    assert flat3._hits.walk_kernel().startswith("bvhgpu::k_traverse_wide<float, 3, 2, 1024, 8, %d>" % (0 if dtype == np.float32 else 1))
+    if dtype == np.float64:
+        from bvh_amd._lib import TUNE_WIDE_F64_GUIDE
+        ctx3.set_tuning(TUNE_WIDE_F64_GUIDE, 0)
+        cl2b, prim2b, _ = flat3.closest_hits(_rb(eng, rays))
+        assert cl2b.tobytes() == oclosest.tobytes() and np.array_equal(prim2b, oprim)
+        assert flat3._hits.walk_kernel().startswith("bvhgpu::k_traverse_wide<double, 3, 2,")
+        ctx3.set_tuning(TUNE_WIDE_F64_GUIDE, 1)
     # ... and where the minimum is not unique: pairs of overlapping coplanar triangles (planes z = const, a ray along +z meets both at exactly
     # the same distance) whose centroids lie far apart, so that they sit in different subtrees — different ITEMS of the ray.  The reference keeps
     # the candidate its loop meets first (strict <, testbase.rs:831-833): the key's item number must reproduce that order.

@@ -1,4 +1,5 @@
-"""Markdown summary of a bench.py JSON line for DESIGN.md §7:  python tools/design_numbers.py gpurun_out/<run>/bench_default.json"""
+"""Markdown summary of a bench.py run for DESIGN.md §7:  python tools/design_numbers.py gpurun_out/<run>/bench_detail.json
+(the DETAIL file of the run — round 6 on the stdout line is compact; a round-5 verbose line works too)"""
 import json
 import sys
 
@@ -16,9 +17,14 @@ if j.get("pipelined"):
     print(f"  `pipelined` (one host thread, two streams, never `value`): {j['pipelined']['value']:.0f} Mrays/s.")
 x = j.get("step_excludes") or {}
 if x and "error" not in x:
-    print(f"  What the step excludes (each the same step with it inside, {x.get('steps')} steps; never `value`; {j.get('settle_steps')} untimed settle steps precede the warmup): "
-          + "; ".join(f"`{k}` {x[k]['value']:.0f} Mrays/s ({x[k]['delta_ms_vs_value'] * 1e3:+.0f} µs)" for k in ("with_ray_gen", "with_flat_array", "host_io") if k in x)
+    print(f"  Beside the step (each the same step with the thing changed, {x.get('steps')} steps; never `value`; {j.get('settle_steps')} untimed settle steps precede the warmup; "
+          f"the step's FlatNode array: {j.get('config', {}).get('flat_array', 'lazy')}): "
+          + "; ".join(f"`{k}` {x[k]['value']:.0f} Mrays/s ({x[k]['delta_ms_vs_value'] * 1e3:+.0f} µs)"
+                      for k in ("with_ray_gen", "with_flat_array", "lazy_flat_array", "eager_flat_array", "beside_flat_array", "host_io") if k in x)
           + (f" — host_io moves {sum(x['host_io']['bytes_per_step'].values()) / 1e6:.0f} MB per step at {x['host_io']['pcie_gbs']} GB/s." if "host_io" in x else "."))
+    for k, v in ((x.get("host_io") or {}).get("paths") or {}).items():
+        print(f"    host_io `{k}`: {v['value']:.0f} Mrays/s, {v['ms_per_step']:.4f} ms per step, {v['pcie_gbs']} GB/s over the link"
+              + (f", CSR equal to the pageable path: {str(v.get('csr_equal_to_pageable_path')).lower()}" if "csr_equal_to_pageable_path" in v else ""))
 for e in j.get("extra_configs", []):
     if "error" in e:
         print(f"* {e['workload']} {e['dtype']}: ERROR {e['error']}")
@@ -31,6 +37,8 @@ for e in j.get("extra_configs", []):
               f"build {q['build_ms']:.3f}, flatten {q['flatten_ms']:.3f}, walk + triangle stage {q['traverse_kernel_ms']:.3f}, output {q['traverse_total_ms'] - q['traverse_kernel_ms']:.3f}); "
               f"walk bound `{rr.get('bound')}` {rr.get('frac')}, HBM-side {rr.get('hbm_frac')}; parity equal: {str(e.get('parity', {}).get('equal')).lower()} "
               f"({e.get('parity', {}).get('what')}); the oracle's same loop on {ch.get('cores')} host threads: {ch.get('value')} Mrays/s.")
+        continue
+    if e.get("harness"):
         continue
     tag = {("standin-primary", "weak"): "configs[2] (10 M primary rays, stand-in scene)", ("standin-incoherent", "weak"): "configs[3], one 12.5 M-ray shard",
            ("standin-incoherent", "strong"): "configs[3] whole (100 M rays on one GPU)", ("cubes120k", "weak"): "configs[4] f64, guide walk",
@@ -46,6 +54,8 @@ for e in j.get("extra_configs", []):
               f"{f['phases_ms']['traverse_kernel_ms']:.3f}); bound `{f['roofline'].get('bound')}` {f['roofline'].get('frac')}; parity equal: {str(f.get('parity', {}).get('equal')).lower()}.")
 c = j.get("cpu_baseline")
 if c:
+    legs = c.get("legs") or {}
     print(f"* CPU baseline on the same box (oracle, kind `{c['kind']}`, {c['cores']} threads of {c['host_cpus_visible']} visible CPUs): {c['value']:.1f} Mrays/s "
-          f"(build {c['build_ms']} ms on {c.get('build_threads')} threads, flatten {c['flatten_ms']} ms, traversal {c['traverse_ms_all_cores']} ms, {c['traverse_ns_per_ray_1thread']} ns/ray single-threaded) — "
-          f"the GPU step is {j.get('speedup_vs_cpu_baseline')} x; a reported baseline, not a target.")
+          f"(build {c['build_ms']} ms on {c.get('build_threads')} threads, flatten {c['flatten_ms']} ms, traversal {c['traverse_ms_all_cores']} ms, {c['traverse_ns_per_ray_1thread']} ns/ray single-threaded"
+          + (f"; median of the phases {c['value_median']:.1f}; legs " + ", ".join(f"{k} {v.get('value')}" for k, v in legs.items()) + f"; load average {c.get('host_load_1m')}" if legs else "")
+          + f") — the GPU step is {j.get('speedup_vs_cpu_baseline')} x; a reported baseline, not a target.")
