@@ -901,7 +901,8 @@ constexpr bool LEVEL_DEDICATED = LEVEL_THREADS > 256;
 // BUILD_FLAG_PERSIST_GAVE_UP and the host builds the tree again with a launch per level (build_finalize).
 // (One kernel body for both: `a` must stay the kernel's own by-value parameter — handed to a helper by reference it is copied to scratch,
 //  344 bytes, and every access to it becomes a scratch load: 182 VGPRs and +67 µs per build, measured.)
-constexpr uint32_t XCD_SPIN_MAX = 3000000u;
+constexpr unsigned long long XCD_SPIN_TICKS = 200000ull;   // 2 ms of the 100 MHz wall clock: a group barrier that has not come back by then never will (ADVICE r5:
+                                                           // the bound used to be a poll COUNT — seconds of a stalled stream when the group's workgroups are not co-resident)
 template <typename T, bool ROOT, bool DEV = false> __global__ __launch_bounds__(LEVEL_THREADS) void k_level(BuildArgs<T> a, int L_first) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
@@ -1352,10 +1353,12 @@ template <typename T, bool ROOT, bool DEV = false> __global__ __launch_bounds__(
                 word = (unsigned long long)(uint32_t)(round + 1) | (((old >> 32) + (unsigned long long)s_live) << 32);
                 __hip_atomic_store(go, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
-                uint32_t spins = 0;
-                while ((uint32_t)(word = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (uint32_t)(round + 1) && ++spins < XCD_SPIN_MAX)
+                const unsigned long long t0 = wall_clock64();
+                bool late = false;
+                while ((uint32_t)(word = __hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (uint32_t)(round + 1) &&
+                       !(late = wall_clock64() - t0 > XCD_SPIN_TICKS))
                     __builtin_amdgcn_s_sleep(1);
-                if (spins >= XCD_SPIN_MAX) ok = 0u;
+                if (late) ok = 0u;
             }
             s_word = word; s_go = ok;
         }
@@ -2199,6 +2202,8 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     // Persistent level tier (k_level<T, false, true>): where the eight level-3 subtrees are big enough to be worth a workgroup group each.  A tree on
     // which it once gave up (its workgroups were not resident together: another stream kept the CUs) stays with a launch per level.
     const int persist_knob = ctx->tune[BVHGPU_TUNE_BUILD_LEVEL_PERSIST];
+    // (a tree on which the persistent tier once gave up tries it again 64 builds later: whatever kept its workgroups apart may be gone)
+    if (t->persist_broken && persist_knob != 0 && !redo && t->persist_retry_in > 0 && --t->persist_retry_in == 0) t->persist_broken = false;
     const bool persist = persist_knob != 0 && !t->persist_broken && level_fused<T>(t) && n >= 32 * (MID_MAX + 1);
     if (persist) t->xbar.reserve(XBAR_WORDS * sizeof(unsigned long long));
     for (int i = 0; i < 2; i++) {
@@ -2292,6 +2297,7 @@ template <typename T> void build_finalize(bvhgpu_tree* t) {
     if (t->pend_persist && (pin[CTR_FLAGS] & BUILD_FLAG_PERSIST_GAVE_UP)) {
         // the persistent level tier left the tree unfinished: the same generation again with a launch per level (this tree stays with that)
         t->persist_broken = true;
+        t->persist_retry_in = 64;
         const bool fl = t->pend_flatten;
         build_enqueue<T>(t, static_cast<const T*>(nullptr), n, fl, true);
         build_finalize<T>(t);

@@ -126,7 +126,8 @@ struct bvhgpu_tree {
                                  // grandchildren, so traversal must test every ancestor (binary walk only)
     int pend_level = 0;
     bool pend_persist = false;   // the build in flight ran the level tier's lower passes as one persistent launch (build.hip k_level_xcd)
-    bool persist_broken = false; // ... which once gave up on this tree (its workgroups were not resident together): a launch per level from then on
+    bool persist_broken = false; // ... which gave up on this tree (its workgroups were not resident together): a launch per level for the next
+    int persist_retry_in = 0;    //     persist_retry_in builds, then the persistent tier is tried again
     int levels = 0;
     int hint_levels = 0;         // level-synchronous passes the previous build of hint_n shapes needed
     size_t hint_n = 0;

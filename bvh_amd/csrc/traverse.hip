@@ -1965,6 +1965,8 @@ void traverse_enqueue(bvhgpu_tree* t, const typename Traits<T>::Ray* rays_dev, s
     auto launch_ordered = [&](auto mode_tag, auto asc_tag) {
         constexpr int M = decltype(mode_tag)::value;
         constexpr bool A = decltype(asc_tag)::value;
+        std::snprintf(g_walk_kernel, sizeof g_walk_kernel, "bvhgpu::%s<%s, %d, %s>", best_first ? "k_traverse_heap" : "k_traverse_ordered", type_name<T>(), M,
+                      A ? "true" : "false");
         if (best_first) {   // DistanceTraverseIterator
             const size_t lanes = (size_t)heap_grid * 256;
             if (lanes * h->heap_cap * (sizeof(T) + 4) > ((size_t)16 << 30))

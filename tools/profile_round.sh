@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --pipeline-streams 0 --no-extra --no-parity $*"
+CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --pipeline-streams 0 --no-extra --no-parity --no-excluded $*"   # (--no-excluded: the host-resident variants walk the batch in chunks — the same kernel at other sizes would dilute the per-launch means)
 rocprofv3 --kernel-trace --stats -d $out/trace -o out -- $CMD > $out/bench_under_rocprof.json 2> $out/trace.err
 db=$(ls $out/trace/*.db $out/trace/*/*.db 2>/dev/null | head -1)
 python $R/tools/prof_summary.py $db $out/kernel_stats.md "$tag: $CMD" > /dev/null
