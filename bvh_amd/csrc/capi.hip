@@ -563,7 +563,6 @@ int host_batch_walk(bvhgpu_tree* tree, unsigned flags, uint32_t* offsets, uint32
     hb.indices_host = (hb.offsets_host && indices && indices_cap) ? dev_visible(indices) : nullptr;
     hb.idx_stage = hb.indices_host ? indices_cap : (indices ? std::min(indices_cap, HostBatch::IDX_STAGE_MAX) : 0);
     if (hb.idx_stage && !hb.indices_host) hb.indices.reserve(hb.idx_stage * 4);
-    BVH_HIP(hipMemsetAsync(offs_all, 0, 4, st));   // the first chunk's base
     int enq = 0;
     auto finish_all = [&](bool swallow) {   // every chunk that was enqueued is completed, whatever the first failure was
         bool replayed = false;
@@ -578,7 +577,7 @@ int host_batch_walk(bvhgpu_tree* tree, unsigned flags, uint32_t* offsets, uint32
         const size_t a = hb.r0[k], nk = hb.r0[k + 1] - a;
         offsets_rebase(st, hb.hits[k]->offsets.template as<uint32_t>(), nk, offs_all + a, hb.offsets_host ? hb.offsets_host + a : nullptr,
                        hb.hits[k]->indices.template as<uint32_t>(), hb.indices_host ? hb.indices_host : (hb.idx_stage ? hb.indices.as<uint32_t>() : nullptr),
-                       hb.idx_stage);
+                       hb.idx_stage, k == 0);
     };
     try {
         for (int k = 0; k < K; k++) {
@@ -606,7 +605,6 @@ int host_batch_walk(bvhgpu_tree* tree, unsigned flags, uint32_t* offsets, uint32
         for (int k = 0; k < K; k++) tot += hb.hits[k]->total;
         if (tot > 0xFFFFFFFFull) throw HipFail{hipErrorInvalidValue, "OVERFLOW", __LINE__};
         if (replayed) {   // what went down came from an incomplete walk: rebase again, one copy
-            BVH_HIP(hipMemsetAsync(offs_all, 0, 4, st));
             for (int k = 0; k < K; k++) rebase_chunk(k);
             if (!hb.offsets_host) BVH_HIP(hipMemcpyAsync(offsets, offs_all, (n_rays + 1) * 4, hipMemcpyDeviceToHost, st));
             BVH_HIP(hipStreamSynchronize(st));

@@ -275,7 +275,7 @@ void rays_new(bvhgpu_ctx* ctx, const T* origins_dev, const T* dirs_dev, size_t n
 // out[i] = out[0] + offs[i], i = 1..n_rays; idx_all_dev != NULL: the chunk's index list copied to idx_all_dev[out[0] ..) as far as idx_cap entries reach
 // out_host (device-visible pinned host memory, or NULL): the same values stored there as well; idx_all (device or such host memory)
 void offsets_rebase(hipStream_t st, const uint32_t* offs_dev, size_t n_rays, uint32_t* out_dev, uint32_t* out_host = nullptr,
-                    const uint32_t* idx_dev = nullptr, uint32_t* idx_all = nullptr, size_t idx_cap = 0);
+                    const uint32_t* idx_dev = nullptr, uint32_t* idx_all = nullptr, size_t idx_cap = 0, bool first = false);
 void copy16(hipStream_t st, const void* src, void* dst, size_t bytes);   // a copy KERNEL (src / dst may be device-visible host memory)
 template <typename T>
 void gen_primary(bvhgpu_ctx* ctx, const float cam[14], uint32_t width, uint32_t height, uint64_t first, size_t n,

@@ -2542,27 +2542,30 @@ template void rays_new<double>(bvhgpu_ctx*, const double*, const double*, size_t
 // CSR offsets of one chunk of a host-resident batch (bvhgpu_traverse_host_*), moved to their place in the whole batch's array:
 // out[0] holds the hits of all chunks before this one (written by the previous chunk's pass on the same stream; 0 for the first)
 // (out_host: the caller's own array when it is pinned memory the device can write — the offsets then need no download)
+// (first: the batch's first chunk — its base is 0 and out[0] is written here instead of read)
 __global__ __launch_bounds__(256) void k_offsets_rebase(const uint32_t* __restrict__ offs, uint32_t n_plus_1, uint32_t* __restrict__ out,
-                                                        uint32_t* __restrict__ out_host) {
+                                                        uint32_t* __restrict__ out_host, uint32_t first) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_plus_1) return;
-    const uint32_t v = out[0] + (i ? offs[i] : 0u);
-    if (i) out[i] = v;        // (out[0] is the base itself)
+    const uint32_t v = (first ? 0u : out[0]) + (i ? offs[i] : 0u);
+    if (i || first) out[i] = v;        // (out[0] of a later chunk is the base itself: the previous chunk's last entry)
     if (out_host) out_host[i] = v;
 }
 // ... and its index list appended to the batch's (what fits into `cap` entries): base = out[0], count = offs[n_rays]
 __global__ __launch_bounds__(256) void k_indices_append(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ offs, uint32_t n_rays,
-                                                        const uint32_t* __restrict__ base_ptr, uint32_t* __restrict__ dst, unsigned long long cap) {
-    const unsigned long long base = base_ptr[0], cnt = offs[n_rays];
+                                                        const uint32_t* __restrict__ base_ptr, uint32_t* __restrict__ dst, unsigned long long cap, uint32_t first) {
+    const unsigned long long base = first ? 0ull : base_ptr[0], cnt = offs[n_rays];
     for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < cnt && base + i < cap; i += (unsigned long long)gridDim.x * blockDim.x)
         dst[base + i] = idx[i];
 }
 void offsets_rebase(hipStream_t st, const uint32_t* offs_dev, size_t n_rays, uint32_t* out_dev, uint32_t* out_host, const uint32_t* idx_dev,
-                    uint32_t* idx_all, size_t idx_cap) {
+                    uint32_t* idx_all, size_t idx_cap, bool first) {
     // (the index list first: it reads the chunk's base out[0] and the chunk-local count, both untouched by the rebase)
     if (idx_all && idx_cap)
-        hipLaunchKernelGGL(k_indices_append, dim3(128), dim3(256), 0, st, idx_dev, offs_dev, (uint32_t)n_rays, out_dev, idx_all, (unsigned long long)idx_cap);
-    hipLaunchKernelGGL(k_offsets_rebase, dim3((unsigned)((n_rays + 1 + 255) / 256)), dim3(256), 0, st, offs_dev, (uint32_t)(n_rays + 1), out_dev, out_host);
+        hipLaunchKernelGGL(k_indices_append, dim3(128), dim3(256), 0, st, idx_dev, offs_dev, (uint32_t)n_rays, out_dev, idx_all, (unsigned long long)idx_cap,
+                           first ? 1u : 0u);
+    hipLaunchKernelGGL(k_offsets_rebase, dim3((unsigned)((n_rays + 1 + 255) / 256)), dim3(256), 0, st, offs_dev, (uint32_t)(n_rays + 1), out_dev, out_host,
+                       first ? 1u : 0u);
     BVH_HIP(hipGetLastError());
 }
 

@@ -110,6 +110,18 @@ def test_small_and_empty_batches(eng, orc):
         ooff, oidx = _oracle_csr(orc, aabbs, rays) if n else (np.zeros(1, np.uint32), np.zeros(0, np.uint32))
         assert total == len(oidx) and np.array_equal(off, ooff) and np.array_equal(idx[:total], oidx), n
     bvh.close()
+    # an empty hierarchy (bvh_impl.rs:57-59: no nodes, every traversal returns nothing) and one with a single shape (flat_bvh.rs:129-141)
+    o, d, rays = _od(orc, 0, 40_000, np.float32)
+    for a in (np.zeros((0, 6), np.float32), aabbs[:1]):
+        tree = Bvh.from_aabbs(a, ctx); tree.flatten_in_place()
+        off, idx = np.full(len(o) + 1, 7, np.uint32), np.zeros(4096, np.uint32)
+        total = tree.traverse_host(o, d, off, idx)
+        if len(a):
+            ooff, oidx = _oracle_csr(orc, a, rays)
+        else:
+            ooff, oidx = np.zeros(len(o) + 1, np.uint32), np.zeros(0, np.uint32)
+        assert total == len(oidx) and np.array_equal(off, ooff) and np.array_equal(idx[:total], oidx), len(a)
+        tree.close()
 
 
 @pytest.mark.parametrize("pinned", [False, True])
