@@ -50,9 +50,10 @@ def parse(argv=None):
     A("--scaling", choices=["weak", "strong"], default=None, help="weak: --rays per GPU; strong: --rays in total, sharded over the GPUs")
     A("--scene-dist", choices=["auto", "bcast", "replicate", "bcast-torch"], default="auto",
       help="N>1: RCCL-broadcast rank 0's flattened tree through the C ABI each step, or rebuild it on every rank; auto measures both")
-    A("--flat-array", choices=["eager", "beside", "lazy"], default="eager",
-      help="the reference-layout FlatNode array (what Bvh::flatten returns) is written in every step: eager = by the flatten kernel, "
-           "beside = by a second pass on the side stream beside the walk; lazy: on first use (NOT in the step)")
+    A("--flat-array", choices=["eager", "all", "beside", "lazy"], default="eager",
+      help="the reference-layout FlatNode array (what Bvh::flatten returns) is written in every step: eager = by the flatten kernel "
+           "(the engine's own folded binary array on first use), all = both arrays, beside = both by a second pass beside the walk; "
+           "lazy: on first use (NOT in the step)")
     A("--collective-timeout", type=float, default=60.0, help="N>1: seconds the exchange plan may take before the replicate line is printed")
     A("--regions", type=int, default=5, help="timed regions of exactly K steps each; `value` is the median region, all are on the line")
     A("--settle-steps", type=int, default=300, help="untimed steps before the W warmup steps (clock ramp; at most 20 for big batches)")
@@ -244,7 +245,7 @@ def run_workload(wl, args, env, steps, warmup, detailed, force_plan=None, region
         "unit": "Mrays/s", "ms_per_step": round(ms_per_step, 4), "steps": steps, "warmup": warmup, "settle_steps": settle,
         "regions_ms_per_step": [round(t * 1e3 / max(steps, 1), 4) for t in region_s],
         "scaling": wl.scaling, "triangles": wl.n_tri, "rays_this_rank": wl.R, "rays_total": wl.total_rays, "scene_dist": plan,
-        "flat_array": {0: "eager", 1: "lazy", 2: "beside"}[ctx.get_tuning(TUNE_FLATTEN_LAZY)],
+        "flat_array": {0: "all", 1: "lazy", 2: "beside", 3: "eager"}[ctx.get_tuning(TUNE_FLATTEN_LAZY)],
         "hits_all_ranks": int(hits_all), "visited_per_ray": round(stats["visited"] / max(wl.R, 1), 2),
         "scene_dist_probe_ms_per_step": {k: round(v, 4) for k, v in probe_ms.items()} or None,
     }
@@ -321,7 +322,7 @@ def compact_line(d):
         if "error" in x:
             out["step_excludes"] = {"error": x["error"][:200]}
         else:
-            keys = ("with_ray_gen", "lazy_flat_array", "eager_flat_array", "beside_flat_array")
+            keys = ("with_ray_gen", "lazy_flat_array", "eager_flat_array", "all_arrays_eager", "beside_flat_array")
             out["step_excludes"] = {k: x[k]["value"] for k in keys if k in x}
             h = x.get("host_io")
             if h:
@@ -407,7 +408,7 @@ def main():
     # the ctx creates a non-blocking stream of its own — either way the timed region is bracketed by torch.cuda.synchronize(dev)
     # (device-wide), and everything the engine does for one step is on that one stream
     ctx = Context(local_rank, stream=torch.cuda.current_stream(dev).cuda_stream)
-    ctx.set_tuning(TUNE_FLATTEN_LAZY, {"eager": 0, "lazy": 1, "beside": 2}[args.flat_array])
+    ctx.set_tuning(TUNE_FLATTEN_LAZY, {"all": 0, "lazy": 1, "beside": 2, "eager": 3}[args.flat_array])
     for k, v in os.environ.items():   # developer A/B runs: BVH_TUNE_<knob>=<value> (tools/ab_tune.sh); results never depend on a knob
         if k.startswith("BVH_TUNE_"):
             ctx.set_tuning(int(k[9:]), int(v))

@@ -400,9 +400,9 @@ def measure_excluded(wl, args, env, ms_step):
     (device sync on both sides):
       with_ray_gen      Ray::new for every ray of the batch (ray_impl.rs:70-80 via create_ray, testbase.rs:687-691: the reference's
                         bench iteration starts with it) generated on the device inside the step — k_gen_rays on the step's stream
-      lazy / eager / beside_flat_array   the step of `value` writes the reference-layout FlatNode array + the folded binary array in every
-                        step (flat_bvh.rs:60-143; --flat-array); the other ways: on first use (lazy: NOT in the step), in the flatten kernel
-                        itself (eager), by a second pass on the side stream beside the walk (beside)
+      lazy / all / beside ...   the step of `value` writes the reference-layout FlatNode array in every flatten (flat_bvh.rs:60-143;
+                        --flat-array eager; the engine's own folded binary array follows on first use); the other ways: on first use
+                        (lazy: NOT in the step), both arrays in the flatten kernel (all_arrays_eager), both by a second pass beside the walk
       host_io           shape AABBs and rays start in HOST memory, the CSR ends in host memory: what GpuBvh::build + traverse_batch
                         of the Rust shim costs a caller whose data lives in Vecs (rust/bvh-mi355x/src/lib.rs) — upload, step, download"""
     import torch
@@ -443,7 +443,7 @@ def measure_excluded(wl, args, env, ms_step):
     def step_index():
         bvh.rebuild_async(wl.aabbs)
         return bvh.traverse_async(wl.rays, flags=TRAVERSE_RAYS_READY).wait()
-    for mode, key in ((1, "lazy_flat_array"), (0, "eager_flat_array"), (2, "beside_flat_array")):
+    for mode, key in ((1, "lazy_flat_array"), (3, "eager_flat_array"), (0, "all_arrays_eager"), (2, "beside_flat_array")):
         if mode == prev:
             continue
         ctx.set_tuning(TUNE_FLATTEN_LAZY, mode)

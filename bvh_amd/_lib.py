@@ -159,7 +159,7 @@ TUNE_WIDE_STAGE_SHIFT = 12       # wide walk, whole rays, indices only: 2^v shap
 TUNE_WIDE_REC8 = 13              # wide walk, whole rays, indices only: pair records, 8 bytes per hit (1, default) or the 12-byte HitRec (0)
 TUNE_BUILD_LEVEL_LAUNCHES = 10   # builder, level tier: 1 one launch per level, 2 k_bin + k_split per level, 0 (default) by scene size
 TUNE_WIDE_F64_GUIDE = 14        # wide walk, f64 trees, indices only: walk the f32 guide boxes, test leaf candidates in f64 (1, default) or the f64 walk (0)
-TUNE_FLATTEN_LAZY = 15           # the flatten behind a build writes the wide walk's arrays; FlatNode / binary arrays follow on first use (1, default), at once (0), or at once on the side stream beside the walk (2)
+TUNE_FLATTEN_LAZY = 15           # the flatten behind a build writes the wide walk's arrays; FlatNode / binary arrays follow on first use (1, default), at once (0), at once on the side stream beside the walk (2), or the FlatNode array at once and the binary array on first use (3)
 TUNE_WIDE_MIN_RAYS_PER_WG = 18   # wide walk over items, batches below 512 K rays: spread over all workgroup slots down to this many rays each (256 default, 0 off)
 TUNE_HOST_ZERO_COPY = 19         # host batches on pinned buffers: bit 0 the device reads the ray arrays itself, bit 1 it writes offsets / indices itself (2 default)
 TUNE_HOST_CHUNKS = 17            # bvhgpu_traverse_host_*: chunks the batch is walked in (0, default = by batch size)

@@ -100,6 +100,7 @@ struct bvhgpu_tree {
     bool flattened = false; // has trav (+ flat if built) — or owes them: see lazy_flat
     bool lazy_flat = false; // the flatten of this generation wrote the wide walk's arrays only (BVHGPU_TUNE_FLATTEN_LAZY): flat / trav /
                             // slot_entry are written by ensure_flat_arrays() the first time something reads them
+    int lazy_parts = 0;     // ... which of them (flatten.hip FLATTEN_FLAT | FLATTEN_TRAV; BVHGPU_TUNE_FLATTEN_LAZY = 3 owes the binary array only)
     bool flat_beside = false;   // part 1 of this generation's flatten (flat / trav / slot_entry) is in flight on the ctx's SIDE stream
     hipEvent_t ev_flat0 = nullptr, ev_flat = nullptr;   // (BVHGPU_TUNE_FLATTEN_LAZY = 2): main → side, side → main (join_flat)
     bool unfolded = false;  // trav mirrors an uploaded FlatBvh 1:1 (nav and leaf entries kept apart)

@@ -116,7 +116,7 @@ __device__ __forceinline__ void flatten_wide_node(const typename Traits<T>::Node
 // PARTS: bit 0 = the FlatNode array (reference layout), the folded binary array and the binary walk's LDS slot table; bit 1 = the wide
 // nodes (+ an f64 tree's guide nodes) and their LDS slot table.  3 = everything in one pass; with BVHGPU_TUNE_FLATTEN_LAZY the flatten
 // behind a build runs part 2 — what the wide walk reads — and part 1 follows when something asks for those arrays (ensure_flat_arrays).
-constexpr int FLATTEN_FLAT = 1, FLATTEN_WIDE = 2;
+constexpr int FLATTEN_FLAT = 1, FLATTEN_WIDE = 2, FLATTEN_TRAV = 4;   // FLAT: the reference-layout FlatNode array; TRAV: the folded binary array + its LDS slot table
 template <typename T, int PARTS>
 __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node* __restrict__ nodes,
                                                  const uint32_t* __restrict__ node_start,
@@ -152,16 +152,20 @@ __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node*
         if (!odd_level) flatten_wide_node<T>(nodes, nd, i, node_slot, wide, wslot_node, n_nodes, n_shapes, guide);
         if (guide_info && i == 0) guide_info[0] = (float)guide_scene_extent<T>(nd.l_min, nd.l_max, nd.r_min, nd.r_max);   // (read by the ray conversion of the guide walk)
     }
-    if (!(PARTS & FLATTEN_FLAT)) return;
+    if (!(PARTS & (FLATTEN_FLAT | FLATTEN_TRAV))) return;
     if (n_nodes == 1) {
         // single-shape tree: the root is a leaf and emits one leaf entry (flat_bvh.rs:129-141); its
         // traversal entry tests the shape's own AABB (flat_bvh.rs:411-418)
-        typename Tr::Flat f = {};
-        for (int k = 0; k < 3; k++) { f.min[k] = Tr::inf(); f.max[k] = -Tr::inf(); }
-        f.entry = NONE; f.exit = 1; f.shape = nd.shape;
-        flat[0] = f;
-        const T* sb = aabbs + 6 * (size_t)nd.shape;
-        write_trav<T>(&trav[0], sb, sb + 3, 1u, nd.shape);
+        if (PARTS & FLATTEN_FLAT) {
+            typename Tr::Flat f = {};
+            for (int k = 0; k < 3; k++) { f.min[k] = Tr::inf(); f.max[k] = -Tr::inf(); }
+            f.entry = NONE; f.exit = 1; f.shape = nd.shape;
+            flat[0] = f;
+        }
+        if (PARTS & FLATTEN_TRAV) {
+            const T* sb = aabbs + 6 * (size_t)nd.shape;
+            write_trav<T>(&trav[0], sb, sb + 3, 1u, nd.shape);
+        }
         return;
     }
     if (i == 0) return;  // the root emits nothing itself (flat_bvh.rs:104-127)
@@ -182,32 +186,38 @@ __global__ __launch_bounds__(256) void k_flatten(const typename Traits<T>::Node*
     const uint32_t L = node_start[i], kcnt = node_count[i];
     // the builder numbered the nodes heap-style (root 1, children 2h / 2h+1): the first TopCfg<T>::SLOTS of
     // them are the top of the tree that traversal keeps in LDS; slot h holds traversal entry i-1
-    const uint32_t myslot = node_slot[i];
-    if (myslot < TopCfg<T>::SLOTS) slot_entry[myslot] = i - 1;
-    const uint32_t nav = i - 1 + L;
-    typename Tr::Flat f = {};
-#pragma unroll
-    for (int k = 0; k < 3; k++) { f.min[k] = mn[k]; f.max[k] = mx[k]; }
-    f.entry = nav + 1;
-    f.exit = nav + 3 * kcnt - 1;
-    f.shape = NONE;
-    flat[nav] = f;
     const bool leaf = nd.shape != NONE;
-    if (leaf) {
-        typename Tr::Flat lf = {};
+    if (PARTS & FLATTEN_FLAT) {
+        const uint32_t nav = i - 1 + L;
+        typename Tr::Flat f = {};
 #pragma unroll
-        for (int k = 0; k < 3; k++) { lf.min[k] = Tr::inf(); lf.max[k] = -Tr::inf(); }
-        lf.entry = NONE; lf.exit = nav + 2; lf.shape = nd.shape;
-        flat[nav + 1] = lf;
-        // folded leaf: one test against the shape's own AABB.  For a tree built here it is
-        // bit-identical to the navigator box (join(empty, aabb) == aabb), so nav-then-leaf of
-        // flat_bvh.rs:411-427 collapses to a single slab test with the same outcome.
-        const T* sb = aabbs + 6 * (size_t)nd.shape;
-        write_trav<T>(&trav[i - 1], sb, sb + 3, i, nd.shape);
-    } else {
-        const uint32_t ex = (i - 1) + (2 * kcnt - 1);                       // first entry after the subtree
-        const uint32_t exs = ex + 1 < n_nodes ? (uint32_t)node_slot[ex + 1] : SLOT_NONE;  // entry ex belongs to tree node ex+1
-        write_trav<T>(&trav[i - 1], mn, mx, ex, TRAV_INNER | exs);
+        for (int k = 0; k < 3; k++) { f.min[k] = mn[k]; f.max[k] = mx[k]; }
+        f.entry = nav + 1;
+        f.exit = nav + 3 * kcnt - 1;
+        f.shape = NONE;
+        flat[nav] = f;
+        if (leaf) {
+            typename Tr::Flat lf = {};
+#pragma unroll
+            for (int k = 0; k < 3; k++) { lf.min[k] = Tr::inf(); lf.max[k] = -Tr::inf(); }
+            lf.entry = NONE; lf.exit = nav + 2; lf.shape = nd.shape;
+            flat[nav + 1] = lf;
+        }
+    }
+    if (PARTS & FLATTEN_TRAV) {
+        const uint32_t myslot = node_slot[i];
+        if (myslot < TopCfg<T>::SLOTS) slot_entry[myslot] = i - 1;
+        if (leaf) {
+            // folded leaf: one test against the shape's own AABB.  For a tree built here it is
+            // bit-identical to the navigator box (join(empty, aabb) == aabb), so nav-then-leaf of
+            // flat_bvh.rs:411-427 collapses to a single slab test with the same outcome.
+            const T* sb = aabbs + 6 * (size_t)nd.shape;
+            write_trav<T>(&trav[i - 1], sb, sb + 3, i, nd.shape);
+        } else {
+            const uint32_t ex = (i - 1) + (2 * kcnt - 1);                       // first entry after the subtree
+            const uint32_t exs = ex + 1 < n_nodes ? (uint32_t)node_slot[ex + 1] : SLOT_NONE;  // entry ex belongs to tree node ex+1
+            write_trav<T>(&trav[i - 1], mn, mx, ex, TRAV_INNER | exs);
+        }
     }
 }
 
@@ -343,7 +353,7 @@ template <typename T> static void flat_beside(bvhgpu_tree* t) {
     t->trav.reserve(t->n_trav * sizeof(TravNode<T>));
     BVH_HIP(hipEventRecord(t->ev_flat0, ctx->stream));
     BVH_HIP(hipStreamWaitEvent(ctx->side, t->ev_flat0, 0));
-    launch_flatten<T, FLATTEN_FLAT>(t, false, false, nullptr, nullptr, 0, nullptr, 0, 0, ctx->side);
+    launch_flatten<T, FLATTEN_FLAT | FLATTEN_TRAV>(t, false, false, nullptr, nullptr, 0, nullptr, 0, 0, ctx->side);
     BVH_HIP(hipEventRecord(t->ev_flat, ctx->side));
     t->lazy_flat = false;
     t->flat_beside = true;
@@ -361,14 +371,19 @@ template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr, uint3
     if (with_wide) t->wide.reserve((size_t)nn * sizeof(WideNode<T>));
     const bool with_guide = with_wide && sizeof(T) == 8;
     if (with_guide) { t->wide_guide.reserve((size_t)nn * sizeof(WideNode<float>)); t->guide_info.reserve(16); }
-    if (wide_only && with_wide) {   // (a tree without wide nodes is walked by the binary kernels: nothing to postpone)
+    if (wide_only && with_wide && t->ctx->tune[BVHGPU_TUNE_FLATTEN_LAZY] == 3) {
+        // the reference's FlatNode array at once (what Bvh::flatten returns), the engine's own folded binary array on first use
+        t->flat.reserve(t->n_flat * sizeof(typename Tr::Flat));
+        launch_flatten<T, FLATTEN_FLAT | FLATTEN_WIDE>(t, true, with_guide, pub_ctr, pub_host, pub_words, bstat, flags_idx, level_idx);
+        t->lazy_flat = true; t->lazy_parts = FLATTEN_TRAV;
+    } else if (wide_only && with_wide) {   // (a tree without wide nodes is walked by the binary kernels: nothing to postpone)
         launch_flatten<T, FLATTEN_WIDE>(t, true, with_guide, pub_ctr, pub_host, pub_words, bstat, flags_idx, level_idx);
-        t->lazy_flat = true;
+        t->lazy_flat = true; t->lazy_parts = FLATTEN_FLAT | FLATTEN_TRAV;
         if (t->ctx->tune[BVHGPU_TUNE_FLATTEN_LAZY] == 2) flat_beside<T>(t);
     } else {
         t->flat.reserve(t->n_flat * sizeof(typename Tr::Flat));
         t->trav.reserve(t->n_trav * sizeof(TravNode<T>));
-        launch_flatten<T, FLATTEN_FLAT | FLATTEN_WIDE>(t, with_wide, with_guide, pub_ctr, pub_host, pub_words, bstat, flags_idx, level_idx);
+        launch_flatten<T, FLATTEN_FLAT | FLATTEN_TRAV | FLATTEN_WIDE>(t, with_wide, with_guide, pub_ctr, pub_host, pub_words, bstat, flags_idx, level_idx);
     }
     t->has_wide = with_wide;
     t->has_guide = with_guide;
@@ -381,14 +396,17 @@ void ensure_flat_arrays(bvhgpu_tree* t) {
     join_flat(t);
     if (!t->lazy_flat) return;
     t->lazy_flat = false;
+    const bool trav_only = t->lazy_parts == FLATTEN_TRAV;   // (BVHGPU_TUNE_FLATTEN_LAZY = 3: the FlatNode array is there already)
     if (t->dtype == BVHGPU_F32) {
         t->flat.reserve(t->n_flat * sizeof(Traits<float>::Flat));
         t->trav.reserve(t->n_trav * sizeof(TravNode<float>));
-        launch_flatten<float, FLATTEN_FLAT>(t, false, false, nullptr, nullptr, 0, nullptr, 0, 0);
+        if (trav_only) launch_flatten<float, FLATTEN_TRAV>(t, false, false, nullptr, nullptr, 0, nullptr, 0, 0);
+        else launch_flatten<float, FLATTEN_FLAT | FLATTEN_TRAV>(t, false, false, nullptr, nullptr, 0, nullptr, 0, 0);
     } else {
         t->flat.reserve(t->n_flat * sizeof(Traits<double>::Flat));
         t->trav.reserve(t->n_trav * sizeof(TravNode<double>));
-        launch_flatten<double, FLATTEN_FLAT>(t, false, false, nullptr, nullptr, 0, nullptr, 0, 0);
+        if (trav_only) launch_flatten<double, FLATTEN_TRAV>(t, false, false, nullptr, nullptr, 0, nullptr, 0, 0);
+        else launch_flatten<double, FLATTEN_FLAT | FLATTEN_TRAV>(t, false, false, nullptr, nullptr, 0, nullptr, 0, 0);
     }
 }
 

@@ -423,7 +423,9 @@ typedef enum {
                                               folded binary array are written by a second pass the first time something asks for them (bvhgpu_flat_nodes,
                                               a binary / STATS / t-slice / ordered walk, nearest_to, scene export, a broadcast) — same arrays, byte for byte;
                                               0 = every flatten writes everything at once; 2 = every flatten writes everything, the second pass on the ctx's side
-                                              stream BESIDE the walk that follows (the walk reads none of it); the batch's wait covers it */
+                                              stream BESIDE the walk that follows (the walk reads none of it); the batch's wait covers it; 3 = every flatten writes
+                                              the reference-layout FlatNode array (what Bvh::flatten returns) and the wide walk's arrays; only the engine's own folded
+                                              binary array waits for its first reader */
     BVHGPU_TUNE_BUILD_LEVEL_PERSIST = 16,  /* builder, level tier with one launch per level, scenes of 32 x 769 shapes and more: != 0 = the tier's passes from tree level 4 on run as
                                               ONE persistent launch, a workgroup group per level-3 subtree that synchronises with itself after every pass (1 = 32 workgroups
                                               per group, 8 .. 64 = that many); 0 (default) = a launch per level throughout.  Measured on configs[1]: 64 per group builds in

@@ -41,7 +41,7 @@ def test_default_line_sections_at_a_small_size():
     assert roof["kernel"].startswith("bvhgpu::k_traverse_wide<float, 0, ") and roof["kernel"].endswith(">")      # as the library spells it
     assert roof["algorithmic_frac"] > 0 and set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(roof)
     ex, exd = out["step_excludes"], det["step_excludes"]
-    for k in ("with_ray_gen", "lazy_flat_array", "beside_flat_array", "host_io"):
+    for k in ("with_ray_gen", "lazy_flat_array", "all_arrays_eager", "beside_flat_array", "host_io"):
         assert ex[k] > 0 and exd[k]["value"] == ex[k] and exd[k]["ms_per_step"] > 0, ex
     pg, pn = exd["host_io"]["paths"]["pageable"], exd["host_io"]["paths"]["pinned"]
     assert pg["bytes_per_step"]["aabbs_up"] == 2500 * 12 * 24 and pg["bytes_per_step"]["rays_up"] == 200000 * 36

@@ -335,7 +335,7 @@ def test_lazy_flatten_same_arrays_whoever_asks_first(eng, orc, dtype):
     ooff, oidx, ots, ost = orc.traverse_flat(oflat, aabbs, rays, want_t=True, threads=orc.max_threads())
     pts = np.random.default_rng(3).uniform(-900, 900, size=(500, 3)).astype(dtype)
     firsts = ["flat_nodes", "stats_walk", "wide_walk_then_flat", "scene_blob", "nearest", "async_step"]
-    for lazy in (1, 0, 2):      # 2: the second pass at once, on the side stream beside the walk (what bench.py's headline step runs)
+    for lazy in (1, 0, 2, 3):      # 2: the second pass at once, on the side stream beside the walk; 3: the FlatNode array at once, the binary array on first use (bench.py's step)
         for first in firsts:
             ctx = Context(0)
             ctx.set_tuning(TUNE_FLATTEN_LAZY, lazy)

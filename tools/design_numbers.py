@@ -20,7 +20,7 @@ if x and "error" not in x:
     print(f"  Beside the step (each the same step with the thing changed, {x.get('steps')} steps; never `value`; {j.get('settle_steps')} untimed settle steps precede the warmup; "
           f"the step's FlatNode array: {j.get('config', {}).get('flat_array', 'lazy')}): "
           + "; ".join(f"`{k}` {x[k]['value']:.0f} Mrays/s ({x[k]['delta_ms_vs_value'] * 1e3:+.0f} µs)"
-                      for k in ("with_ray_gen", "with_flat_array", "lazy_flat_array", "eager_flat_array", "beside_flat_array", "host_io") if k in x)
+                      for k in ("with_ray_gen", "with_flat_array", "lazy_flat_array", "eager_flat_array", "all_arrays_eager", "beside_flat_array", "host_io") if k in x)
           + (f" — host_io moves {sum(x['host_io']['bytes_per_step'].values()) / 1e6:.0f} MB per step at {x['host_io']['pcie_gbs']} GB/s." if "host_io" in x else "."))
     for k, v in ((x.get("host_io") or {}).get("paths") or {}).items():
         print(f"    host_io `{k}`: {v['value']:.0f} Mrays/s, {v['ms_per_step']:.4f} ms per step, {v['pcie_gbs']} GB/s over the link"
