@@ -190,6 +190,34 @@ def test_host_batch_on_a_tree_that_is_still_building(eng, orc):
     hs.close(); bvh.close()
 
 
+def test_registered_caller_memory(eng, orc):
+    """bvhgpu_host_register: memory the caller already owns (ordinary numpy arrays here, a Vec's allocation in Rust) announced once — the batch then
+    runs at pinned speed and the device writes offsets / indices straight into those arrays.  Same CSR as ever."""
+    import ctypes as C
+    from bvh_amd import Bvh, Context, _lib, testbase as tb
+    ctx = Context(0)
+    lib = _lib.load()
+    _, aabbs = tb.create_n_cubes(3000)
+    n = 300_000
+    o, d, rays = _od(orc, 0, n, np.float32)
+    ooff, oidx = _oracle_csr(orc, aabbs, rays)
+    od = np.ascontiguousarray(np.concatenate([o, d], axis=1))
+    off, idx = np.full(n + 1, 0xABABABAB, np.uint32), np.full(max(len(oidx), 1) + 100, 0xABABABAB, np.uint32)
+    regs = [od, off, idx]
+    for a in regs:
+        assert lib.bvhgpu_host_register(ctx._h, a.ctypes.data_as(C.c_void_p), a.nbytes) == 0
+    try:
+        bvh = Bvh.from_aabbs(aabbs, ctx); bvh.flatten_in_place()
+        for _ in range(2):
+            off[:] = 0xABABABAB; idx[:] = 0xABABABAB
+            assert bvh.traverse_host(od, None, off, idx, od6=True) == len(oidx)
+            assert np.array_equal(off, ooff) and np.array_equal(idx[:len(oidx)], oidx) and (idx[len(oidx):] == 0xABABABAB).all()
+        bvh.close()
+    finally:
+        for a in regs:
+            assert lib.bvhgpu_host_unregister(ctx._h, a.ctypes.data_as(C.c_void_p)) == 0
+
+
 def test_pinned_memory_entry_points(eng):
     import ctypes as C
     from bvh_amd import Context, _lib
