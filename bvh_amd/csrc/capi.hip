@@ -428,17 +428,19 @@ int do_nearest(bvhgpu_tree* t, const T* points, size_t n, int mem, int kind, uin
 }
 
 
-// ---- host-resident batches (ABI 7): bvhgpu_traverse_host_* ------------------------------------------------------------------------
+// ---- host-resident batches (ABI 7): bvhgpu_traverse_host_* / bvhgpu_build_traverse_host_* -------------------------------------------
 // What GpuBvh::traverse_batch of the Rust shim costs a caller whose rays live in host memory and who wants the hit lists back there is a
 // PCIe problem, not a kernel problem: 1 M rays are 36 MB as Ray structs and 24 MB as origins + directions, the CSR offsets 4 MB.  The
-// batch is cut into chunks, each an ordinary asynchronous batch on a result object of its own:
-//   up stream    chunk k+1: origins + directions H2D, Ray::new on the device (k_rays_new: the correctly rounded divide and square
-//                root give the bits Ray::new gives, ray_impl.rs:70-80)
-//   main stream  chunk k: the walk + CSR assembly (behind the tree's build if that is still in flight: the uploads do not wait for
-//                it), then its offsets rebased into the batch's array
-//   down stream  chunk k-1: offsets D2H
-// and one host wait at the end, after which the (small) index lists follow.  A chunk that had to be replayed (hit pool too small on
-// a first batch, a build that finished on the slow path) sends the offsets again, in one piece.
+// batch is cut into chunks (host_batch_upload says how), each an ordinary asynchronous batch on a result object of its own:
+//   upload stream  chunk k+1: origins + directions H2D (the copy engines; one transfer per chunk in the OD6 layout)
+//   main stream    [the tree's build, if one is in flight: the uploads do not wait for it]  chunk k: Ray::new (k_rays_new: the correctly
+//                  rounded divide and square root give the bits Ray::new gives, ray_impl.rs:70-80), the walk + CSR assembly, then the
+//                  chunk's index list appended to the batch's and its offsets rebased into the batch's array — through their host
+//                  addresses straight into the caller's arrays when those are pinned (BVHGPU_TUNE_HOST_ZERO_COPY bit 1)
+//   download stream (result arrays that are NOT pinned) chunk k-1: offsets D2H; behind the last chunk the index lists, as many entries as
+//                  the previous batch had hits
+// and ONE host wait at the end.  A chunk that had to be replayed (hit pool too small on a first batch, a build that finished on the
+// slow path) sends its results again, in one piece.
 void free_host_batch(bvhgpu_ctx* ctx) {
     HostBatch* hb = ctx->host;
     if (!hb) return;
@@ -598,7 +600,13 @@ int host_batch_walk(bvhgpu_tree* tree, unsigned flags, uint32_t* offsets, uint32
             if (nk + 1 > skip) BVH_HIP(hipMemcpyAsync(offsets + a + skip, offs_all + a + skip, (nk + 1 - skip) * 4, hipMemcpyDeviceToHost, hb.down));
         }
         uint64_t sent = hb.indices_host ? hb.idx_stage : std::min<uint64_t>(hb.guess, hb.idx_stage);
-        if (sent && !hb.indices_host) BVH_HIP(hipMemcpyAsync(indices, hb.indices.p, sent * 4, hipMemcpyDeviceToHost, hb.down));
+        if (sent && !hb.indices_host) {
+            // (behind the last chunk's append on the main stream — also when the offsets went straight to a pinned array and no chunk
+            //  has tied the download stream to the main stream yet)
+            BVH_HIP(hipEventRecord(hb.ev_done[K - 1], st));
+            BVH_HIP(hipStreamWaitEvent(hb.down, hb.ev_done[K - 1], 0));
+            BVH_HIP(hipMemcpyAsync(indices, hb.indices.p, sent * 4, hipMemcpyDeviceToHost, hb.down));
+        }
         const bool replayed = finish_all(false);
         BVH_HIP(hipStreamSynchronize(hb.down));
         uint64_t tot = 0;

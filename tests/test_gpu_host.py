@@ -76,8 +76,18 @@ def test_host_batch_equals_oracle_and_device_path(eng, orc, dtype, chunks, zero_
     assert bvh.traverse_host(od_page, None, off6, idx6, od6=True) == len(oidx)
     assert np.array_equal(off6, ooff) and np.array_equal(idx6[:len(oidx)], oidx)
     hs6.close()
-    # the caller's own Ray structs out of pinned memory
+    # result arrays of two kinds: pinned offsets with pageable indices (the device writes the one, the download stream carries the other) and the reverse
     from bvh_amd.api import pinned_array
+    for rep in range(2):
+        p_off, g_idx = pinned_array(ctx, (n + 1,), np.uint32), np.zeros(max(len(oidx), 1), np.uint32)
+        p_off[:] = 0
+        assert bvh.traverse_host(hs.origins, hs.directions, p_off, g_idx) == len(oidx)
+        assert np.array_equal(p_off, ooff) and np.array_equal(g_idx[:len(oidx)], oidx), rep
+        g_off, p_idx = np.zeros(n + 1, np.uint32), pinned_array(ctx, (max(len(oidx), 1),), np.uint32)
+        p_idx[:] = 0
+        assert bvh.traverse_host(hs.origins, hs.directions, g_off, p_idx) == len(oidx)
+        assert np.array_equal(g_off, ooff) and np.array_equal(p_idx[:len(oidx)], oidx), rep
+    # the caller's own Ray structs out of pinned memory
     pr = pinned_array(ctx, (n,), rays.dtype)
     pr[:] = rays
     hs.offsets[:] = 0; hs.indices[:] = 0
