@@ -170,6 +170,42 @@ def test_committed_lines_of_this_round_are_compact():
         assert j["roofline"]["frac"] is not None and j["cpu_baseline"]["value"] > 0 and j["parity"]["equal"] is True, f
 
 
+def test_committed_line_is_what_the_renderer_makes_of_the_committed_detail():
+    """the evidence chain's first link: every stdout line committed from round 6 on is exactly bench.render_line() of the detail file committed
+    beside it — nothing on the line that the detail does not carry, nothing reformatted by hand"""
+    b = _bench()
+    seen = 0
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.json"))):
+        d = f.replace("_bench_default.json", "_bench_detail.json")
+        if int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)) < 6 or not os.path.exists(d):
+            continue
+        line = json.loads(open(f).read().strip().splitlines()[-1])
+        again = json.loads(b.render_line(json.loads(open(d).read())))
+        assert again == line, f
+        seen += 1
+    assert seen >= 1
+
+
+def test_cpu_baseline_leg_runs_as_a_process_of_its_own(tmp_path):
+    """oracle/baseline_leg.py — bench.py's cpu_baseline, pinned and free — on a tiny scene: one JSON object with the contract's keys"""
+    import subprocess
+    import sys
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from oracle import orc
+    _, a = orc.create_n_cubes(300)
+    np.save(tmp_path / "a.npy", a)
+    np.save(tmp_path / "r.npy", orc.create_rays(0, 20000))
+    for env_extra in ({}, {"OMP_PROC_BIND": "close", "OMP_PLACES": "cores"}):
+        p = subprocess.run([sys.executable, "-m", "oracle.baseline_leg", str(tmp_path / "a.npy"), str(tmp_path / "r.npy"), "40000", "2"],
+                           cwd=ROOT, env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-800:]
+        j = json.loads(p.stdout.strip().splitlines()[-1])
+        assert j["kind"] == "port" and j["value"] >= j["value_median"] > 0 and j["cores"] >= 1 and j["sample_rays"] == 20000
+        assert j["build_ms"] <= j["build_ms_serial"] * 1.5 and len(j["host_load_1m"]) == 2 and len(j["sample"]) < 220
+        assert ("pinned" if env_extra else "free") in j["sample"]
+
+
 def test_source_files_keep_their_shape_budget():
     """VERDICT r5 #6: bench.py = argument parsing + the timed step + the compact line; nothing wider than 140 columns in either file"""
     for name, max_lines in (("bench.py", 520), ("bench_sections.py", 800)):
