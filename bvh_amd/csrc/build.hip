@@ -128,6 +128,10 @@ template <typename T> struct BuildArgs {
     ItemStats<T>* stats[2];
     uint32_t* tile_item[2];
     uint32_t* tile_cnt;
+    uint32_t* chunk_cnt[2];  // two-launch schedule, items of more than CHUNK_TILES tiles: bucket counts per CHUNK_TILES-tile block of the level's tile
+                             // ids, [level & 1][(block * 2 + slot) * NUM_BUCKETS + bucket] (slot 1: the item starts inside the block) — see scatter_role
+    uint32_t n_chunks;       // blocks per parity
+    uint32_t tile2;          // positions per tile in the two-launch schedule (level_tile(): TILE, more on scenes of millions of shapes); the fused schedule keeps TILE
     uint32_t* ctr;
     typename Traits<T>::Key* rootkeys;   // [gridDim of k_prep][12]: every workgroup's bounds (joined by k_root / k_level<ROOT>)
     uint32_t prep_wgs;                   // gridDim of k_prep
@@ -166,6 +170,8 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep(BuildArgs<T>
         for (int r = 0; r < STAT_REP; r++) init_stats<T>(&a.lv.stats[0][r], (int)threadIdx.x);
     if (a.xbar && blockIdx.x == 0)
         for (uint32_t i = threadIdx.x; i < (uint32_t)XBAR_WORDS; i += blockDim.x) a.xbar[i] = 0ull;
+    if (a.chunk_cnt[0] && blockIdx.x == 1 % gridDim.x)   // both parities start a build all-zero (k_split keeps the next level's so)
+        for (uint32_t i = threadIdx.x; i < 2u * a.n_chunks * 2u * (uint32_t)NUM_BUCKETS; i += blockDim.x) a.chunk_cnt[0][i] = 0u;
     if (blockIdx.x == 0) {   // the LDS slot tables of the previous tree (filled again by flatten)
         for (uint32_t i = threadIdx.x; i < a.n_slots; i += blockDim.x) a.slot_entry[i] = NONE;
         for (uint32_t i = threadIdx.x; i < WIDE_SLOTS; i += blockDim.x) a.wslot_node[i] = NONE;
@@ -281,7 +287,7 @@ __device__ void push_item(const BuildArgs<T>& a, int next_level, uint32_t ni, ui
     uint32_t slot = 0, tb = 0;
     const bool is_small = count <= (uint32_t)SMALL_MAX;
     const bool is_mid2 = !is_small && count <= a.mid_max;
-    const uint32_t ntile = (count + TILE - 1) / TILE;
+    const uint32_t ntile = (count + a.tile2 - 1) / a.tile2;
     if (lane == 0) {
         if (is_small) slot = atomicAdd(&a.ctr[CTR_SMALL], 1u);
         else if (is_mid2) slot = atomicAdd(&a.ctr[CTR_MID2], 1u);
@@ -315,7 +321,7 @@ __device__ void push_pair(const BuildArgs<T>& a, int next_level, uint32_t parent
     const int npar = next_level & 1;
     const uint32_t mycount = lane == 0 ? lcount : rcount;
     const int mykind = mycount <= (uint32_t)SMALL_MAX ? 0 : (mycount <= a.mid_max ? 1 : 3);   // wave / workgroup / level tier
-    const uint32_t myntile = (mycount + TILE - 1) / TILE;
+    const uint32_t myntile = (mycount + a.tile2 - 1) / a.tile2;
     uint32_t slot = 0, tb = 0;
     if (lane < 2) {
         if (mykind == 0) slot = atomicAdd(&a.ctr[CTR_SMALL], 1u);
@@ -330,7 +336,7 @@ __device__ void push_pair(const BuildArgs<T>& a, int next_level, uint32_t parent
     for (int side = 0; side < 2; side++) {
         const uint32_t cslot = __shfl(slot, side), ctb = __shfl(tb, side);
         const int kind = __shfl(mykind, side);
-        const uint32_t ccount = side ? rcount : lcount, ntile = (ccount + TILE - 1) / TILE;
+        const uint32_t ccount = side ? rcount : lcount, ntile = (ccount + a.tile2 - 1) / a.tile2;
         Item<T>* it = kind == 0 ? &a.small[cslot] : (kind == 1 ? &a.mid2[cslot] : &a.big[npar][cslot]);
         if (lane == 0) {
             it->ni = side ? ri : li; it->parent = parent; it->start = side ? rstart : lstart; it->count = ccount;
@@ -359,6 +365,10 @@ template <typename T> __global__ __launch_bounds__(256) void k_publish_build(Bui
 // ------------------------------------------------------------------------------------------------
 // tier 1 / bin
 // ------------------------------------------------------------------------------------------------
+#ifndef BVH_CHUNK_TILES
+#define BVH_CHUNK_TILES 256
+#endif
+constexpr int CHUNK_TILES = BVH_CHUNK_TILES;   // tile ids per block of BuildArgs::chunk_cnt (items above CHUNK_TILES tiles use the block sums)
 constexpr int BIN_REP = 16;  // LDS replicas of the tile statistics: lanes l and l+16.. share one, so a wave's
                              // same-address atomic conflicts drop from ~64/6 to ~4/6 per instruction
 template <typename T> __global__ __launch_bounds__(256) void k_bin(BuildArgs<T> a, int level) {
@@ -374,8 +384,8 @@ template <typename T> __global__ __launch_bounds__(256) void k_bin(BuildArgs<T> 
         const uint32_t item_id = a.tile_item[par][t];
         const Item<T>* it = &a.big[par][item_id];
         const uint32_t start = it->start, count = it->count;
-        const uint32_t p0 = start + (t - it->tile_base) * TILE;
-        const uint32_t pend = min(start + count, p0 + (uint32_t)TILE);
+        const uint32_t p0 = start + (t - it->tile_base) * a.tile2;
+        const uint32_t pend = min(start + count, p0 + a.tile2);
         T C[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) C[k] = it->C[k];
@@ -421,6 +431,11 @@ template <typename T> __global__ __launch_bounds__(256) void k_bin(BuildArgs<T> 
             sc[0][threadIdx.x] = c;   // only this thread reads/writes column threadIdx.x here
             a.tile_cnt[t * NUM_BUCKETS + threadIdx.x] = c;
             if (c) atomicAdd(&gs->cnt[threadIdx.x], c);
+            if (c && count > (uint32_t)CHUNK_TILES * a.tile2) {   // an item of many tiles: its scatter adds up block sums instead of every earlier tile's counts
+                const uint32_t blk = t / (uint32_t)CHUNK_TILES;
+                const uint32_t slot = it->tile_base > blk * (uint32_t)CHUNK_TILES ? 1u : 0u;
+                atomicAdd(&a.chunk_cnt[par][(size_t)(blk * 2u + slot) * NUM_BUCKETS + threadIdx.x], c);
+            }
         }
         __syncthreads();
         if (threadIdx.x < NUM_BUCKETS * STAT_KEYS) {
@@ -625,23 +640,48 @@ template <typename T> __device__ void scatter_role(const BuildArgs<T>& a, int le
     for (uint32_t t = block; t < ntiles; t += nblocks) {
         const Item<T>* it = &a.big[par][a.tile_item[par][t]];
         const uint32_t start = it->start, count = it->count;
-        const uint32_t p0 = start + (t - it->tile_base) * TILE;
-        const uint32_t pend = min(start + count, p0 + (uint32_t)TILE);
+        const uint32_t p0 = start + (t - it->tile_base) * a.tile2;
+        const uint32_t pend = min(start + count, p0 + a.tile2);
         // exclusive offset of (this tile, bucket b) inside the item's slice = shapes of the item in buckets < b
         // + shapes of bucket b in the item's earlier tiles.  Every workgroup adds those up itself (at most a few
         // hundred tiles per item) — a serial scan per item in the selection was the longest part of that launch.
         {
-            const uint32_t tl = t - it->tile_base, ntl = (count + TILE - 1) / TILE;
+            const uint32_t tl = t - it->tile_base, ntl = (count + a.tile2 - 1) / a.tile2;
             uint32_t before[NUM_BUCKETS], all[NUM_BUCKETS];
 #pragma unroll
             for (int b = 0; b < NUM_BUCKETS; b++) { before[b] = 0; all[b] = 0; }
             const uint32_t* tc = a.tile_cnt + (size_t)it->tile_base * NUM_BUCKETS;
-            for (uint32_t j = threadIdx.x; j < ntl; j += 256) {
+            if (count > (uint32_t)CHUNK_TILES * a.tile2) {
+                // An item of MANY tiles (the root of a 12 M-shape scene has 23 437): every one of its workgroups adding up all of its tiles' counts is
+                // quadratic — 13 GB of (cached) reads for that root alone, k_split 0.72 ms at the top levels against 0.07 ms further down.  k_bin
+                // has left the counts per block of CHUNK_TILES tile ids as well (a block holds tiles of at most two such items: the tail of one —
+                // slot 0 — and the head of the next — slot 1): whole blocks by their sums, the ragged ends tile by tile.
+                const uint32_t T0 = it->tile_base, T1 = T0 + ntl;
+                const uint32_t g0 = T0 / (uint32_t)CHUNK_TILES, g1 = (T1 - 1u) / (uint32_t)CHUNK_TILES, gt = t / (uint32_t)CHUNK_TILES;
+                const uint32_t* cc = a.chunk_cnt[par];
+                for (uint32_t g = g0 + threadIdx.x; g <= g1; g += 256) {
+                    const uint32_t sl = T0 > g * (uint32_t)CHUNK_TILES ? 1u : 0u;
 #pragma unroll
-                for (int b = 0; b < NUM_BUCKETS; b++) {
-                    const uint32_t v = tc[(size_t)j * NUM_BUCKETS + b];
-                    all[b] += v;
-                    before[b] += j < tl ? v : 0u;
+                    for (int b = 0; b < NUM_BUCKETS; b++) {
+                        const uint32_t v = cc[(size_t)(g * 2u + sl) * NUM_BUCKETS + b];
+                        all[b] += v;
+                        before[b] += g < gt ? v : 0u;
+                    }
+                }
+                // the tiles of this tile's own block that come before it
+                const uint32_t j0 = max(gt * (uint32_t)CHUNK_TILES, T0);
+                for (uint32_t j = j0 + threadIdx.x; j < t; j += 256) {
+#pragma unroll
+                    for (int b = 0; b < NUM_BUCKETS; b++) before[b] += a.tile_cnt[(size_t)j * NUM_BUCKETS + b];
+                }
+            } else {
+                for (uint32_t j = threadIdx.x; j < ntl; j += 256) {
+#pragma unroll
+                    for (int b = 0; b < NUM_BUCKETS; b++) {
+                        const uint32_t v = tc[(size_t)j * NUM_BUCKETS + b];
+                        all[b] += v;
+                        before[b] += j < tl ? v : 0u;
+                    }
                 }
             }
             // run[b] = (shapes of the item in buckets < b) + (shapes of bucket b in earlier tiles)
@@ -694,6 +734,10 @@ template <typename T> __device__ void scatter_role(const BuildArgs<T>& a, int le
 // only the per-tile bucket counts — NOT the chosen split) are independent, so the first `sel_blocks` workgroups
 // select while the others scatter.
 template <typename T> __global__ __launch_bounds__(256) void k_split(BuildArgs<T> a, int level, uint32_t sel_blocks) {
+    if (blockIdx.x == 0 && a.chunk_cnt[0]) {   // the block sums the NEXT level's k_bin adds to (this level reads the other parity)
+        uint32_t* nx = a.chunk_cnt[(level + 1) & 1];
+        for (uint32_t i = threadIdx.x; i < a.n_chunks * 2u * (uint32_t)NUM_BUCKETS; i += 256) nx[i] = 0u;
+    }
     if (blockIdx.x < sel_blocks) select_role<T>(a, level, blockIdx.x, sel_blocks);
     else scatter_role<T>(a, level, blockIdx.x - sel_blocks, gridDim.x - sel_blocks);
 }
@@ -2075,6 +2119,22 @@ template <typename T> struct LevelLayout {
     }
 };
 
+template <typename T> static bool level_fused(const bvhgpu_tree* t) {
+    const int v = t->ctx->tune[BVHGPU_TUNE_BUILD_LEVEL_LAUNCHES];
+    return v == 1 || (v != 2 && t->n <= MID_SCENE_SPLIT);
+}
+// Positions per tile of the two-launch schedule.  Every tile is one pass of a workgroup through a chain of dependent fetches (tile -> item -> counts ->
+// offsets) ahead of its shapes, so a level of millions of positions is cheaper in fewer, longer tiles — and a level of 360 k in many short ones
+// (build ms by tile, tools/level_tile_sweep.py, profiles/r6_level_tile_sweep.log: 12 M shapes 6.99 / 6.38 / 6.19 / 6.12 at 512 / 1024 / 2048 /
+// 4096; 3.6 M 2.15 / 1.99 / 1.96 / 2.01; 1.2 M 0.83 / 0.77 / 0.77 / 0.87; 360 k 0.35 / 0.35 / 0.40 / 0.50).  A scheduling unit only: the trees
+// are byte-equal whatever the tile (same sweep).  The fused schedule's kernels are written for TILE.
+template <typename T> static uint32_t level_tile(const bvhgpu_tree* t) {
+    if (level_fused<T>(t)) return (uint32_t)TILE;
+    const int v = t->ctx->tune[BVHGPU_TUNE_BUILD_LEVEL_TILE];
+    if (v > 0) return (uint32_t)std::min(std::max((v + 255) / 256 * 256, (int)TILE), 16384);   // (the buffers are sized for TILE-position tiles: never fewer positions)
+    return t->n >= 6000000 ? 4096u : t->n >= 2000000 ? 2048u : t->n >= 600000 ? 1024u : (uint32_t)TILE;
+}
+
 template <typename T> static BuildArgs<T> make_args(bvhgpu_tree* t, const T* src) {
     using Tr = Traits<T>;
     using Key = typename Tr::Key;
@@ -2097,6 +2157,10 @@ template <typename T> static BuildArgs<T> make_args(bvhgpu_tree* t, const T* src
     a.stats[0] = t->stats[0].as<ItemStats<T>>(); a.stats[1] = t->stats[1].as<ItemStats<T>>();
     a.tile_item[0] = t->tile_item[0].as<uint32_t>(); a.tile_item[1] = t->tile_item[1].as<uint32_t>();
     a.tile_cnt = t->tile_cnt.as<uint32_t>();
+    a.tile2 = level_tile<T>(t);
+    a.n_chunks = (uint32_t)(t->chunk_cnt.cap / (2 * 2 * NUM_BUCKETS * 4));
+    a.chunk_cnt[0] = t->chunk_cnt.as<uint32_t>();
+    a.chunk_cnt[1] = a.chunk_cnt[0] ? a.chunk_cnt[0] + (size_t)a.n_chunks * 2 * NUM_BUCKETS : nullptr;
     a.ctr = t->ctr.as<uint32_t>();
     a.rootkeys = reinterpret_cast<Key*>(reinterpret_cast<char*>(t->ctr.p) + ROOTKEY_OFF);
     a.n = (uint32_t)t->n;
@@ -2126,7 +2190,7 @@ template <typename T> struct BuildGrid {
         max_big = n / (mid_max + 1) + 2;       // simultaneously active nodes with > mid_max shapes
         max_mid2 = n / (SMALL_MAX + 1) + 2;    // workgroup tier: nodes with 65..mid_max shapes
         max_tiles = n / TILE + max_big + 2;
-        tile_grid = (int)std::min<size_t>(max_tiles, 2048);
+        tile_grid = (int)std::min<size_t>(n / level_tile<T>(t) + max_big + 2, 2048);
         sel_grid = (int)std::min<size_t>((max_big + 3) / 4, 1024);
         mid2_grid = (int)std::min<size_t>(max_mid2, (size_t)t->ctx->n_cu * 4);
         small_grid = (int)std::min<size_t>((n + 3) / 4, (size_t)t->ctx->n_cu * 8);
@@ -2141,10 +2205,6 @@ template <typename T> struct BuildGrid {
 // Which schedule: the fused launch shortens the dependent chain (what small scenes are bound by: 0.200 against 0.220 ms at
 // 120 k shapes) and does more work per shape (selection per tile, three rotating accumulator sets, binning inside the rewrite:
 // 0.374 against 0.349 ms at 360 k, 10.5 against 8.4 ms at 12 M) — so it is used up to MID_SCENE_SPLIT shapes.
-template <typename T> static bool level_fused(const bvhgpu_tree* t) {
-    const int v = t->ctx->tune[BVHGPU_TUNE_BUILD_LEVEL_LAUNCHES];
-    return v == 1 || (v != 2 && t->n <= MID_SCENE_SPLIT);
-}
 template <typename T> static void run_level(bvhgpu_tree* t, const BuildArgs<T>& a, const BuildGrid<T>& g, int L) {
     hipStream_t st = t->ctx->stream;
     if (level_fused<T>(t)) {
@@ -2214,6 +2274,7 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     t->mid2.reserve(g.max_mid2 * sizeof(Item<T>));
     t->small.reserve((n + 1) * sizeof(Item<T>));
     t->tile_cnt.reserve(g.max_tiles * NUM_BUCKETS * 4);
+    if (!level_fused<T>(t)) t->chunk_cnt.reserve((g.max_tiles / CHUNK_TILES + 2) * 2 * 2 * NUM_BUCKETS * 4);   // (two parities x two slots per block)
     if (t->ctr.reserve(ROOTKEY_OFF + (size_t)PREP_MAX_WG * STAT_KEYS * sizeof(Key))) t->ctr_ready = false;   // a fresh buffer has not been zeroed by the previous build
     if (!t->pin) BVH_HIP(hipHostMalloc(&t->pin, ROOTKEY_OFF, hipHostMallocDefault));
 

@@ -74,7 +74,7 @@ void free_tree_buffers(bvhgpu_tree* t) {
     t->idx[0].release(); t->idx[1].release(); t->bk.release(); t->lvbuf.release();
     t->big[0].release(); t->big[1].release(); t->mid2.release(); t->small.release();
     t->stats[0].release(); t->stats[1].release();
-    t->tile_item[0].release(); t->tile_item[1].release(); t->tile_cnt.release(); t->ctr.release(); t->refit_seg.release();
+    t->tile_item[0].release(); t->tile_item[1].release(); t->tile_cnt.release(); t->chunk_cnt.release(); t->ctr.release(); t->refit_seg.release();
     t->wide.release(); t->wslot_node.release(); t->wide_guide.release(); t->guide_info.release();
     t->bstat.release();
     if (t->ev_flat0) { (void)hipEventDestroy(t->ev_flat0); t->ev_flat0 = nullptr; }

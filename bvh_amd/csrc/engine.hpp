@@ -74,7 +74,7 @@ struct bvhgpu_ctx {
     bool own_stream = false;
     std::string err;
     int n_cu = 256;
-    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0, 0, -1, 1, 1, 1, 0, 0, 256, 2};  // bvhgpu_set_tuning defaults
+    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0, 0, -1, 1, 1, 1, 0, 0, 256, 2, 0};  // bvhgpu_set_tuning defaults
     // timing
     bool timing = false;
     hipEvent_t ev[8] = {};
@@ -164,6 +164,7 @@ struct bvhgpu_tree {
     bvhgpu::DevBuf stats[2];    // per big item: 6 x (12 keys) + 6 counts
     bvhgpu::DevBuf tile_item[2];
     bvhgpu::DevBuf tile_cnt;    // per tile 6 x u32 (counts, then exclusive offsets)
+    bvhgpu::DevBuf chunk_cnt;   // two-launch level schedule: the same counts per block of 256 tile ids (build.hip BuildArgs::chunk_cnt)
     bvhgpu::DevBuf ctr;         // counters
     bvhgpu::DevBuf refit_seg;   // refit: complete binary tree of joins over the sorted positions (2 * n_pad boxes)
 };

@@ -443,7 +443,9 @@ typedef enum {
                                               bytes at link speed (56 GB/s) but the build running beside it slows down four-fold while a kernel streams host memory
                                               (k_level 12 -> 50 µs: profiles/r6_host_zero_copy.log), so the copy engines keep the upload.  0 = copy engines both
                                               ways.  Pageable buffers always go through the copy engines */
-    BVHGPU_TUNE_COUNT = 20
+    BVHGPU_TUNE_BUILD_LEVEL_TILE = 20,     /* builder, level tier, two launches per level (scenes above 250 K shapes): positions per workgroup tile, a multiple of 256
+                                              (0, default: 512, from 600 K shapes 1024, from 2 M 2048, from 6 M 4096).  A scheduling unit only: the tree is the same whatever the tile */
+    BVHGPU_TUNE_COUNT = 21
 } bvhgpu_tune;
 int bvhgpu_set_tuning(bvhgpu_ctx *ctx, int knob, int value);
 int bvhgpu_get_tuning(const bvhgpu_ctx *ctx, int knob, int *value);

@@ -185,14 +185,17 @@ def test_parity_unbalanced_deep_tree(eng, orc):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("launches", [1, 2])
+@pytest.mark.parametrize("launches", [1, 2, (2, 1024), (2, 4096)])
 def test_level_tier_schedules_same_tree(eng, orc, launches, dtype):
     """The level tier as one launch per level (k_level: split of level L-1 and binning of level L fused, default) and as two
     (k_bin, k_split) must both reproduce the oracle's node array: balanced scene, the unbalanced deep tree (host-continued
     level loop), sizes around the tier's hand-over, a scene with colliding centroids (degenerate halving in the level tier)."""
     from bvh_amd import Bvh, Context, testbase as tb
-    from bvh_amd._lib import TUNE_BUILD_LEVEL_LAUNCHES
+    from bvh_amd._lib import TUNE_BUILD_LEVEL_LAUNCHES, TUNE_BUILD_LEVEL_TILE
     ctx = Context(0)
+    if isinstance(launches, tuple):   # the two-launch schedule with the tile size it takes on scenes of millions of shapes (a scheduling unit: same tree)
+        launches, tile = launches
+        ctx.set_tuning(TUNE_BUILD_LEVEL_TILE, tile)
     ctx.set_tuning(TUNE_BUILD_LEVEL_LAUNCHES, launches)
     rng = np.random.default_rng(5)
     scenes = []
@@ -1237,8 +1240,9 @@ def test_fuzz_all_queries(eng, orc, seed):
     # the large-batch walk (four grandchildren per step, rays cut into items) on the same small batch, and the two level-tier
     # schedules of the builder alternating with the seed
     from bvh_amd import Context
-    from bvh_amd._lib import TUNE_BUILD_LEVEL_LAUNCHES, TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_WIDE_ITEMS_LOG4
+    from bvh_amd._lib import TUNE_BUILD_LEVEL_LAUNCHES, TUNE_BUILD_LEVEL_TILE, TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_WIDE_ITEMS_LOG4
     wctx = Context(0)
+    wctx.set_tuning(TUNE_BUILD_LEVEL_TILE, (0, 1024, 2048)[seed % 3])
     wctx.set_tuning(TUNE_TRAVERSE_LDS_MIN_RAYS, 0)
     wctx.set_tuning(TUNE_WIDE_ITEMS_LOG4, (seed // 2) % 3)
     wctx.set_tuning(TUNE_BUILD_LEVEL_LAUNCHES, 1 + seed % 2)
