@@ -63,9 +63,15 @@ template <typename T> struct MidSmallScene {   // up to MID_SCENE_SPLIT shapes
     static constexpr int THREADS = BVH_MID_SMALL_THREADS;
     static constexpr int HANDOFF = SMALL_MAX;
 };
+#ifndef BVH_MID_LARGE_MAXN
+#define BVH_MID_LARGE_MAXN 1536
+#endif
+#ifndef BVH_MID_LARGE_THREADS
+#define BVH_MID_LARGE_THREADS 256
+#endif
 template <typename T> struct MidLargeScene {
-    static constexpr int MAXN = sizeof(T) == 4 ? 1536 : 1024;   // f64: 6 x 8 B per shape in LDS
-    static constexpr int THREADS = 256;
+    static constexpr int MAXN = sizeof(T) == 4 ? BVH_MID_LARGE_MAXN : BVH_MID_LARGE_MAXN * 2 / 3;   // f64: 6 x 8 B per shape in LDS
+    static constexpr int THREADS = BVH_MID_LARGE_THREADS;
     static constexpr int HANDOFF = SMALL_MAX;
 };
 constexpr size_t MID_SCENE_SPLIT = 250000;
