@@ -1602,16 +1602,28 @@ __global__ __launch_bounds__(Cfg::THREADS) void k_mid(BuildArgs<T> a, uint32_t f
         uint32_t* gdst = a.idx[it->parity ^ 1];   // where the <= 64-shape children's slices are left
         const uint32_t out_parity = it->parity ^ 1;
         lds_barrier();  // previous item fully done with LDS
-        for (uint32_t p = tid; p < (uint32_t)MAXN; p += MID_THREADS) {
-            if (p < count) {
-                const uint32_t shp = gsrc[istart + p];
-                const T* b = a.aabbs + 6 * (size_t)shp;
-                s_idx[p] = shp;
-                s_seg[p] = 0;
+        {   // all index loads of the thread, then all its gathers, then the LDS stores (one dependent pair at a time: 12 M shapes 5.90 -> 5.85 ms, 120 k 0.197 -> 0.195)
+            uint32_t shq[PPT];
+            T bq[PPT][6];
 #pragma unroll
-                for (int k = 0; k < 6; k++) s_box[6 * p + k] = b[k];
-            } else {
-                s_seg[p] = SEG_NONE;
+            for (int j = 0; j < PPT; j++) { const uint32_t p = tid + (uint32_t)j * MID_THREADS; shq[j] = p < count ? gsrc[istart + p] : 0u; }
+#pragma unroll
+            for (int j = 0; j < PPT; j++) {
+                const T* b = a.aabbs + 6 * (size_t)shq[j];
+#pragma unroll
+                for (int k = 0; k < 6; k++) bq[j][k] = b[k];
+            }
+#pragma unroll
+            for (int j = 0; j < PPT; j++) {
+                const uint32_t p = tid + (uint32_t)j * MID_THREADS;
+                if (p < count) {
+                    s_idx[p] = shq[j];
+                    s_seg[p] = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) s_box[6 * p + k] = bq[j][k];
+                } else {
+                    s_seg[p] = SEG_NONE;
+                }
             }
         }
         if (tid == 0) {
