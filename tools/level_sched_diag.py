@@ -7,7 +7,7 @@ from bvh_amd import Bvh, Context, testbase as tb
 from bvh_amd._lib import TUNE_BUILD_LEVEL_LAUNCHES
 
 dev = torch.device("cuda", 0)
-for cubes in (10_000, 30_000, 100_000, 300_000, 1_000_000):
+for cubes in [int(x) for x in sys.argv[1:]] or (10_000, 30_000, 100_000, 300_000, 1_000_000):
     _, a = tb.create_n_cubes(cubes, tb.default_bounds())
     aabbs = torch.from_numpy(a).to(dev)
     row = []
