@@ -24,7 +24,7 @@
 //                   levels of the subtree at once: segmented ballot ranks for the stable sort, ds_permute to move
 //                   shapes, segmented min/max prefix+suffix scans for the L/R bounds of the 5 candidate splits
 //                   (plays the role of rayon_executor's sequential cut-off, bvh_impl.rs:534).
-#include "engine.hpp"
+#include "flatten_node.hpp"
 
 namespace bvhgpu {
 
@@ -137,6 +137,8 @@ template <typename T> struct BuildArgs {
     uint32_t* chunk_cnt[2];  // two-launch schedule, items of more than CHUNK_TILES tiles: bucket counts per CHUNK_TILES-tile block of the level's tile
                              // ids, [level & 1][(block * 2 + slot) * NUM_BUCKETS + bucket] (slot 1: the item starts inside the block) — see scatter_role
     uint32_t n_chunks;       // blocks per parity
+    FlattenArgs<T> fl;       // k_small, fl_parts != 0: the wave that has built a subtree also writes these parts of the flatten for its nodes (flatten_node.hpp)
+    uint32_t fl_parts;
     uint32_t tile2;          // positions per tile in the two-launch schedule (level_tile(): TILE, more on scenes of millions of shapes); the fused schedule keeps TILE
     uint32_t* ctr;
     typename Traits<T>::Key* rootkeys;   // [gridDim of k_prep][12]: every workgroup's bounds (joined by k_root / k_level<ROOT>)
@@ -374,6 +376,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_publish_build(Bui
 #ifndef BVH_CHUNK_TILES
 #define BVH_CHUNK_TILES 256
 #endif
+constexpr size_t FLATTEN_INLINE_MIN_SHAPES = 1000000;   // BVHGPU_TUNE_FLATTEN_INLINE = 1: scenes from which the wave tier flattens its own subtrees
 constexpr int SCATTER_AHEAD = 4;   // rounds of 256 positions whose loads the stable scatter issues together
 constexpr int CHUNK_TILES = BVH_CHUNK_TILES;   // tile ids per block of BuildArgs::chunk_cnt (items above CHUNK_TILES tiles use the block sums)
 constexpr int BIN_REP = 16;  // LDS replicas of the tile statistics: lanes l and l+16.. share one, so a wave's
@@ -1967,6 +1970,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
     const Item<T>* it = &a.small[wave];
     const uint32_t istart = it->start;
     const int n = (int)it->count;
+    const uint32_t ni0 = it->ni;   // the subtree's nodes: [ni0, ni0 + 2 n - 1), pre-order
     const uint32_t* idx = a.idx[it->parity];
 
     bool done = lane >= n;
@@ -2131,6 +2135,21 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
             for (int k = 0; k < 6; k++) Cb[k] = Cn[k];
         }
     }
+    // ---- the subtree is complete: its part of the flatten, by the wave that still has it in its caches (BVHGPU_TUNE_FLATTEN_INLINE).  FLAT
+    //      and WIDE only read records of the subtree itself and of the item's parent (written by the launch that queued the item); TRAV
+    //      reads a node BEHIND the subtree and stays with k_flatten.
+    if constexpr (sizeof(T) == 4) if (a.fl_parts != 0u) {   // (uniform; f32 only: an f64 wide node is 64 registers)
+        // this wave's own stores (node records, start / count / slot) are read back below: workgroup scope is enough (one CU, one L1) — a device-scope
+        // fence writes the XCD's L2 back (0.1 ms per item on this chip)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const uint32_t nn_item = 2u * (uint32_t)n - 1u;
+        for (uint32_t j = (uint32_t)lane; j < nn_item; j += WAVE) {
+            const uint32_t i = ni0 + j;
+            const typename Tr::Node ndf = a.fl.nodes[i];
+            if (a.fl_parts == (uint32_t)(FLATTEN_FLAT | FLATTEN_WIDE)) flatten_node<T, FLATTEN_FLAT | FLATTEN_WIDE>(a.fl, i, ndf);
+            else flatten_node<T, FLATTEN_WIDE>(a.fl, i, ndf);
+        }
+    }
 #ifdef BVH_SMALL_PROFILE
     if (sp_on) g_small_prof[20 * wave + 18] = wall_clock64();
 #endif
@@ -2199,6 +2218,7 @@ template <typename T> static BuildArgs<T> make_args(bvhgpu_tree* t, const T* src
     a.tile_item[0] = t->tile_item[0].as<uint32_t>(); a.tile_item[1] = t->tile_item[1].as<uint32_t>();
     a.tile_cnt = t->tile_cnt.as<uint32_t>();
     a.tile2 = level_tile<T>(t);
+    a.fl = FlattenArgs<T>{}; a.fl_parts = 0;   // (build_enqueue sets them when the flatten behind the build is known)
     a.n_chunks = (uint32_t)(t->chunk_cnt.cap / (2 * 2 * NUM_BUCKETS * 4));
     a.chunk_cnt[0] = t->chunk_cnt.as<uint32_t>();
     a.chunk_cnt[1] = a.chunk_cnt[0] ? a.chunk_cnt[0] + (size_t)a.n_chunks * 2 * NUM_BUCKETS : nullptr;
@@ -2365,6 +2385,18 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
             }
         }
     }
+    // the flatten behind this build: its FLAT / WIDE parts for every node of at most SMALL_MAX shapes by the wave tier itself
+    uint32_t inline_parts = 0;
+    // (measured, tools/gpu_flatten_inline.sh: 12 M shapes 16.15 -> 15.31 ms per step, 120 k shapes 0.3351 -> 0.3331 — the wave tier pays back most of what
+    //  the flatten kernel saves where the step is a latency chain; by default only where it is a throughput matter)
+    const int inl = ctx->tune[BVHGPU_TUNE_FLATTEN_INLINE];
+    if (flatten_after && n >= 2 && sizeof(T) == 4 && (inl == 2 || (inl == 1 && n >= FLATTEN_INLINE_MIN_SHAPES))) {   // (f64: a wide node is 64 registers — k_flatten keeps it)
+        const FlattenPlan p = flatten_plan<T>(t, ctx->tune[BVHGPU_TUNE_FLATTEN_LAZY] != 0);
+        if (p.with_wide) {
+            inline_parts = (uint32_t)(p.parts & (FLATTEN_FLAT | FLATTEN_WIDE));
+            a.fl = flatten_args<T>(t, p.with_wide, p.with_guide); a.fl_parts = inline_parts;
+        }
+    }
     run_lower_tiers<T>(t, a, g, 0u, 0u);
     // counters: readback through the pinned page + reset for the next build, by the flatten kernel when there is one
     // (optimistic too: redone if the build turns out to be unfinished) and by a launch of their own otherwise
@@ -2374,7 +2406,7 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     if (flatten_after && n >= 1)
         flatten_tree<T>(t, a.ctr, reinterpret_cast<uint32_t*>(t->pin), (uint32_t)(ROOTKEY_OFF / 4), t->bstat.as<uint32_t>(), (uint32_t)CTR_FLAGS,
                         (n > (size_t)MID_MAX && !t->pend_persist) ? (uint32_t)(CTR_LEVEL0 + 2 * lvl_slot(level)) : (uint32_t)CTR_FLAGS,   // (persistent tier: its give-up flag IS the unfinished bit)
-                        ctx->tune[BVHGPU_TUNE_FLATTEN_LAZY] != 0);
+                        ctx->tune[BVHGPU_TUNE_FLATTEN_LAZY] != 0, inline_parts);
     else hipLaunchKernelGGL(k_publish_build<T>, dim3(1), dim3(256), 0, st, a, reinterpret_cast<uint32_t*>(t->pin));
     t->ctr_ready = true;
     t->pending_build = true; t->pend_level = level; t->pend_flatten = flatten_after;

@@ -68,13 +68,16 @@ struct HostBatch {
 };
 }
 
+#ifndef BVH_FLATTEN_INLINE_DEFAULT
+#define BVH_FLATTEN_INLINE_DEFAULT 1
+#endif
 struct bvhgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
     int n_cu = 256;
-    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0, 0, -1, 1, 1, 1, 0, 0, 256, 2, 0};  // bvhgpu_set_tuning defaults
+    int tune[BVHGPU_TUNE_COUNT] = {3, -1, -1, 16384, 0, 0, 1, 0, 0, 0, 0, 0, -1, 1, 1, 1, 0, 0, 256, 2, 0, BVH_FLATTEN_INLINE_DEFAULT};  // bvhgpu_set_tuning defaults
     // timing
     bool timing = false;
     hipEvent_t ev[8] = {};
@@ -241,8 +244,12 @@ template <typename T> void build_finalize(bvhgpu_tree* t);
 // pub_*: also publish + reset the builder's counters (build_enqueue's last launch); see k_flatten
 // bstat (with pub_*): device-side status word = pub_ctr[flags_idx] | (pub_ctr[level_idx] != 0 ? BSTAT_UNFINISHED : 0), level_idx == flags_idx: no level tier
 // wide_only: write the wide walk's arrays only and leave flat / trav / slot_entry to ensure_flat_arrays (ignored where the tree has no wide nodes)
+// inline_parts: the parts the builder's wave tier has already written for every node of at most SMALL_MAX shapes (build.hip k_small, flatten_node.hpp)
 template <typename T> void flatten_tree(bvhgpu_tree* t, uint32_t* pub_ctr = nullptr, uint32_t* pub_host = nullptr, uint32_t pub_words = 0,
-                                        uint32_t* bstat = nullptr, uint32_t flags_idx = 0, uint32_t level_idx = 0, bool wide_only = false);
+                                        uint32_t* bstat = nullptr, uint32_t flags_idx = 0, uint32_t level_idx = 0, bool wide_only = false,
+                                        uint32_t inline_parts = 0);
+struct FlattenPlan { int parts = 0; bool with_wide = false, with_guide = false; };
+template <typename T> FlattenPlan flatten_plan(bvhgpu_tree* t, bool wide_only);
 // the FlatNode array, the folded binary array and the binary walk's LDS slot table of a tree whose flatten was lazy: enqueued on the
 // tree's stream now (a no-op for every other tree).  Everything that reads t->flat / t->trav / t->slot_entry calls this first.
 void ensure_flat_arrays(bvhgpu_tree* t);

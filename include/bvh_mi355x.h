@@ -445,7 +445,10 @@ typedef enum {
                                               ways.  Pageable buffers always go through the copy engines */
     BVHGPU_TUNE_BUILD_LEVEL_TILE = 20,     /* builder, level tier, two launches per level (scenes above 250 K shapes): positions per workgroup tile, a multiple of 256
                                               (0, default: 512, from 600 K shapes 1024, from 2 M 2048, from 6 M 4096).  A scheduling unit only: the tree is the same whatever the tile */
-    BVHGPU_TUNE_COUNT = 21
+    BVHGPU_TUNE_FLATTEN_INLINE = 21,       /* f32 trees, the flatten enqueued with a build: the builder's wave tier writes the FlatNode / wide-node entries of the
+                                              subtrees it builds (<= 64 shapes: 97 % of the nodes) itself and the flatten kernel behind it only the nodes above:
+                                              1 (default) from 1 M shapes, 2 always, 0 never (the flatten kernel writes everything).  Same arrays either way */
+    BVHGPU_TUNE_COUNT = 22
 } bvhgpu_tune;
 int bvhgpu_set_tuning(bvhgpu_ctx *ctx, int knob, int value);
 int bvhgpu_get_tuning(const bvhgpu_ctx *ctx, int knob, int *value);

@@ -173,7 +173,9 @@ def test_host_batch_on_a_tree_that_is_still_building(eng, orc):
     """rebuild_async from pinned AABBs, the batch enqueued at once: the ray upload runs beside the build; a build that fails (NaN input)
     is reported by the batch's call and leaves the ctx usable"""
     from bvh_amd import Bvh, Context, HostStep, testbase as tb
+    from bvh_amd._lib import TUNE_FLATTEN_INLINE
     ctx = Context(0)
+    ctx.set_tuning(TUNE_FLATTEN_INLINE, 2)   # (the wave tier flattens its own subtrees: a failed build runs none, the walk behind it must still find a consistent tree)
     _, a1 = tb.create_n_cubes(2000)
     _, a2 = tb.create_n_cubes(2500)
     a2 = a2[:len(a1)] * np.float32(0.5)
