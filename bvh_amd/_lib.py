@@ -163,7 +163,7 @@ TUNE_FLATTEN_LAZY = 15           # the flatten behind a build writes the wide wa
 TUNE_WIDE_MIN_RAYS_PER_WG = 18   # wide walk over items, batches below 512 K rays: spread over all workgroup slots down to this many rays each (256 default, 0 off)
 TUNE_HOST_ZERO_COPY = 19         # host batches on pinned buffers: bit 0 the device reads the ray arrays itself, bit 1 it writes offsets / indices itself (2 default)
 TUNE_BUILD_LEVEL_TILE = 20      # builder, two launches per level: positions per tile (0 default = by scene size, 512 .. 4096)
-TUNE_FLATTEN_INLINE = 21        # f32: the builder's wave tier writes the flatten's FLAT / WIDE parts for its subtrees itself (1 default = from 1 M shapes, 2 always, 0 = the flatten kernel writes everything)
+TUNE_FLATTEN_INLINE = 21        # f32: the builder's wave tier writes the flatten's FLAT / WIDE parts for its subtrees itself (1 default, 0 = the flatten kernel writes everything)
 TUNE_HOST_CHUNKS = 17            # bvhgpu_traverse_host_*: chunks the batch is walked in (0, default = by batch size)
 TUNE_BUILD_LEVEL_PERSIST = 16    # builder, level tier: tree levels 3.. of the tier as ONE persistent launch, one level-3 subtree per XCD (1) or a launch per level (0)
 TRAVERSE_RAYS_OD6 = 512

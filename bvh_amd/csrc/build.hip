@@ -376,7 +376,6 @@ template <typename T> __global__ __launch_bounds__(256) void k_publish_build(Bui
 #ifndef BVH_CHUNK_TILES
 #define BVH_CHUNK_TILES 256
 #endif
-constexpr size_t FLATTEN_INLINE_MIN_SHAPES = 1000000;   // BVHGPU_TUNE_FLATTEN_INLINE = 1: scenes from which the wave tier flattens its own subtrees
 constexpr int SCATTER_AHEAD = 4;   // rounds of 256 positions whose loads the stable scatter issues together
 constexpr int CHUNK_TILES = BVH_CHUNK_TILES;   // tile ids per block of BuildArgs::chunk_cnt (items above CHUNK_TILES tiles use the block sums)
 constexpr int BIN_REP = 16;  // LDS replicas of the tile statistics: lanes l and l+16.. share one, so a wave's
@@ -2387,10 +2386,9 @@ template <typename T> void build_enqueue(bvhgpu_tree* t, const T* aabbs_dev, siz
     }
     // the flatten behind this build: its FLAT / WIDE parts for every node of at most SMALL_MAX shapes by the wave tier itself
     uint32_t inline_parts = 0;
-    // (measured, tools/gpu_flatten_inline.sh: 12 M shapes 16.15 -> 15.31 ms per step, 120 k shapes 0.3351 -> 0.3331 — the wave tier pays back most of what
-    //  the flatten kernel saves where the step is a latency chain; by default only where it is a throughput matter)
-    const int inl = ctx->tune[BVHGPU_TUNE_FLATTEN_INLINE];
-    if (flatten_after && n >= 2 && sizeof(T) == 4 && (inl == 2 || (inl == 1 && n >= FLATTEN_INLINE_MIN_SHAPES))) {   // (f64: a wide node is 64 registers — k_flatten keeps it)
+    // (measured, tools/gpu_flatten_inline.sh: 12 M shapes 16.15 -> 15.31 ms per step; 120 k shapes, 6 + 3 alternating pairs of processes: 2 973 -> 3 006
+    //  Mrays/s on average — the flatten kernel is the step's HBM-bound launch, inside the wave tier's dependent chain its stores cost next to nothing)
+    if (flatten_after && n >= 2 && sizeof(T) == 4 && ctx->tune[BVHGPU_TUNE_FLATTEN_INLINE] != 0) {   // (f64: a wide node is 64 registers — k_flatten keeps it)
         const FlattenPlan p = flatten_plan<T>(t, ctx->tune[BVHGPU_TUNE_FLATTEN_LAZY] != 0);
         if (p.with_wide) {
             inline_parts = (uint32_t)(p.parts & (FLATTEN_FLAT | FLATTEN_WIDE));

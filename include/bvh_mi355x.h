@@ -447,7 +447,7 @@ typedef enum {
                                               (0, default: 512, from 600 K shapes 1024, from 2 M 2048, from 6 M 4096).  A scheduling unit only: the tree is the same whatever the tile */
     BVHGPU_TUNE_FLATTEN_INLINE = 21,       /* f32 trees, the flatten enqueued with a build: the builder's wave tier writes the FlatNode / wide-node entries of the
                                               subtrees it builds (<= 64 shapes: 97 % of the nodes) itself and the flatten kernel behind it only the nodes above:
-                                              1 (default) from 1 M shapes, 2 always, 0 never (the flatten kernel writes everything).  Same arrays either way */
+                                              1 (default), or 0: the flatten kernel writes everything.  Same arrays either way */
     BVHGPU_TUNE_COUNT = 22
 } bvhgpu_tune;
 int bvhgpu_set_tuning(bvhgpu_ctx *ctx, int knob, int value);

@@ -175,7 +175,7 @@ def test_host_batch_on_a_tree_that_is_still_building(eng, orc):
     from bvh_amd import Bvh, Context, HostStep, testbase as tb
     from bvh_amd._lib import TUNE_FLATTEN_INLINE
     ctx = Context(0)
-    ctx.set_tuning(TUNE_FLATTEN_INLINE, 2)   # (the wave tier flattens its own subtrees: a failed build runs none, the walk behind it must still find a consistent tree)
+    ctx.set_tuning(TUNE_FLATTEN_INLINE, 1)   # (the wave tier flattens its own subtrees: a failed build runs none, the walk behind it must still find a consistent tree)
     _, a1 = tb.create_n_cubes(2000)
     _, a2 = tb.create_n_cubes(2500)
     a2 = a2[:len(a1)] * np.float32(0.5)

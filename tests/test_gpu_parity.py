@@ -339,8 +339,8 @@ def test_lazy_flatten_same_arrays_whoever_asks_first(eng, orc, dtype):
     pts = np.random.default_rng(3).uniform(-900, 900, size=(500, 3)).astype(dtype)
     firsts = ["flat_nodes", "stats_walk", "wide_walk_then_flat", "scene_blob", "nearest", "async_step"]
     # lazy 2: the second pass at once, on the side stream beside the walk; 3: the FlatNode array at once, the binary array on first use (bench.py's step);
-    # inline 2: the builder's wave tier writes the FLAT / WIDE parts of its own subtrees (BVHGPU_TUNE_FLATTEN_INLINE; by default only from 1 M shapes)
-    for lazy, inline in ((1, 1), (0, 1), (2, 1), (3, 1), (1, 2), (0, 2), (3, 2)):
+    # inline 1 (default): the builder's wave tier writes the FLAT / WIDE parts of its own subtrees (BVHGPU_TUNE_FLATTEN_INLINE), 0: the flatten kernel everything
+    for lazy, inline in ((1, 1), (0, 1), (2, 1), (3, 1), (1, 0), (0, 0), (3, 0)):
         for first in firsts:
             ctx = Context(0)
             ctx.set_tuning(TUNE_FLATTEN_LAZY, lazy)
@@ -1245,7 +1245,7 @@ def test_fuzz_all_queries(eng, orc, seed):
     from bvh_amd import Context
     from bvh_amd._lib import TUNE_BUILD_LEVEL_LAUNCHES, TUNE_BUILD_LEVEL_TILE, TUNE_FLATTEN_INLINE, TUNE_TRAVERSE_LDS_MIN_RAYS, TUNE_WIDE_ITEMS_LOG4
     wctx = Context(0)
-    wctx.set_tuning(TUNE_FLATTEN_INLINE, 2 * (seed % 2))   # the wave tier flattens its own subtrees / the flatten kernel writes everything
+    wctx.set_tuning(TUNE_FLATTEN_INLINE, seed % 2)   # the wave tier flattens its own subtrees / the flatten kernel writes everything
     wctx.set_tuning(TUNE_BUILD_LEVEL_TILE, (0, 1024, 2048)[seed % 3])
     wctx.set_tuning(TUNE_TRAVERSE_LDS_MIN_RAYS, 0)
     wctx.set_tuning(TUNE_WIDE_ITEMS_LOG4, (seed // 2) % 3)
