@@ -1965,7 +1965,11 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const int lane = lane_id();
     const unsigned long long lt = lanemask_lt();
+    __shared__ uint32_t s_inner[256 / WAVE][WAVE];   // per wave: the inner nodes of the subtree it is building, in the order it creates them (the wave's flatten below)
+    uint32_t* my_inner = s_inner[threadIdx.x >> 6];
     for (uint32_t wave = first + wave0; wave < n_small; wave += nwaves) {
+    uint32_t ninner = 0;       // (wave-uniform)
+    bool wave_empty = false;   // (wave-uniform) a split without a SAH winner: the children's stored boxes are EMPTY, not their shapes' (bvh_node.rs:225-230)
     const Item<T>* it = &a.small[wave];
     const uint32_t istart = it->start;
     const int n = (int)it->count;
@@ -2112,6 +2116,12 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
         }
         if (!taken) { box_empty(AL); box_empty(AR); box_empty(Cn); }
         if (!done && !taken && lane == lo) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_EMPTY_SPLIT);
+        wave_empty = wave_empty || __any(!done && !taken);
+        {   // the nodes this level creates (one per segment, by its first lane), filed for the wave's flatten
+            const unsigned long long cm = __ballot(!done && lane == lo);
+            if (!done && lane == lo) my_inner[ninner + (uint32_t)__popcll(cm & lt)] = ni;
+            ninner += (uint32_t)__popcll(cm);
+        }
         if (!done) {
             const uint32_t li = ni + 1;
             const uint32_t ri = li + (uint32_t)(2 * nl - 1);
@@ -2141,11 +2151,32 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
         // this wave's own stores (node records, start / count / slot) are read back below: workgroup scope is enough (one CU, one L1) — a device-scope
         // fence writes the XCD's L2 back (0.1 ms per item on this chip)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const bool with_flat = (a.fl_parts & (uint32_t)FLATTEN_FLAT) != 0u;
+        const bool fast = n >= 2 && !(with_flat && wave_empty);   // (wave-uniform)
+        if (fast) {
+            // ONE round: lane j takes the j-th inner node the wave created (at most 63) through the shared body; a leaf has no wide node, and its two
+            // FlatNode entries need no load at all — the lane still holds its shape, its node index and its box, and the box its parent stored for it is
+            // that box bit for bit (the prefix / suffix join over a segment of one lane is the lane's own box; a split without a winner stores EMPTY boxes
+            // instead: such a subtree takes the general loop below).  Leaves first: what the loop kept per lane dies before the inner nodes' registers are needed
+            if (with_flat && lane < n) {
+                const uint32_t nav = ni - 1u + (istart + (uint32_t)lane);   // flatten_node.hpp: nav(i) = i - 1 + L_i
+                typename Tr::Flat fe = {}, lf = {};
+#pragma unroll
+                for (int k = 0; k < 3; k++) { fe.min[k] = box[k]; fe.max[k] = box[3 + k]; lf.min[k] = Tr::inf(); lf.max[k] = -Tr::inf(); }
+                fe.entry = nav + 1u; fe.exit = nav + 2u; fe.shape = NONE;    // exit = nav + 3 k - 1, k = 1
+                lf.entry = NONE; lf.exit = nav + 2u; lf.shape = shape;       // flat_bvh.rs:129-141
+                a.fl.flat[nav] = fe;
+                a.fl.flat[nav + 1u] = lf;
+            }
+        }
+        // the nodes that go through the shared body: the inner nodes from the wave's list (one round), or — the general case — every node of the subtree
         const uint32_t nn_item = 2u * (uint32_t)n - 1u;
-        for (uint32_t j = (uint32_t)lane; j < nn_item; j += WAVE) {
-            const uint32_t i = ni0 + j;
+        const uint32_t todo = fast ? ninner : nn_item;
+#pragma unroll 1
+        for (uint32_t j = (uint32_t)lane; j < todo; j += WAVE) {
+            const uint32_t i = fast ? my_inner[j] : ni0 + j;
             const typename Tr::Node ndf = a.fl.nodes[i];
-            if (a.fl_parts == (uint32_t)(FLATTEN_FLAT | FLATTEN_WIDE)) flatten_node<T, FLATTEN_FLAT | FLATTEN_WIDE>(a.fl, i, ndf);
+            if (with_flat) flatten_node<T, FLATTEN_FLAT | FLATTEN_WIDE>(a.fl, i, ndf);
             else flatten_node<T, FLATTEN_WIDE>(a.fl, i, ndf);
         }
     }
