@@ -1955,7 +1955,9 @@ void debug_small_prof(unsigned long long* out, size_t n) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_prof), sizeof(unsigned long long) * n);
 }
 #endif
-template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T> a, uint32_t first) {
+// FLAT_INLINE: the wave also writes its subtree's part of the flatten (a.fl_parts; f32).  A kernel of its own because that part needs 119 registers (4 waves per
+// SIMD) where the build alone needs 40: a build that is not followed by its flatten keeps 8 (600 k shapes: 0.414 against 0.429 ms)
+template <typename T, bool FLAT_INLINE> __global__ __launch_bounds__(256) void k_small(BuildArgs<T> a, uint32_t first) {
     using Tr = Traits<T>;
 #ifdef BVH_SMALL_PROFILE
     const unsigned long long sp_t0 = wall_clock64();
@@ -1965,8 +1967,8 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const int lane = lane_id();
     const unsigned long long lt = lanemask_lt();
-    __shared__ uint32_t s_inner[256 / WAVE][WAVE];   // per wave: the inner nodes of the subtree it is building, in the order it creates them (the wave's flatten below)
-    uint32_t* my_inner = s_inner[threadIdx.x >> 6];
+    __shared__ uint32_t s_inner[FLAT_INLINE ? 256 / WAVE : 1][WAVE];   // per wave: the inner nodes of the subtree it is building, in the order it creates them (the wave's flatten below)
+    uint32_t* my_inner = s_inner[FLAT_INLINE ? (threadIdx.x >> 6) : 0];
     for (uint32_t wave = first + wave0; wave < n_small; wave += nwaves) {
     uint32_t ninner = 0;       // (wave-uniform)
     bool wave_empty = false;   // (wave-uniform) a split without a SAH winner: the children's stored boxes are EMPTY, not their shapes' (bvh_node.rs:225-230)
@@ -2116,8 +2118,8 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
         }
         if (!taken) { box_empty(AL); box_empty(AR); box_empty(Cn); }
         if (!done && !taken && lane == lo) atomicOr(&a.ctr[CTR_FLAGS], BUILD_FLAG_EMPTY_SPLIT);
-        wave_empty = wave_empty || __any(!done && !taken);
-        {   // the nodes this level creates (one per segment, by its first lane), filed for the wave's flatten
+        if constexpr (FLAT_INLINE) {   // the nodes this level creates (one per segment, by its first lane), filed for the wave's flatten
+            wave_empty = wave_empty || __any(!done && !taken);
             const unsigned long long cm = __ballot(!done && lane == lo);
             if (!done && lane == lo) my_inner[ninner + (uint32_t)__popcll(cm & lt)] = ni;
             ninner += (uint32_t)__popcll(cm);
@@ -2147,7 +2149,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_small(BuildArgs<T
     // ---- the subtree is complete: its part of the flatten, by the wave that still has it in its caches (BVHGPU_TUNE_FLATTEN_INLINE).  FLAT
     //      and WIDE only read records of the subtree itself and of the item's parent (written by the launch that queued the item); TRAV
     //      reads a node BEHIND the subtree and stays with k_flatten.
-    if constexpr (sizeof(T) == 4) if (a.fl_parts != 0u) {   // (uniform; f32 only: an f64 wide node is 64 registers)
+    if constexpr (FLAT_INLINE && sizeof(T) == 4) if (a.fl_parts != 0u) {   // (uniform; f32 only: an f64 wide node is 64 registers)
         // this wave's own stores (node records, start / count / slot) are read back below: workgroup scope is enough (one CU, one L1) — a device-scope
         // fence writes the XCD's L2 back (0.1 ms per item on this chip)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -2314,7 +2316,8 @@ template <typename T> static void run_lower_tiers(bvhgpu_tree* t, const BuildArg
         if (t->n <= MID_SCENE_SPLIT) hipLaunchKernelGGL((k_mid<T, MidSmallScene<T>>), dim3(g.mid2_grid), dim3(MidSmallScene<T>::THREADS), 0, st, a, mid2_done);
         else hipLaunchKernelGGL((k_mid<T, MidLargeScene<T>>), dim3(g.mid2_grid), dim3(MidLargeScene<T>::THREADS), 0, st, a, mid2_done);
     }
-    hipLaunchKernelGGL(k_small<T>, dim3(g.small_grid), dim3(256), 0, st, a, small_done);
+    if (a.fl_parts != 0u) hipLaunchKernelGGL((k_small<T, true>), dim3(g.small_grid), dim3(256), 0, st, a, small_done);
+    else hipLaunchKernelGGL((k_small<T, false>), dim3(g.small_grid), dim3(256), 0, st, a, small_done);
 }
 
 // redo: build_finalize builds the SAME generation again (the persistent level tier gave up): no new generation, the tree's own AABB copy
